@@ -1,0 +1,144 @@
+/*
+ * kpl.h -- C-ABI of libkpl: the MI355X (gfx950) engine for the scoring path of
+ * pcl::keypoints::KeypointLearningDetector (feature -> random forest -> radius NMS).
+ *
+ * This is the drop-in boundary.  The reference has no FFI; its boundary is the C++ class
+ * declared in /root/reference/include/KeypointLearning.h:55-206.  Each entry point below names
+ * the reference member it replaces; include/KeypointLearning.h in this repo is the same class
+ * re-implemented on top of these calls, and INTEGRATION.md shows the binding a maintainer of
+ * the reference would add.
+ *
+ * Conventions: plain pointers and sizes only; every function returns a kpl_status (0 = OK) and
+ * never throws; kpl_last_error() gives the message of the last failure on that handle.  A
+ * handle is not thread safe; distinct handles are independent (one handle per view/stream).
+ * All arrays are caller owned; the handle owns its forest and (grow-only) device scratch.
+ * There is NO CPU fallback: without a usable HIP device every compute call fails with
+ * KPL_ERR_DEVICE.
+ */
+#ifndef KPL_H
+#define KPL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KPL_VERSION 100
+
+typedef enum kpl_status {
+    KPL_OK = 0,
+    KPL_ERR_INVALID_ARG = 1,   /* null pointer, negative size, bad stride, radius <= 0 ...      */
+    KPL_ERR_NO_FOREST = 2,     /* detect before loadForest                                     */
+    KPL_ERR_FOREST_PARSE = 3,  /* malformed YAML / unsupported forest                          */
+    KPL_ERR_VAR_COUNT = 4,     /* n_annulus * n_bins != forest var_count                       */
+    KPL_ERR_GRID_TOO_LARGE = 5,/* bounding box / radius needs more than 2^28 cells             */
+    KPL_ERR_CAPACITY = 6,      /* kp_cap too small; kp_count still reports the needed size     */
+    KPL_ERR_DEVICE = 7,        /* HIP error or no device                                       */
+    KPL_ERR_UNSUPPORTED = 8,   /* k-search mode, surface != input, > 255 features ...          */
+    KPL_ERR_IO = 9,            /* file cannot be read                                          */
+    KPL_ERR_NO_CLOUD = 10      /* compute before a cloud was bound                             */
+} kpl_status;
+
+typedef struct kpl_detector kpl_detector;
+
+/* Parameters = the state set by the reference's ctor and setters
+ * (/root/reference/include/KeypointLearning.h:81-90, impl/KeypointLearning.hpp:60-113) plus
+ * pcl::Keypoint::setRadiusSearch (used at /root/reference/src/main_test_detector.cpp:130). */
+typedef struct kpl_params {
+    int n_annulus;                    /* setNAnnulus, default 5                               */
+    int n_bins;                       /* setNBins, default 10                                 */
+    double radius_search;             /* setRadiusSearch: feature support radius (required)   */
+    double non_max_radius;            /* setNonMaxRadius, default 0                           */
+    double prediction_th;             /* setPredictionThreshold, default 0.5                  */
+    int non_maxima;                   /* setNonMaxima, default 1                              */
+    int non_maxima_draws_remove;      /* setNonMaximaDrawsRemove, default 1                   */
+    float non_maxima_draws_threshold; /* setNonMaximaDrawsThreshold (uninitialised in the
+                                         reference ctor; 0 here)                              */
+} kpl_params;
+
+/* Counters for the algorithmic-bytes model of SURVEY.md 8(d), filled by kpl_collect_stats. */
+typedef struct kpl_stats {
+    int64_t n_points;        /* points handed in                                              */
+    int64_t n_scored;        /* points with finite xyz and normal                             */
+    int64_t n_thresholded;   /* scored points with score >= prediction_th                     */
+    int64_t sum_kf;          /* sum over scored points of feature-radius neighbors (incl self)*/
+    int64_t sum_kn;          /* sum over thresholded points of NMS-radius neighbors           */
+    int64_t sum_depth;       /* forest nodes visited (internal + leaf), all trees, all points */
+    int64_t n_keypoints;
+    int64_t n_cells;
+} kpl_stats;
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+/* ctor of KeypointLearningDetector (KeypointLearning.h:81-90); `device` = HIP device ordinal. */
+int kpl_create(kpl_detector **out, int device);
+/* dtor (KeypointLearning.h:93-97). */
+void kpl_destroy(kpl_detector *h);
+const char *kpl_last_error(const kpl_detector *h);
+const char *kpl_status_string(int status);
+int kpl_version(void);
+
+/* ---- parameters ----------------------------------------------------------------------- */
+void kpl_default_params(kpl_params *p);
+int kpl_set_params(kpl_detector *h, const kpl_params *p);   /* the setters, hpp:60-113        */
+int kpl_get_params(const kpl_detector *h, kpl_params *p);
+
+/* ---- forest: loadForest (hpp:159-176) = cv::ml::RTrees::load ---------------------------- */
+/* OpenCV RTrees YAML, plain or gzip (sniffed by magic bytes, not by extension). */
+int kpl_load_forest_file(kpl_detector *h, const char *path);
+int kpl_load_forest_memory(kpl_detector *h, const void *data, size_t len);
+/* Same forest handed over as node arrays (children by global node index, var = -1 for a leaf). */
+int kpl_load_forest_arrays(kpl_detector *h, int ntrees, int nnodes, int var_count,
+                           const int *root, const int *var, const float *thr,
+                           const int *left, const int *right, const double *value);
+/* getRoots().size() (hpp:172, :271) and friends. */
+int kpl_forest_info(const kpl_detector *h, int *ntrees, int *var_count, int64_t *nnodes,
+                    int *max_depth);
+
+/* ---- compute(): host buffers ------------------------------------------------------------
+ * pcl::Keypoint::compute -> initCompute (hpp:116-156) + detectKeypoints (hpp:179-263).
+ * xyz / normals point at the first float of element 0; strides are in bytes (>= 12), so
+ * pcl::PointXYZ (16 B) and pcl::Normal (32 B) arrays are passed as they are.
+ * scores_out (optional, n floats): forest response per input point in INPUT index space, NaN
+ * for a point whose xyz or normal is not finite.  kp_idx_out receives the keypoint indices in
+ * ascending order (= keypoints_indices_), kp_count their number.  If kp_count > kp_cap the first
+ * kp_cap are written and KPL_ERR_CAPACITY is returned. */
+int kpl_detect(kpl_detector *h, const void *xyz, size_t xyz_stride,
+               const void *normals, size_t normals_stride, int n,
+               float *scores_out, int *kp_idx_out, int kp_cap, int *kp_count);
+
+/* computePointsForTrainingFeatures (hpp:299-318): features of the listed points, m x
+ * (n_annulus*n_bins) floats, row major.  A row of a point with non-finite xyz is NaN. */
+int kpl_compute_features(kpl_detector *h, const void *xyz, size_t xyz_stride,
+                         const void *normals, size_t normals_stride, int n,
+                         const int *indices, int m, float *features_out);
+
+/* ---- compute(): device-resident buffers, asynchronous -------------------------------------
+ * Same path for callers that already hold the view in HBM (the bench, multi-view batches).
+ * `stream` is a hipStream_t (NULL = default stream).  kpl_bind_cloud_device only records the
+ * pointers.  kpl_compute_device enqueues index build + scoring + NMS + compaction on `stream`;
+ * d_kp_count (1 int) and d_kp_idx (kp_cap ints) are written on the device; d_scores optional.
+ * kpl_build_index_device / kpl_detect_device are the two halves (initCompute / detectKeypoints)
+ * for callers that want them timed apart. */
+int kpl_bind_cloud_device(kpl_detector *h, const void *d_xyz, size_t xyz_stride,
+                          const void *d_normals, size_t normals_stride, int n);
+int kpl_build_index_device(kpl_detector *h, void *stream);
+int kpl_detect_device(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap,
+                      int *d_kp_count, void *stream);
+int kpl_compute_device(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap,
+                       int *d_kp_count, void *stream);
+int kpl_compute_features_device(kpl_detector *h, const int *d_indices, int m,
+                                float *d_features, void *stream);
+
+/* Instrumented pass over the bound cloud (not for timing): fills the counters above. */
+int kpl_collect_stats(kpl_detector *h, kpl_stats *out, void *stream);
+
+/* computeCloudResolution (/root/reference/include/impl/point_cloud_utilities.hpp:120-151). */
+int kpl_cloud_resolution(kpl_detector *h, const void *xyz, size_t xyz_stride, int n,
+                         double *resolution);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KPL_H */

@@ -1,0 +1,273 @@
+"""keypoint-learning_amd -- MI355X-native engine for the scoring path of
+pcl::keypoints::KeypointLearningDetector (feature -> random forest -> radius NMS).
+
+The product is the C-ABI shared library `libkpl.so` (include/kpl.h; HIP kernels in csrc/).
+This module is a thin ctypes binding of that ABI plus `KeypointLearningDetector`, a Python
+mirror of the reference class (/root/reference/include/KeypointLearning.h:55-206) used by the
+tests and the bench.  It never computes anything itself and has no CPU fallback: if the HIP
+library is missing or no GPU is usable, it raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkpl.so")
+
+OK, ERR_INVALID_ARG, ERR_NO_FOREST, ERR_FOREST_PARSE, ERR_VAR_COUNT, ERR_GRID_TOO_LARGE, \
+    ERR_CAPACITY, ERR_DEVICE, ERR_UNSUPPORTED, ERR_IO, ERR_NO_CLOUD = range(11)
+
+
+class KplError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("kpl status %d: %s" % (status, message))
+        self.status = status
+
+
+class Params(C.Structure):
+    _fields_ = [("n_annulus", C.c_int), ("n_bins", C.c_int), ("radius_search", C.c_double),
+                ("non_max_radius", C.c_double), ("prediction_th", C.c_double),
+                ("non_maxima", C.c_int), ("non_maxima_draws_remove", C.c_int),
+                ("non_maxima_draws_threshold", C.c_float)]
+
+
+class Stats(C.Structure):
+    _fields_ = [(k, C.c_int64) for k in ("n_points", "n_scored", "n_thresholded", "sum_kf",
+                                         "sum_kn", "sum_depth", "n_keypoints", "n_cells")]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+# every symbol include/kpl.h declares: (name, restype, argtypes)
+_vp, _ip, _fp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float)
+SYMBOLS = {
+    "kpl_version": (C.c_int, []),
+    "kpl_status_string": (C.c_char_p, [C.c_int]),
+    "kpl_default_params": (None, [C.POINTER(Params)]),
+    "kpl_create": (C.c_int, [C.POINTER(_vp), C.c_int]),
+    "kpl_destroy": (None, [_vp]),
+    "kpl_last_error": (C.c_char_p, [_vp]),
+    "kpl_set_params": (C.c_int, [_vp, C.POINTER(Params)]),
+    "kpl_get_params": (C.c_int, [_vp, C.POINTER(Params)]),
+    "kpl_load_forest_file": (C.c_int, [_vp, C.c_char_p]),
+    "kpl_load_forest_memory": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "kpl_load_forest_arrays": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _ip, _ip, _fp, _ip, _ip,
+                                         C.POINTER(C.c_double)]),
+    "kpl_forest_info": (C.c_int, [_vp, _ip, _ip, C.POINTER(C.c_int64), _ip]),
+    "kpl_detect": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_int, _vp, _vp, C.c_int, _ip]),
+    "kpl_compute_features": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_int, _vp,
+                                       C.c_int, _vp]),
+    "kpl_bind_cloud_device": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_int]),
+    "kpl_build_index_device": (C.c_int, [_vp, _vp]),
+    "kpl_detect_device": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
+    "kpl_compute_device": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
+    "kpl_compute_features_device": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),
+    "kpl_collect_stats": (C.c_int, [_vp, C.POINTER(Stats), _vp]),
+    "kpl_cloud_resolution": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
+}
+
+_lib = None
+
+
+def load_library():
+    """dlopen libkpl.so and bind every symbol of include/kpl.h.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libkpl.so is not built: run `python keypoint-learning_amd/build.py` "
+                          "(there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class KeypointLearningDetector:
+    """Mirror of pcl::keypoints::KeypointLearningDetector over the C-ABI.
+
+    Same constructor defaults and setter names as the reference class
+    (/root/reference/include/KeypointLearning.h:81-155); clouds are numpy arrays [n,3] (or
+    [n,k>=3] rows whose first three floats are xyz / normal, e.g. a PointXYZ array viewed as
+    [n,4]).
+    """
+
+    def __init__(self, prediction_th=0.5, non_maxima=True, non_maxima_draws_remove=True,
+                 non_max_radius=0.0, n_annulus=5, n_bins=10, device=0):
+        self._lib = load_library()
+        h = _vp()
+        rc = self._lib.kpl_create(C.byref(h), device)
+        if rc != OK:
+            raise KplError(rc, "kpl_create failed (is a HIP device visible?): "
+                           + self._lib.kpl_status_string(rc).decode())
+        self._h = h
+        self._p = Params()
+        self._lib.kpl_default_params(C.byref(self._p))
+        self._p.prediction_th = prediction_th
+        self._p.non_maxima = int(non_maxima)
+        self._p.non_maxima_draws_remove = int(non_maxima_draws_remove)
+        self._p.non_max_radius = non_max_radius
+        self._p.n_annulus = n_annulus
+        self._p.n_bins = n_bins
+        self._cloud = self._normals = None
+        self._keep = []
+        self.keypoints_indices = np.zeros(0, dtype=np.int32)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.kpl_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    # -- error plumbing ----------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != OK:
+            raise KplError(rc, self._lib.kpl_last_error(self._h).decode())
+
+    def _push(self):
+        self._check(self._lib.kpl_set_params(self._h, C.byref(self._p)))
+
+    # -- the reference's setters -------------------------------------------------------------
+    def setInputCloud(self, cloud):
+        cloud = _f32(cloud)
+        if self._normals is not None and self._cloud is not None and cloud is not self._cloud:
+            self._normals = None            # impl/KeypointLearning.hpp:52-55
+        self._cloud = cloud
+
+    def setNormals(self, normals):
+        self._normals = _f32(normals)
+
+    def setNonMaxima(self, v):
+        self._p.non_maxima = int(v)
+
+    def setNonMaximaDrawsRemove(self, v):
+        self._p.non_maxima_draws_remove = int(v)
+
+    def setNonMaximaDrawsThreshold(self, v):
+        self._p.non_maxima_draws_threshold = v
+
+    def setPredictionThreshold(self, th):
+        self._p.prediction_th = th
+
+    def setNonMaxRadius(self, r):
+        self._p.non_max_radius = r
+
+    def setNAnnulus(self, n):
+        self._p.n_annulus = n
+
+    def setNBins(self, n):
+        self._p.n_bins = n
+
+    def setRadiusSearch(self, r):
+        self._p.radius_search = r
+
+    def loadForest(self, path):
+        rc = self._lib.kpl_load_forest_file(self._h, os.fsencode(path))
+        return rc == OK
+
+    def loadForestMemory(self, data):
+        buf = (C.c_char * len(data)).from_buffer_copy(data)
+        self._check(self._lib.kpl_load_forest_memory(self._h, C.cast(buf, _vp), len(data)))
+
+    def loadForestArrays(self, root, var, thr, left, right, value, var_count):
+        root, var, left, right = (np.ascontiguousarray(a, dtype=np.int32) for a in (root, var, left, right))
+        thr = _f32(thr)
+        value = np.ascontiguousarray(value, dtype=np.float64)
+        self._check(self._lib.kpl_load_forest_arrays(
+            self._h, len(root), len(var), int(var_count),
+            root.ctypes.data_as(_ip), var.ctypes.data_as(_ip), thr.ctypes.data_as(_fp),
+            left.ctypes.data_as(_ip), right.ctypes.data_as(_ip),
+            value.ctypes.data_as(C.POINTER(C.c_double))))
+
+    def forestInfo(self):
+        nt, vc, md, nn = C.c_int(), C.c_int(), C.c_int(), C.c_int64()
+        self._check(self._lib.kpl_forest_info(self._h, C.byref(nt), C.byref(vc), C.byref(nn), C.byref(md)))
+        return {"ntrees": nt.value, "var_count": vc.value, "nnodes": nn.value, "max_depth": md.value}
+
+    def lastError(self):
+        return self._lib.kpl_last_error(self._h).decode()
+
+    # -- compute -----------------------------------------------------------------------------
+    @staticmethod
+    def _rows(a):
+        a = _f32(a)
+        if a.ndim != 2 or a.shape[1] < 3:
+            raise ValueError("expected an [n, >=3] float32 array")
+        return a, a.shape[1] * 4
+
+    def compute(self, with_scores=True):
+        """pcl::Keypoint::compute.  Returns (keypoints [k,4] = x,y,z,score, scores [n] or None);
+        the indices are left in `keypoints_indices` like getKeypointsIndices()."""
+        if self._cloud is None:
+            raise KplError(ERR_NO_CLOUD, "no input cloud")
+        if self._normals is None:
+            raise KplError(ERR_UNSUPPORTED, "normals must be given (setNormals): normal estimation "
+                           "inside the detector is outside the accelerated path")
+        xyz, xs = self._rows(self._cloud)
+        nrm, ns = self._rows(self._normals)
+        n = xyz.shape[0]
+        if nrm.shape[0] != n:
+            raise KplError(ERR_INVALID_ARG, "the number of normals does not match the number of "
+                           "input points")   # impl/KeypointLearning.hpp:149-153
+        self._push()
+        scores = np.empty(max(n, 1), dtype=np.float32) if with_scores else None
+        kp = np.empty(max(n, 1), dtype=np.int32)
+        cnt = C.c_int()
+        rc = self._lib.kpl_detect(self._h, xyz.ctypes.data, xs, nrm.ctypes.data, ns, n,
+                                  scores.ctypes.data if with_scores else None,
+                                  kp.ctypes.data, n, C.byref(cnt))
+        self._check(rc)
+        self.keypoints_indices = kp[:cnt.value].copy()
+        if with_scores:
+            scores = scores[:n]
+            out = np.concatenate([xyz[self.keypoints_indices, :3],
+                                  scores[self.keypoints_indices, None]], axis=1)
+            return out, scores
+        return xyz[self.keypoints_indices, :3], None
+
+    def getKeypointsIndices(self):
+        return self.keypoints_indices
+
+    def computePointsForTrainingFeatures(self, indices):
+        xyz, xs = self._rows(self._cloud)
+        nrm, ns = self._rows(self._normals)
+        idx = np.ascontiguousarray(indices, dtype=np.int32)
+        self._push()
+        F = self._p.n_annulus * self._p.n_bins
+        out = np.empty((len(idx), F), dtype=np.float32)
+        self._check(self._lib.kpl_compute_features(self._h, xyz.ctypes.data, xs, nrm.ctypes.data, ns,
+                                                   xyz.shape[0], idx.ctypes.data, len(idx),
+                                                   out.ctypes.data))
+        return out
+
+    # -- device-resident path (pointers are raw device addresses, e.g. torch .data_ptr()) -----
+    def bindCloudDevice(self, d_xyz, xyz_stride, d_nrm, nrm_stride, n):
+        self._check(self._lib.kpl_bind_cloud_device(self._h, d_xyz, xyz_stride, d_nrm, nrm_stride, n))
+
+    def buildIndexDevice(self, stream=None):
+        self._push()
+        self._check(self._lib.kpl_build_index_device(self._h, stream))
+
+    def detectDevice(self, d_scores, d_kp_idx, kp_cap, d_kp_count, stream=None):
+        self._push()
+        self._check(self._lib.kpl_detect_device(self._h, d_scores, d_kp_idx, kp_cap, d_kp_count, stream))
+
+    def computeDevice(self, d_scores, d_kp_idx, kp_cap, d_kp_count, stream=None):
+        self._push()
+        self._check(self._lib.kpl_compute_device(self._h, d_scores, d_kp_idx, kp_cap, d_kp_count, stream))
+
+    def collectStats(self, stream=None):
+        self._push()
+        st = Stats()
+        self._check(self._lib.kpl_collect_stats(self._h, C.byref(st), stream))
+        return st.as_dict()

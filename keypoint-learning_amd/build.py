@@ -1,0 +1,63 @@
+"""Builds libkpl.so (the C-ABI of include/kpl.h) for gfx950 with hipcc, in tree.
+
+`python keypoint-learning_amd/build.py` or `build()` from __graft_entry__.  hipcc cross-compiles
+without a GPU.  -ffp-contract=off is part of the specification of the kernels (bit-exact float
+arithmetic); do not add -ffast-math.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libkpl.so")
+SOURCES = ["kernels.hip", "api.cpp", "forest.cpp"]
+HEADERS = ["kernels.h", "forest.h", os.path.join("..", "..", "include", "kpl.h")]
+TOOLS = {"TestDetector": ["test_detector_main.cpp"]}
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+         "-fno-fast-math", "-Wall", "-Wno-unused-result", "-x", "hip"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=False):
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    if force or _stale(LIB, deps):
+        objs = []
+        for s in srcs:
+            o = os.path.splitext(s)[0] + ".o"
+            if force or _stale(o, deps):
+                cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+                if verbose:
+                    print(" ".join(cmd))
+                subprocess.check_call(cmd)
+            objs.append(o)
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + \
+              ["-lz", "-Wl,-rpath,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    for name, tsrcs in TOOLS.items():
+        tpaths = [os.path.join(CSRC, s) for s in tsrcs]
+        if not all(os.path.exists(p) for p in tpaths):
+            continue
+        exe = os.path.join(HERE, name)
+        if force or _stale(exe, tpaths + [LIB, os.path.join(HERE, "..", "include", "KeypointLearning.h")]):
+            cmd = ["g++", "-O2", "-std=c++14", "-I", os.path.join(HERE, "..", "include")] + tpaths + \
+                  ["-o", exe, "-L", HERE, "-lkpl", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,548 @@
+// api.cpp -- the C-ABI of libkpl (include/kpl.h): handle, parameter/forest state, and the
+// orchestration of the gfx950 kernels.  Host code only; every compute step is a HIP kernel in
+// kernels.hip -- there is no CPU fallback.
+//
+// Reference counterparts: pcl::keypoints::KeypointLearningDetector
+// (/root/reference/include/KeypointLearning.h:55-206, include/impl/KeypointLearning.hpp).
+#include "../../include/kpl.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "forest.h"
+#include "kernels.h"
+
+using namespace kpl;
+
+namespace {
+
+constexpr int64_t kMaxCells = (int64_t)1 << 28;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+}  // namespace
+
+struct kpl_detector {
+    int device = 0;
+    std::string err;
+    kpl_params prm;
+
+    bool has_forest = false;
+    ForestModel model;
+    FlatForest flat;
+    DevBuf d_nodes, d_roots;
+
+    // bound view
+    const char *d_xyz = nullptr, *d_nrm = nullptr;
+    size_t xs = 0, ns = 0;
+    int n = 0;
+    bool bound = false;
+    bool index_valid = false;
+    double index_radius = 0.0;
+
+    GridDesc grid{};
+    DevBuf stage_xyz, stage_nrm, stage_idx, stage_feat;
+    DevBuf bbox, cid, cnt, cell_start, cursor, tmp_idx, scan_tmp, pts, nrm, pos_of;
+    DevBuf score_sorted, flags, prefix, stats, out_scores, out_kp, out_count;
+    uint32_t *h_bbox = nullptr;   // pinned
+    int *h_count = nullptr;       // pinned
+};
+
+namespace {
+
+int fail(kpl_detector *h, int code, const char *fmt, ...) {
+    if (h) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof(buf), fmt, ap);
+        va_end(ap);
+        h->err = buf;
+    }
+    return code;
+}
+
+#define KPL_HIP(h, call)                                                                       \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(h, KPL_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(e_));     \
+    } while (0)
+
+int use_device(kpl_detector *h) {
+    KPL_HIP(h, hipSetDevice(h->device));
+    return KPL_OK;
+}
+
+FeatDesc make_feat(const kpl_params &p) {
+    FeatDesc f;
+    f.A = p.n_annulus;
+    f.B = p.n_bins;
+    f.F = p.n_annulus * p.n_bins;
+    f.support = (float)p.radius_search;       // double search_radius_ -> float `support`
+    f.ann_dim = f.support / (float)f.A;       // cpp:43
+    f.ann_half = f.ann_dim / 2;               // cpp:52
+    f.bin_dim = 2 / (float)f.B;               // cpp:75
+    f.bin_half = f.bin_dim / 2;               // cpp:83
+    f.r2 = (float)(p.radius_search * p.radius_search);
+    f.rr = (float)(p.radius_search * (1.0 + 1.0 / 1024.0));
+    return f;
+}
+
+NmsDesc make_nms(const kpl_params &p) {
+    NmsDesc d;
+    d.r2 = (float)(p.non_max_radius * p.non_max_radius);
+    d.rr = (float)(p.non_max_radius * (1.0 + 1.0 / 1024.0));
+    d.thr = p.prediction_th;
+    d.non_maxima = p.non_maxima;
+    return d;
+}
+
+int check_params_for_compute(kpl_detector *h, bool need_forest) {
+    const kpl_params &p = h->prm;
+    if (!(p.radius_search > 0.0) || !std::isfinite(p.radius_search))
+        return fail(h, KPL_ERR_INVALID_ARG,
+                    "radius_search must be > 0 (k-search mode is not supported: the reference "
+                    "passes search_radius_ == 0 as the annulus support)");
+    if (p.n_annulus < 1 || p.n_bins < 1) return fail(h, KPL_ERR_INVALID_ARG, "n_annulus and n_bins must be >= 1");
+    if ((int64_t)p.n_annulus * p.n_bins > 255)
+        return fail(h, KPL_ERR_UNSUPPORTED, "n_annulus * n_bins must be <= 255");
+    if (!(p.non_max_radius >= 0.0) || !std::isfinite(p.non_max_radius))
+        return fail(h, KPL_ERR_INVALID_ARG, "non_max_radius must be >= 0");
+    if (need_forest) {
+        if (!h->has_forest) return fail(h, KPL_ERR_NO_FOREST, "no forest loaded");
+        if (p.n_annulus * p.n_bins != h->flat.var_count)
+            return fail(h, KPL_ERR_VAR_COUNT, "n_annulus*n_bins = %d but the forest has var_count = %d",
+                        p.n_annulus * p.n_bins, h->flat.var_count);
+    }
+    return KPL_OK;
+}
+
+int install_forest(kpl_detector *h, ForestModel &&m) {
+    FlatForest flat;
+    std::string err;
+    if (!flatten_forest(m, flat, err)) return fail(h, KPL_ERR_FOREST_PARSE, "forest: %s", err.c_str());
+    int rc = use_device(h);
+    if (rc) return rc;
+    KPL_HIP(h, h->d_nodes.ensure(sizeof(FlatNode) * flat.nodes.size()));
+    KPL_HIP(h, h->d_roots.ensure(sizeof(uint32_t) * flat.roots.size()));
+    KPL_HIP(h, hipMemcpy(h->d_nodes.p, flat.nodes.data(), sizeof(FlatNode) * flat.nodes.size(), hipMemcpyHostToDevice));
+    KPL_HIP(h, hipMemcpy(h->d_roots.p, flat.roots.data(), sizeof(uint32_t) * flat.roots.size(), hipMemcpyHostToDevice));
+    h->model = std::move(m);
+    h->flat = std::move(flat);
+    h->has_forest = true;
+    return KPL_OK;
+}
+
+int build_index(kpl_detector *h, hipStream_t st) {
+    int rc = check_params_for_compute(h, false);
+    if (rc) return rc;
+    if (!h->bound) return fail(h, KPL_ERR_NO_CLOUD, "no cloud bound");
+    rc = use_device(h);
+    if (rc) return rc;
+    const int n = h->n;
+    KPL_HIP(h, h->bbox.ensure(6 * sizeof(uint32_t)));
+    launch_bbox(h->d_xyz, h->xs, n, h->bbox.as<uint32_t>(), st);
+    KPL_HIP(h, hipMemcpyAsync(h->h_bbox, h->bbox.p, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    KPL_HIP(h, hipStreamSynchronize(st));
+    float mn[3], mx[3];
+    decode_bbox(h->h_bbox, mn, mx);
+    GridDesc g{};
+    g.h = (float)h->prm.radius_search;
+    const bool any = h->h_bbox[0] != 0xffffffffu && n > 0;
+    int64_t nc = any ? 1 : 0;
+    for (int k = 0; k < 3; ++k) {
+        g.mn[k] = any ? mn[k] : 0.0f;
+        g.dims[k] = 0;
+        if (!any) continue;
+        const float t = std::floor((mx[k] - mn[k]) / g.h);
+        if (!(t < 1.0e9f))
+            return fail(h, KPL_ERR_GRID_TOO_LARGE, "extent / radius too large along axis %d", k);
+        g.dims[k] = (int)t + 1;
+        nc *= g.dims[k];
+        if (nc > kMaxCells)
+            return fail(h, KPL_ERR_GRID_TOO_LARGE, "grid would need more than 2^28 cells");
+    }
+    g.ncells = (int)nc;
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    KPL_HIP(h, h->cid.ensure(sizeof(int) * nn));
+    KPL_HIP(h, h->cnt.ensure(sizeof(int) * ((size_t)nc + 2)));
+    KPL_HIP(h, h->cell_start.ensure(sizeof(int) * ((size_t)nc + 2)));
+    KPL_HIP(h, h->cursor.ensure(sizeof(int) * ((size_t)nc + 2)));
+    KPL_HIP(h, h->tmp_idx.ensure(sizeof(int) * nn));
+    const size_t scan_len = (size_t)(nc > (int64_t)n ? nc : n) + 1;
+    KPL_HIP(h, h->scan_tmp.ensure(sizeof(int) * (scan_len / 4096 + 4)));
+    KPL_HIP(h, h->pts.ensure(sizeof(float4) * nn));
+    KPL_HIP(h, h->nrm.ensure(sizeof(float4) * nn));
+    KPL_HIP(h, h->pos_of.ensure(sizeof(int) * nn));
+    launch_cell_count(h->d_xyz, h->xs, n, g, h->cid.as<int>(), h->cnt.as<int>(), st);
+    launch_exclusive_scan(h->cnt.as<int>(), h->cell_start.as<int>(), g.ncells, h->scan_tmp.as<int>(), st);
+    KPL_HIP(h, hipMemcpyAsync(h->cursor.p, h->cell_start.p, sizeof(int) * ((size_t)nc + 1), hipMemcpyDeviceToDevice, st));
+    launch_scatter(h->cid.as<int>(), n, h->cell_start.as<int>(), h->cursor.as<int>(), h->tmp_idx.as<int>(), st);
+    launch_rank_store(h->d_xyz, h->xs, h->d_nrm, h->ns, n, g, h->cid.as<int>(), h->cell_start.as<int>(),
+                      h->tmp_idx.as<int>(), h->pts.as<float4>(), h->nrm.as<float4>(), h->pos_of.as<int>(), st);
+    KPL_HIP(h, hipGetLastError());
+    h->grid = g;
+    h->index_valid = true;
+    h->index_radius = h->prm.radius_search;
+    return KPL_OK;
+}
+
+int ensure_index(kpl_detector *h, hipStream_t st) {
+    if (h->index_valid && h->index_radius == h->prm.radius_search) return KPL_OK;
+    return build_index(h, st);
+}
+
+int detect_on_device(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, int *d_kp_count,
+                     hipStream_t st, StatsDev *d_stats) {
+    int rc = check_params_for_compute(h, true);
+    if (rc) return rc;
+    if (!h->bound) return fail(h, KPL_ERR_NO_CLOUD, "no cloud bound");
+    if (kp_cap < 0 || !d_kp_count || (kp_cap > 0 && !d_kp_idx))
+        return fail(h, KPL_ERR_INVALID_ARG, "bad keypoint output buffers");
+    if (h->prm.non_maxima && h->prm.non_maxima_draws_remove)
+        return fail(h, KPL_ERR_UNSUPPORTED, "non_maxima_draws_remove = true is not available yet");
+    rc = use_device(h);
+    if (rc) return rc;
+    rc = ensure_index(h, st);
+    if (rc) return rc;
+    const int n = h->n;
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    KPL_HIP(h, h->score_sorted.ensure(sizeof(float) * nn));
+    KPL_HIP(h, h->flags.ensure(sizeof(int) * (nn + 1)));
+    KPL_HIP(h, h->prefix.ensure(sizeof(int) * (nn + 2)));
+    KPL_HIP(h, h->scan_tmp.ensure(sizeof(int) * (nn / 4096 + 4)));
+    const FeatDesc f = make_feat(h->prm);
+    const NmsDesc nd = make_nms(h->prm);
+    ForestDev fd{h->d_nodes.as<uint2>(), h->d_roots.as<uint32_t>(), h->flat.ntrees};
+    if (d_scores) launch_fill_f32(d_scores, NAN, n, st);
+    launch_score(h->pts.as<float4>(), h->nrm.as<float4>(), h->cell_start.as<int>(), h->grid, f, fd, n,
+                 h->score_sorted.as<float>(), d_scores, d_stats, st);
+    launch_nms(h->pts.as<float4>(), h->cell_start.as<int>(), h->grid, nd, h->score_sorted.as<float>(), n,
+               h->flags.as<int>(), d_stats, st);
+    launch_exclusive_scan(h->flags.as<int>(), h->prefix.as<int>(), n, h->scan_tmp.as<int>(), st);
+    launch_compact(h->flags.as<int>(), h->prefix.as<int>(), n, d_kp_idx, kp_cap, d_kp_count, st);
+    KPL_HIP(h, hipGetLastError());
+    return KPL_OK;
+}
+
+int upload_view(kpl_detector *h, const void *xyz, size_t xs, const void *nrm, size_t ns, int n) {
+    if (n < 0 || (n > 0 && (!xyz || !nrm))) return fail(h, KPL_ERR_INVALID_ARG, "null cloud or normals");
+    if (xs < 12 || ns < 12 || (xs & 3) || (ns & 3))
+        return fail(h, KPL_ERR_INVALID_ARG, "strides must be multiples of 4 and >= 12 bytes");
+    int rc = use_device(h);
+    if (rc) return rc;
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    KPL_HIP(h, h->stage_xyz.ensure(nn * xs));
+    KPL_HIP(h, h->stage_nrm.ensure(nn * ns));
+    if (n > 0) {
+        // the last element may be shorter than the stride in the caller's array
+        KPL_HIP(h, hipMemcpy(h->stage_xyz.p, xyz, (size_t)(n - 1) * xs + 12, hipMemcpyHostToDevice));
+        KPL_HIP(h, hipMemcpy(h->stage_nrm.p, nrm, (size_t)(n - 1) * ns + 12, hipMemcpyHostToDevice));
+    }
+    h->d_xyz = h->stage_xyz.as<char>();
+    h->d_nrm = h->stage_nrm.as<char>();
+    h->xs = xs;
+    h->ns = ns;
+    h->n = n;
+    h->bound = true;
+    h->index_valid = false;
+    return KPL_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+int kpl_version(void) { return KPL_VERSION; }
+
+const char *kpl_status_string(int s) {
+    switch (s) {
+        case KPL_OK: return "ok";
+        case KPL_ERR_INVALID_ARG: return "invalid argument";
+        case KPL_ERR_NO_FOREST: return "no forest loaded";
+        case KPL_ERR_FOREST_PARSE: return "forest parse error";
+        case KPL_ERR_VAR_COUNT: return "n_annulus*n_bins does not match the forest";
+        case KPL_ERR_GRID_TOO_LARGE: return "grid too large";
+        case KPL_ERR_CAPACITY: return "output capacity too small";
+        case KPL_ERR_DEVICE: return "HIP device error";
+        case KPL_ERR_UNSUPPORTED: return "unsupported";
+        case KPL_ERR_IO: return "i/o error";
+        case KPL_ERR_NO_CLOUD: return "no cloud bound";
+        default: return "unknown status";
+    }
+}
+
+void kpl_default_params(kpl_params *p) {
+    if (!p) return;
+    p->n_annulus = 5;                       // KeypointLearning.h:81
+    p->n_bins = 10;
+    p->radius_search = 0.0;
+    p->non_max_radius = 0.0;
+    p->prediction_th = 0.5f;
+    p->non_maxima = 1;
+    p->non_maxima_draws_remove = 1;
+    p->non_maxima_draws_threshold = 0.0f;
+}
+
+int kpl_create(kpl_detector **out, int device) {
+    if (!out) return KPL_ERR_INVALID_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count)
+        return KPL_ERR_DEVICE;
+    kpl_detector *h = new (std::nothrow) kpl_detector();
+    if (!h) return KPL_ERR_DEVICE;
+    h->device = device;
+    kpl_default_params(&h->prm);
+    if (hipSetDevice(device) != hipSuccess ||
+        hipHostMalloc((void **)&h->h_bbox, 6 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void **)&h->h_count, 16 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+        delete h;
+        return KPL_ERR_DEVICE;
+    }
+    *out = h;
+    return KPL_OK;
+}
+
+void kpl_destroy(kpl_detector *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    DevBuf *bufs[] = {&h->d_nodes, &h->d_roots, &h->stage_xyz, &h->stage_nrm, &h->stage_idx, &h->stage_feat,
+                      &h->bbox, &h->cid, &h->cnt, &h->cell_start, &h->cursor, &h->tmp_idx, &h->scan_tmp,
+                      &h->pts, &h->nrm, &h->pos_of, &h->score_sorted, &h->flags, &h->prefix, &h->stats,
+                      &h->out_scores, &h->out_kp, &h->out_count};
+    for (DevBuf *b : bufs) b->release();
+    if (h->h_bbox) (void)hipHostFree(h->h_bbox);
+    if (h->h_count) (void)hipHostFree(h->h_count);
+    delete h;
+}
+
+const char *kpl_last_error(const kpl_detector *h) { return h ? h->err.c_str() : "null handle"; }
+
+int kpl_set_params(kpl_detector *h, const kpl_params *p) {
+    if (!h || !p) return KPL_ERR_INVALID_ARG;
+    if (p->n_annulus < 1 || p->n_bins < 1) return fail(h, KPL_ERR_INVALID_ARG, "n_annulus and n_bins must be >= 1");
+    h->prm = *p;
+    return KPL_OK;
+}
+
+int kpl_get_params(const kpl_detector *h, kpl_params *p) {
+    if (!h || !p) return KPL_ERR_INVALID_ARG;
+    *p = h->prm;
+    return KPL_OK;
+}
+
+int kpl_load_forest_memory(kpl_detector *h, const void *data, size_t len) {
+    if (!h) return KPL_ERR_INVALID_ARG;
+    if (!data || len == 0) return fail(h, KPL_ERR_INVALID_ARG, "empty forest buffer");
+    std::string text, err;
+    if (!inflate_if_gzip(data, len, text, err)) return fail(h, KPL_ERR_FOREST_PARSE, "%s", err.c_str());
+    ForestModel m;
+    if (!parse_forest_yaml(text.data(), text.size(), m, err)) return fail(h, KPL_ERR_FOREST_PARSE, "%s", err.c_str());
+    return install_forest(h, std::move(m));
+}
+
+int kpl_load_forest_file(kpl_detector *h, const char *path) {
+    if (!h) return KPL_ERR_INVALID_ARG;
+    if (!path) return fail(h, KPL_ERR_INVALID_ARG, "null path");
+    std::string text, err;
+    if (!read_maybe_gzip(path, text, err)) {
+        // impl/KeypointLearning.hpp:165-168: "impossible to load random forest"
+        return fail(h, err.rfind("cannot open", 0) == 0 ? KPL_ERR_IO : KPL_ERR_FOREST_PARSE, "%s", err.c_str());
+    }
+    ForestModel m;
+    if (!parse_forest_yaml(text.data(), text.size(), m, err)) return fail(h, KPL_ERR_FOREST_PARSE, "%s: %s", path, err.c_str());
+    return install_forest(h, std::move(m));
+}
+
+int kpl_load_forest_arrays(kpl_detector *h, int ntrees, int nnodes, int var_count, const int *root,
+                           const int *var, const float *thr, const int *left, const int *right,
+                           const double *value) {
+    if (!h) return KPL_ERR_INVALID_ARG;
+    if (ntrees <= 0 || nnodes <= 0 || !root || !var || !thr || !left || !right || !value)
+        return fail(h, KPL_ERR_INVALID_ARG, "null or empty forest arrays");
+    ForestModel m;
+    m.var_count = var_count;
+    m.root.assign(root, root + ntrees);
+    m.var.assign(var, var + nnodes);
+    m.thr.assign(thr, thr + nnodes);
+    m.left.assign(left, left + nnodes);
+    m.right.assign(right, right + nnodes);
+    m.value.assign(value, value + nnodes);
+    return install_forest(h, std::move(m));
+}
+
+int kpl_forest_info(const kpl_detector *h, int *ntrees, int *var_count, int64_t *nnodes, int *max_depth) {
+    if (!h) return KPL_ERR_INVALID_ARG;
+    if (!h->has_forest) return KPL_ERR_NO_FOREST;
+    if (ntrees) *ntrees = h->flat.ntrees;
+    if (var_count) *var_count = h->flat.var_count;
+    if (nnodes) *nnodes = (int64_t)h->flat.nodes.size();
+    if (max_depth) *max_depth = h->flat.max_depth;
+    return KPL_OK;
+}
+
+int kpl_bind_cloud_device(kpl_detector *h, const void *d_xyz, size_t xyz_stride, const void *d_normals,
+                          size_t normals_stride, int n) {
+    if (!h) return KPL_ERR_INVALID_ARG;
+    if (n < 0 || (n > 0 && (!d_xyz || !d_normals))) return fail(h, KPL_ERR_INVALID_ARG, "null cloud or normals");
+    if (xyz_stride < 12 || normals_stride < 12 || (xyz_stride & 3) || (normals_stride & 3))
+        return fail(h, KPL_ERR_INVALID_ARG, "strides must be multiples of 4 and >= 12 bytes");
+    h->d_xyz = (const char *)d_xyz;
+    h->d_nrm = (const char *)d_normals;
+    h->xs = xyz_stride;
+    h->ns = normals_stride;
+    h->n = n;
+    h->bound = true;
+    h->index_valid = false;
+    return KPL_OK;
+}
+
+int kpl_build_index_device(kpl_detector *h, void *stream) {
+    if (!h) return KPL_ERR_INVALID_ARG;
+    return build_index(h, (hipStream_t)stream);
+}
+
+int kpl_detect_device(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, int *d_kp_count, void *stream) {
+    if (!h) return KPL_ERR_INVALID_ARG;
+    return detect_on_device(h, d_scores, d_kp_idx, kp_cap, d_kp_count, (hipStream_t)stream, nullptr);
+}
+
+int kpl_compute_device(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, int *d_kp_count, void *stream) {
+    if (!h) return KPL_ERR_INVALID_ARG;
+    int rc = check_params_for_compute(h, true);
+    if (rc) return rc;
+    rc = build_index(h, (hipStream_t)stream);
+    if (rc) return rc;
+    return detect_on_device(h, d_scores, d_kp_idx, kp_cap, d_kp_count, (hipStream_t)stream, nullptr);
+}
+
+int kpl_compute_features_device(kpl_detector *h, const int *d_indices, int m, float *d_features, void *stream) {
+    if (!h) return KPL_ERR_INVALID_ARG;
+    if (m < 0 || (m > 0 && (!d_indices || !d_features))) return fail(h, KPL_ERR_INVALID_ARG, "null index or feature buffer");
+    int rc = check_params_for_compute(h, false);
+    if (rc) return rc;
+    if (!h->bound) return fail(h, KPL_ERR_NO_CLOUD, "no cloud bound");
+    rc = use_device(h);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    rc = ensure_index(h, st);
+    if (rc) return rc;
+    launch_features(h->pts.as<float4>(), h->nrm.as<float4>(), h->cell_start.as<int>(), h->pos_of.as<int>(),
+                    h->grid, make_feat(h->prm), d_indices, m, h->n, d_features, st);
+    KPL_HIP(h, hipGetLastError());
+    return KPL_OK;
+}
+
+int kpl_detect(kpl_detector *h, const void *xyz, size_t xyz_stride, const void *normals, size_t normals_stride,
+               int n, float *scores_out, int *kp_idx_out, int kp_cap, int *kp_count) {
+    if (!h) return KPL_ERR_INVALID_ARG;
+    if (!kp_count || kp_cap < 0 || (kp_cap > 0 && !kp_idx_out)) return fail(h, KPL_ERR_INVALID_ARG, "bad keypoint output buffers");
+    *kp_count = 0;
+    int rc = check_params_for_compute(h, true);
+    if (rc) return rc;
+    rc = upload_view(h, xyz, xyz_stride, normals, normals_stride, n);
+    if (rc) return rc;
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    KPL_HIP(h, h->out_scores.ensure(sizeof(float) * nn));
+    KPL_HIP(h, h->out_kp.ensure(sizeof(int) * nn));
+    KPL_HIP(h, h->out_count.ensure(sizeof(int)));
+    hipStream_t st = nullptr;
+    rc = build_index(h, st);
+    if (rc) return rc;
+    rc = detect_on_device(h, scores_out ? h->out_scores.as<float>() : nullptr, h->out_kp.as<int>(), n,
+                          h->out_count.as<int>(), st, nullptr);
+    if (rc) return rc;
+    KPL_HIP(h, hipMemcpyAsync(h->h_count, h->out_count.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    KPL_HIP(h, hipStreamSynchronize(st));
+    const int count = h->h_count[0];
+    *kp_count = count;
+    const int ncopy = count < kp_cap ? count : kp_cap;
+    if (ncopy > 0) KPL_HIP(h, hipMemcpy(kp_idx_out, h->out_kp.p, sizeof(int) * (size_t)ncopy, hipMemcpyDeviceToHost));
+    if (scores_out && n > 0) KPL_HIP(h, hipMemcpy(scores_out, h->out_scores.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
+    if (count > kp_cap) return fail(h, KPL_ERR_CAPACITY, "%d keypoints but capacity %d", count, kp_cap);
+    return KPL_OK;
+}
+
+int kpl_compute_features(kpl_detector *h, const void *xyz, size_t xyz_stride, const void *normals,
+                         size_t normals_stride, int n, const int *indices, int m, float *features_out) {
+    if (!h) return KPL_ERR_INVALID_ARG;
+    if (m < 0 || (m > 0 && (!indices || !features_out))) return fail(h, KPL_ERR_INVALID_ARG, "null index or feature buffer");
+    int rc = check_params_for_compute(h, false);
+    if (rc) return rc;
+    rc = upload_view(h, xyz, xyz_stride, normals, normals_stride, n);
+    if (rc) return rc;
+    if (m == 0) return KPL_OK;
+    const size_t F = (size_t)h->prm.n_annulus * h->prm.n_bins;
+    KPL_HIP(h, h->stage_idx.ensure(sizeof(int) * (size_t)m));
+    KPL_HIP(h, h->stage_feat.ensure(sizeof(float) * (size_t)m * F));
+    KPL_HIP(h, hipMemcpy(h->stage_idx.p, indices, sizeof(int) * (size_t)m, hipMemcpyHostToDevice));
+    rc = kpl_compute_features_device(h, h->stage_idx.as<int>(), m, h->stage_feat.as<float>(), nullptr);
+    if (rc) return rc;
+    KPL_HIP(h, hipStreamSynchronize(nullptr));
+    KPL_HIP(h, hipMemcpy(features_out, h->stage_feat.p, sizeof(float) * (size_t)m * F, hipMemcpyDeviceToHost));
+    return KPL_OK;
+}
+
+int kpl_collect_stats(kpl_detector *h, kpl_stats *out, void *stream) {
+    if (!h || !out) return KPL_ERR_INVALID_ARG;
+    memset(out, 0, sizeof(*out));
+    int rc = use_device(h);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    KPL_HIP(h, h->stats.ensure(sizeof(StatsDev)));
+    KPL_HIP(h, hipMemsetAsync(h->stats.p, 0, sizeof(StatsDev), st));
+    const size_t nn = (size_t)(h->n > 0 ? h->n : 1);
+    KPL_HIP(h, h->out_kp.ensure(sizeof(int) * nn));
+    KPL_HIP(h, h->out_count.ensure(sizeof(int)));
+    rc = detect_on_device(h, nullptr, h->out_kp.as<int>(), h->n, h->out_count.as<int>(), st, h->stats.as<StatsDev>());
+    if (rc) return rc;
+    StatsDev sd;
+    KPL_HIP(h, hipMemcpyAsync(h->h_count, h->out_count.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    KPL_HIP(h, hipStreamSynchronize(st));
+    KPL_HIP(h, hipMemcpy(&sd, h->stats.p, sizeof(sd), hipMemcpyDeviceToHost));
+    out->n_points = h->n;
+    out->n_scored = (int64_t)sd.n_scored;
+    out->n_thresholded = (int64_t)sd.n_thresholded;
+    out->sum_kf = (int64_t)sd.sum_kf;
+    out->sum_kn = (int64_t)sd.sum_kn;
+    out->sum_depth = (int64_t)sd.sum_depth;
+    out->n_keypoints = h->h_count[0];
+    out->n_cells = h->grid.ncells;
+    return KPL_OK;
+}
+
+int kpl_cloud_resolution(kpl_detector *h, const void *xyz, size_t xyz_stride, int n, double *resolution) {
+    if (!h || !resolution) return KPL_ERR_INVALID_ARG;
+    (void)xyz; (void)xyz_stride; (void)n;
+    return fail(h, KPL_ERR_UNSUPPORTED, "kpl_cloud_resolution is not available yet");
+}
+
+}  // extern "C"

@@ -1,0 +1,60 @@
+// forest.h -- host-side random forest model of libkpl.
+//
+// Replaces what the reference gets from cv::ml::RTrees (load / getRoots / predict; call sites
+// /root/reference/include/impl/KeypointLearning.hpp:162,172,271,281): an OpenCV-YAML(.gz)
+// reader, the tree structure as node arrays, and the flattened device layout.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace kpl {
+
+// Trees as parsed: global node numbering, children by index, var < 0 marks a leaf.
+struct ForestModel {
+    int var_count = 0;
+    std::vector<int> root;
+    std::vector<int> var;
+    std::vector<float> thr;
+    std::vector<int> left;
+    std::vector<int> right;
+    std::vector<double> value;
+    int ntrees() const { return (int)root.size(); }
+    int64_t nnodes() const { return (int64_t)var.size(); }
+};
+
+// Device layout: one 8-byte record per node.
+//   x = threshold bits (internal) or leaf value as float bits (leaf)
+//   y = [31:24] split variable (0..254; 255 = leaf)   [23:0] index of the LEFT child
+// Siblings are adjacent (right = left + 1); each tree is laid out breadth first so that the
+// levels every walk touches first are contiguous.
+struct FlatNode {
+    uint32_t x;
+    uint32_t y;
+};
+constexpr uint32_t kLeafVar = 255u;
+constexpr uint32_t kMaxFlatNodes = 1u << 24;
+
+struct FlatForest {
+    int ntrees = 0;
+    int var_count = 0;
+    int max_depth = 0;               // longest root->leaf path, counted in nodes
+    std::vector<uint32_t> roots;     // [ntrees] node index of each root
+    std::vector<FlatNode> nodes;
+};
+
+// Parses OpenCV FileStorage YAML text of a cv::ml::RTrees / DTrees / legacy CvRTrees model.
+// Returns false and sets err on failure.
+bool parse_forest_yaml(const char *text, size_t len, ForestModel &out, std::string &err);
+
+// Reads a file, inflating it when it starts with the gzip magic.
+bool read_maybe_gzip(const char *path, std::string &out, std::string &err);
+bool inflate_if_gzip(const void *data, size_t len, std::string &out, std::string &err);
+
+// Validates the structure (every tree a proper binary tree, indices in range, thresholds finite,
+// leaf values exactly representable as float) and produces the device layout.
+bool flatten_forest(const ForestModel &m, FlatForest &out, std::string &err);
+
+}  // namespace kpl

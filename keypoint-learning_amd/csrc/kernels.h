@@ -1,0 +1,88 @@
+// kernels.h -- launch wrappers of the gfx950 kernels of libkpl (definitions in kernels.hip).
+//
+// Data layout in HBM (per bound view, all owned by the handle):
+//   pts[s]   float4  xyz of the s-th finite point in canonical storage order, w = bits of its
+//                    original index                       (16 B, one dwordx4 load per candidate)
+//   nrm[s]   float4  its normal, w = 1.0f if the normal is finite else 0.0f
+//   cell_start[c]    first storage position of grid cell c, c = (cz*ny + cy)*nx + cx; a run of
+//                    cells along x is therefore ONE contiguous range of pts/nrm
+//   pos_of[i]        storage position of original point i, -1 if its xyz is not finite
+//   score_sorted[s]  forest response in storage order (what the NMS kernel gathers)
+//   flags[i]         1 if original point i is a keypoint (compacted in ascending i)
+// Canonical storage order = ascending (cell id, original index); it is what makes the float
+// accumulation order of the histogram identical to the oracle's.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace kpl {
+
+struct GridDesc {
+    float mn[3];
+    float h;
+    int dims[3];
+    int ncells;
+};
+
+struct FeatDesc {
+    int A, B, F;
+    float support;   // (float)radius_search, the `support` argument of findAnnulusPair
+    float ann_dim;   // support / A
+    float ann_half;  // ann_dim / 2
+    float bin_dim;   // 2 / (float)B
+    float bin_half;
+    float r2;        // (float)(r*r), product in double -- KdTreeFLANN::radiusSearch
+    float rr;        // (float)(r*(1+2^-10)): half width of the cell box that is searched
+};
+
+struct NmsDesc {
+    float r2, rr;
+    double thr;
+    int non_maxima;
+};
+
+struct ForestDev {
+    const uint2 *nodes;
+    const uint32_t *roots;
+    int ntrees;
+};
+
+struct StatsDev {
+    unsigned long long sum_kf, sum_kn, sum_depth, n_scored, n_thresholded;
+};
+
+// ---- index build ("initCompute") ----------------------------------------------------------
+// bbox[0..2] = encoded min, bbox[3..5] = encoded max (order preserving uint encoding)
+void launch_bbox(const char *xyz, size_t stride, int n, uint32_t *bbox, hipStream_t st);
+void decode_bbox(const uint32_t *enc, float *mn, float *mx);
+void launch_cell_count(const char *xyz, size_t stride, int n, GridDesc g, int *cid, int *cnt,
+                       hipStream_t st);
+// exclusive scan of in[0..len) into out[0..len], out[len] = total; tmp holds >= len/4096+2 ints
+void launch_exclusive_scan(const int *in, int *out, int len, int *tmp, hipStream_t st);
+void launch_scatter(const int *cid, int n, const int *cell_start, int *cursor, int *tmp_idx,
+                    hipStream_t st);
+void launch_rank_store(const char *xyz, size_t xs, const char *nrm, size_t ns, int n, GridDesc g,
+                       const int *cid, const int *cell_start, const int *tmp_idx, float4 *pts,
+                       float4 *nrmo, int *pos_of, hipStream_t st);
+
+// ---- scoring ("runForest") ----------------------------------------------------------------
+// scores[i] (original order, may be null) and score_sorted[s]; NaN where not scoreable.
+void launch_score(const float4 *pts, const float4 *nrm, const int *cell_start, GridDesc g,
+                  FeatDesc f, ForestDev forest, int n, float *score_sorted, float *scores,
+                  StatsDev *stats, hipStream_t st);
+int score_block_size(int F);
+// features of listed points -> out[m*F]
+void launch_features(const float4 *pts, const float4 *nrm, const int *cell_start,
+                     const int *pos_of, GridDesc g, FeatDesc f, const int *query, int m, int n,
+                     float *out, hipStream_t st);
+void launch_fill_f32(float *p, float v, int n, hipStream_t st);
+
+// ---- NMS + compaction ("detectKeypoints") -------------------------------------------------
+void launch_nms(const float4 *pts, const int *cell_start, GridDesc g, NmsDesc nd,
+                const float *score_sorted, int n, int *flags, StatsDev *stats, hipStream_t st);
+void launch_compact(const int *flags, const int *prefix, int n, int *kp_idx, int kp_cap,
+                    int *kp_count, hipStream_t st);
+
+}  // namespace kpl

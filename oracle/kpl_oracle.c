@@ -1,0 +1,564 @@
+/*
+ * kpl_oracle.c -- CPU restatement (ORACLE) of the KeypointLearningDetector scoring path.
+ * TEST INFRASTRUCTURE ONLY -- see kpl_oracle.h for who may use it and for the pinning status
+ * ("parity unpinned" for everything the reference delegates to PCL/FLANN, Eigen, OpenCV).
+ *
+ * Build: gcc -O2 -ffp-contract=off -fopenmp -std=c11 (see oracle/Makefile).  -ffp-contract=off
+ * is part of the specification: the reference arithmetic is separate float mul/add/div/sqrt.
+ *
+ * Citations are relative to /root/reference.
+ */
+#include "kpl_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define KPLO_MAX_CELLS ((int64_t)1 << 28)
+
+/* ------------------------------------------------------------------------------------------
+ * Soft assignment.  src/KeypointLearning.cpp:41-65 (annulus) and :68-92 (bin).
+ * `abs` there is the float overload on the reference platform (MSVC) -> fabsf here.
+ * ---------------------------------------------------------------------------------------- */
+void kplo_find_annulus_pair(int n_annulus, float distance, float support,
+                            int *idx, int *pair, float *w)
+{
+    float dim = support / (float)n_annulus;                 /* :43 */
+    int k = (int)floorf(distance / dim);                    /* :45 */
+    if (k == n_annulus) k--;                                /* :46-47 */
+    if (k < 0) k = 0;                 /* :49 assert(0 <= k < n) restated as a clamp: no  */
+    if (k > n_annulus - 1) k = n_annulus - 1; /* effect on in-range values (NaN input -> 0) */
+    float center = ((float)k * dim) + (dim / 2);            /* :52 */
+    float wt = distance - center;                           /* :54 */
+    wt /= dim;                                              /* :55 */
+    int p = (wt > 0) ? k + 1 : k - 1;                       /* :57 */
+    if (p == -1) p = 0;                                     /* :59-60 */
+    if (p == n_annulus) p = k;                              /* :61-62 */
+    *idx = k;
+    *pair = p;
+    *w = fabsf(wt);                                         /* :64 */
+}
+
+void kplo_find_bin_pair(int n_bins, float cosine, int *idx, int *pair, float *w)
+{
+    if (cosine < 0) cosine = 0;                             /* :70-71 */
+    if (cosine > 2) cosine = 2;                             /* :72-73 */
+    float dim = 2 / (float)n_bins;                          /* :75 */
+    int k = (int)floorf(cosine / dim);                      /* :76 */
+    if (k == n_bins) k--;                                   /* :77-78 */
+    if (k < 0) k = 0;                                       /* :80 assert as clamp */
+    if (k > n_bins - 1) k = n_bins - 1;
+    float center = ((float)k * dim) + (dim / 2);            /* :83 */
+    float wt = cosine - center;                             /* :84 */
+    wt /= dim;                                              /* :85 */
+    int p = (wt > 0) ? k + 1 : k - 1;                       /* :86 */
+    if (p == -1) p = 0;                                     /* :87-88 */
+    if (p == n_bins) p = k;                                 /* :89-90 */
+    *idx = k;
+    *pair = p;
+    *w = fabsf(wt);                                         /* :91 */
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Canonical grid (stands in for pcl::search::KdTree -> FLANN, call sites
+ * include/impl/KeypointLearning.hpp:213 and :334).  Normative definition:
+ *   finite points only; mn = componentwise min; h = (float)cell_size;
+ *   cell(v) = clamp((int)floorf((v - mn) / h), 0, dim-1)   (float sub, IEEE float div);
+ *   linear id = (cz*ny + cy)*nx + cx;
+ *   canonical neighbor order = ascending (linear id of the neighbor's cell, neighbor index).
+ * ---------------------------------------------------------------------------------------- */
+struct kplo_grid {
+    int n, nfinite;
+    float mn[3];
+    float h;
+    int dims[3];
+    int64_t ncells;
+    int *cell_start; /* [ncells + 1] */
+    int *sorted;     /* [nfinite] original indices in canonical storage order */
+};
+
+static inline int finite3(const float *p)
+{
+    return isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2]);
+}
+
+static inline int cell_coord(float v, float mn, float h, int dim)
+{
+    float t = floorf((v - mn) / h);
+    if (!(t >= 0.0f)) return 0;
+    if (t >= (float)dim) return dim - 1;
+    return (int)t;
+}
+
+kplo_grid *kplo_grid_create(const float *xyz, int n, double cell_size)
+{
+    kplo_grid *g = (kplo_grid *)calloc(1, sizeof(*g));
+    if (!g) return NULL;
+    g->n = n;
+    g->h = (float)cell_size;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    int nf = 0;
+    for (int i = 0; i < n; ++i) {
+        const float *p = xyz + 3 * (size_t)i;
+        if (!finite3(p)) continue;
+        ++nf;
+        for (int k = 0; k < 3; ++k) {
+            if (p[k] < mn[k]) mn[k] = p[k];
+            if (p[k] > mx[k]) mx[k] = p[k];
+        }
+    }
+    g->nfinite = nf;
+    if (nf == 0 || !(g->h > 0.0f)) {
+        g->dims[0] = g->dims[1] = g->dims[2] = 0;
+        g->ncells = 0;
+        g->cell_start = (int *)calloc(1, sizeof(int));
+        g->sorted = (int *)calloc(1, sizeof(int));
+        return g;
+    }
+    int64_t nc = 1;
+    for (int k = 0; k < 3; ++k) {
+        g->mn[k] = mn[k];
+        float t = floorf((mx[k] - mn[k]) / g->h);
+        if (!(t < 1.0e9f)) { free(g); return NULL; }
+        g->dims[k] = (int)t + 1;
+        nc *= g->dims[k];
+        if (nc > KPLO_MAX_CELLS) { free(g); return NULL; }
+    }
+    g->ncells = nc;
+    g->cell_start = (int *)calloc((size_t)nc + 1, sizeof(int));
+    g->sorted = (int *)malloc(sizeof(int) * (size_t)nf);
+    int *cid = (int *)malloc(sizeof(int) * (size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const float *p = xyz + 3 * (size_t)i;
+        if (!finite3(p)) { cid[i] = -1; continue; }
+        int cx = cell_coord(p[0], g->mn[0], g->h, g->dims[0]);
+        int cy = cell_coord(p[1], g->mn[1], g->h, g->dims[1]);
+        int cz = cell_coord(p[2], g->mn[2], g->h, g->dims[2]);
+        cid[i] = (cz * g->dims[1] + cy) * g->dims[0] + cx;
+        g->cell_start[cid[i] + 1]++;
+    }
+    for (int64_t c = 0; c < nc; ++c) g->cell_start[c + 1] += g->cell_start[c];
+    int *fill = (int *)malloc(sizeof(int) * (size_t)nc);
+    memcpy(fill, g->cell_start, sizeof(int) * (size_t)nc);
+    for (int i = 0; i < n; ++i)           /* ascending i => ascending index inside a cell */
+        if (cid[i] >= 0) g->sorted[fill[cid[i]]++] = i;
+    free(fill);
+    free(cid);
+    return g;
+}
+
+void kplo_grid_free(kplo_grid *g)
+{
+    if (!g) return;
+    free(g->cell_start);
+    free(g->sorted);
+    free(g);
+}
+
+void kplo_grid_info(const kplo_grid *g, int *dims, float *mn, float *h, int *nfinite)
+{
+    for (int k = 0; k < 3; ++k) { dims[k] = g->dims[k]; mn[k] = g->mn[k]; }
+    *h = g->h;
+    *nfinite = g->nfinite;
+}
+
+void kplo_grid_sorted_indices(const kplo_grid *g, int *out)
+{
+    memcpy(out, g->sorted, sizeof(int) * (size_t)g->nfinite);
+}
+
+/* FLANN L2_Simple<float> restated: d = dx*dx; d += dy*dy; d += dz*dz (float). */
+static inline float dist2(const float *a, const float *b)
+{
+    float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+    float d = dx * dx;
+    d += dy * dy;
+    d += dz * dz;
+    return d;
+}
+
+typedef struct {
+    int lo[3], hi[3];
+    float r2;
+} search_box;
+
+/* KdTreeFLANN::radiusSearch: r2 = (float)(radius*radius), product in double; strict d2 < r2.
+ * The cell range is found with the same monotonic cell function applied to p -+ rr with
+ * rr slightly above r, so every accepted point is covered whatever the rounding. */
+static inline void make_box(const kplo_grid *g, const float *p, double radius, search_box *b)
+{
+    float rr = (float)(radius * (1.0 + 1.0 / 1024.0));
+    b->r2 = (float)(radius * radius);
+    for (int k = 0; k < 3; ++k) {
+        b->lo[k] = cell_coord(p[k] - rr, g->mn[k], g->h, g->dims[k]);
+        b->hi[k] = cell_coord(p[k] + rr, g->mn[k], g->h, g->dims[k]);
+    }
+}
+
+#define FOR_EACH_CANDIDATE(g, b, J, ...)                                                  \
+    for (int cz_ = (b).lo[2]; cz_ <= (b).hi[2]; ++cz_)                                      \
+        for (int cy_ = (b).lo[1]; cy_ <= (b).hi[1]; ++cy_) {                                \
+            int row_ = (cz_ * (g)->dims[1] + cy_) * (g)->dims[0];                           \
+            int s0_ = (g)->cell_start[row_ + (b).lo[0]];                                    \
+            int s1_ = (g)->cell_start[row_ + (b).hi[0] + 1];                                \
+            for (int s_ = s0_; s_ < s1_; ++s_) {                                            \
+                int J = (g)->sorted[s_];                                                    \
+                __VA_ARGS__                                                                 \
+            }                                                                               \
+        }
+
+int kplo_radius_search(const kplo_grid *g, const float *xyz, int i, double radius,
+                       int *out_idx, float *out_d2, int cap)
+{
+    const float *p = xyz + 3 * (size_t)i;
+    if (!finite3(p) || g->ncells == 0) return 0;
+    search_box b;
+    make_box(g, p, radius, &b);
+    int cnt = 0;
+    FOR_EACH_CANDIDATE(g, b, j, {
+        float d2 = dist2(p, xyz + 3 * (size_t)j);
+        if (d2 < b.r2) {
+            if (cnt < cap) {
+                if (out_idx) out_idx[cnt] = j;
+                if (out_d2) out_d2[cnt] = d2;
+            }
+            ++cnt;
+        }
+    })
+    return cnt;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * computePointFeatures, include/impl/KeypointLearning.hpp:321-376.
+ * H is A x B row-major (the reference's Eigen matrix is column-major; only (row, col)
+ * addressing matters).  Returns K_f (neighbors found, including the dropped first one).
+ * ---------------------------------------------------------------------------------------- */
+static int point_features(const kplo_grid *g, const float *xyz, const float *nrm, int i,
+                          int A, int B, double r_feat, float *H /* A*B */)
+{
+    const int F = A * B;
+    for (int c = 0; c < F; ++c) H[c] = 0.0f;                       /* :325 */
+    const float *p = xyz + 3 * (size_t)i;
+    const float *np = nrm + 3 * (size_t)i;                         /* :332 */
+    const float support = (float)r_feat;      /* double search_radius_ -> float param, :345 */
+    search_box b;
+    make_box(g, p, r_feat, &b);
+    int seen = 0;
+    FOR_EACH_CANDIDATE(g, b, j, {
+        const float *q = xyz + 3 * (size_t)j;
+        float d2 = dist2(p, q);
+        if (d2 < b.r2) {
+            if (seen++ == 0) continue;                 /* :336 loop starts at neigh_indx = 1 */
+            const float *nq = nrm + 3 * (size_t)j;
+            if (!finite3(nq)) continue;                /* :338 */
+            /* :342  Eigen Vector3f::dot, unrolled as x + (y + z) */
+            float dot = np[0] * nq[0] + (np[1] * nq[1] + np[2] * nq[2]);
+            float cosine = 1 - dot;
+            int a, ap, bi, bp;
+            float aw, bw;
+            kplo_find_annulus_pair(A, sqrtf(d2), support, &a, &ap, &aw);   /* :345 */
+            kplo_find_bin_pair(B, cosine, &bi, &bp, &bw);                  /* :348 */
+            H[a * B + bi] += ((1 - bw) * (1 - aw));                        /* :350 */
+            H[a * B + bp] += ((bw) * (1 - aw));                            /* :351 */
+            H[ap * B + bi] += ((1 - bw) * (aw));                           /* :354 */
+            H[ap * B + bp] += ((bw) * (aw));                               /* :355 */
+        }
+    })
+    for (int a = 0; a < A; ++a) {                                          /* :360-370 */
+        float s = 0.0f;
+        for (int k = 0; k < B; ++k) s += H[a * B + k] * H[a * B + k];
+        float nr = sqrtf(s);
+        if (nr > 0)
+            for (int k = 0; k < B; ++k) H[a * B + k] = H[a * B + k] / nr;
+    }
+    return seen;
+}
+
+void kplo_features(const kplo_grid *g, const float *xyz, const float *nrm, int n,
+                   int n_annulus, int n_bins, double r_feat,
+                   const int *query, int m, float *feat_out)
+{
+    (void)n;
+    const int F = n_annulus * n_bins;
+    for (int q = 0; q < m; ++q) {
+        int i = query[q];
+        float *out = feat_out + (size_t)q * F;
+        if (!finite3(xyz + 3 * (size_t)i)) {   /* the reference would search a NaN query: undefined */
+            for (int c = 0; c < F; ++c) out[c] = NAN;
+            continue;
+        }
+        point_features(g, xyz, nrm, i, n_annulus, n_bins, r_feat, out);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * cv::ml::RTrees::predict(feat, result, PREDICT_SUM) restated (OpenCV 3.2 DTreesImpl::
+ * predictTrees): per tree walk "val <= c ? left : right", sum leaf values in double,
+ * return (float)sum.  Call site include/impl/KeypointLearning.hpp:281.
+ * ---------------------------------------------------------------------------------------- */
+float kplo_forest_predict_sum(const kplo_forest *f, const float *x, int *depth_sum)
+{
+    double sum = 0.0;
+    int depth = 0;
+    for (int t = 0; t < f->ntrees; ++t) {
+        int nd = f->root[t];
+        while (f->var[nd] >= 0) {
+            float val = x[f->var[nd]];
+            nd = (val <= f->thr[nd]) ? f->left[nd] : f->right[nd];
+            ++depth;
+        }
+        ++depth; /* the leaf itself is a visited node */
+        sum += f->value[nd];
+    }
+    if (depth_sum) *depth_sum = depth;
+    return (float)sum;
+}
+
+/* runForest, include/impl/KeypointLearning.hpp:267-296.  Index space = input index space;
+ * a non-scoreable point gets NaN instead of being compacted away (documented divergence,
+ * identical for all-finite clouds). */
+void kplo_scores(const kplo_grid *g, const float *xyz, const float *nrm, int n,
+                 int n_annulus, int n_bins, double r_feat, const kplo_forest *f,
+                 float *scores, int n_threads)
+{
+    const int F = n_annulus * n_bins;
+    const int forest_size = f->ntrees;                                   /* :271 */
+#ifdef _OPENMP
+    if (n_threads < 1) n_threads = 1;
+#pragma omp parallel num_threads(n_threads)
+#endif
+    {
+        float *H = (float *)malloc(sizeof(float) * (size_t)F);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 256)
+#endif
+        for (int i = 0; i < n; ++i) {
+            if (!(finite3(xyz + 3 * (size_t)i) && finite3(nrm + 3 * (size_t)i))) { /* :277 */
+                scores[i] = NAN;
+                continue;
+            }
+            point_features(g, xyz, nrm, i, n_annulus, n_bins, r_feat, H);  /* :279 */
+            const float sum = kplo_forest_predict_sum(f, H, NULL);         /* :281 */
+            scores[i] = 1 - (sum / (forest_size * 1.0f));                  /* :287 */
+        }
+        free(H);
+    }
+    (void)n_threads;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Non-maxima suppression, include/impl/KeypointLearning.hpp:197-261.
+ * ---------------------------------------------------------------------------------------- */
+static int nms_point(const kplo_grid *g, const float *xyz, const float *scores, int idx,
+                     double r_nms, int *has_draw_out, int **draws, int *ndraws, int *cap_draws)
+{
+    const float *p = xyz + 3 * (size_t)idx;
+    search_box b;
+    make_box(g, p, r_nms, &b);                                            /* :213 */
+    int is_maxima = 1, has_draw = 0;
+    const float si = scores[idx];
+    if (ndraws) *ndraws = 0;
+    FOR_EACH_CANDIDATE(g, b, j, {
+        if (dist2(p, xyz + 3 * (size_t)j) < b.r2) {
+            if (si < scores[j]) {                                         /* :219 */
+                is_maxima = 0;
+                goto done;                                                /* :222 break */
+            } else if (si == scores[j]) {                                 /* :224 */
+                if (idx != j) {
+                    has_draw = 1;
+                    if (draws) {
+                        if (*ndraws == *cap_draws) {
+                            *cap_draws = *cap_draws ? *cap_draws * 2 : 64;
+                            *draws = (int *)realloc(*draws, sizeof(int) * (size_t)*cap_draws);
+                        }
+                        (*draws)[(*ndraws)++] = j;                        /* :227 */
+                    }
+                }
+            }
+        }
+    })
+done:
+    *has_draw_out = has_draw;
+    return is_maxima;
+}
+
+int kplo_nms(const kplo_grid *g, const float *xyz, const float *scores, int n,
+             double r_nms, double threshold, int draws_remove, float draws_threshold,
+             int *kp_out, int n_threads)
+{
+    int count = 0;
+    if (!draws_remove) {
+        /* predicate form: order independent, so it may run in parallel */
+        unsigned char *flag = (unsigned char *)calloc((size_t)n + 1, 1);
+#ifdef _OPENMP
+        if (n_threads < 1) n_threads = 1;
+#pragma omp parallel for schedule(dynamic, 256) num_threads(n_threads)
+#endif
+        for (int idx = 0; idx < n; ++idx) {
+            if (!finite3(xyz + 3 * (size_t)idx) || !isfinite(scores[idx]) ||
+                (double)scores[idx] < threshold)                           /* :205-208 */
+                continue;
+            int hd;
+            if (nms_point(g, xyz, scores, idx, r_nms, &hd, NULL, NULL, NULL)) flag[idx] = 1;
+        }
+        for (int idx = 0; idx < n; ++idx)
+            if (flag[idx]) kp_out[count++] = idx;                          /* :252-253 */
+        free(flag);
+        (void)n_threads;
+        return count;
+    }
+    /* draws_remove: order-dependent greedy pass, serial like the reference (:231-250).
+     * skipList membership (std::find, :234) is kept as a flag array. */
+    unsigned char *skip = (unsigned char *)calloc((size_t)n + 1, 1);
+    int *draws = NULL, ndraws = 0, cap = 0;
+    for (int idx = 0; idx < n; ++idx) {
+        if (!finite3(xyz + 3 * (size_t)idx) || !isfinite(scores[idx]) ||
+            (double)scores[idx] < threshold)
+            continue;
+        int has_draw;
+        int is_max = nms_point(g, xyz, scores, idx, r_nms, &has_draw, &draws, &ndraws, &cap);
+        if (!is_max) continue;
+        if (has_draw) {
+            if (!skip[idx]) {                                              /* :234 */
+                int survive = 0;
+                const float *p = xyz + 3 * (size_t)idx;
+                for (int k = 0; k < ndraws; ++k) {
+                    const float *q = xyz + 3 * (size_t)draws[k];
+                    /* :239 (a - b).norm(): Eigen squaredNorm of a fixed 3-vector,
+                     * unrolled x*x + (y*y + z*z), then sqrt */
+                    float dx = p[0] - q[0], dy = p[1] - q[1], dz = p[2] - q[2];
+                    float distance = sqrtf(dx * dx + (dy * dy + dz * dz));
+                    if (distance < draws_threshold) {                      /* :240 */
+                        survive = 1;
+                        skip[draws[k]] = 1;                                /* :242 */
+                    }
+                }
+                if (survive) kp_out[count++] = idx;                        /* :245-248 */
+            }
+        } else {
+            kp_out[count++] = idx;                                         /* :252-253 */
+        }
+    }
+    free(draws);
+    free(skip);
+    return count;
+}
+
+int kplo_detect(const float *xyz, const float *nrm, int n,
+                int n_annulus, int n_bins, double r_feat, double r_nms, double threshold,
+                int non_maxima, int draws_remove, float draws_threshold,
+                const kplo_forest *f, float *scores_out, int *kp_out, int n_threads)
+{
+    kplo_grid *g = kplo_grid_create(xyz, n, r_feat);
+    if (!g) return -1;
+    float *scores = scores_out ? scores_out : (float *)malloc(sizeof(float) * (size_t)(n + 1));
+    kplo_scores(g, xyz, nrm, n, n_annulus, n_bins, r_feat, f, scores, n_threads);
+    int count = 0;
+    if (!non_maxima) {
+        /* :189-196: every response point is a keypoint.  In input index space that is every
+         * scoreable point. */
+        for (int i = 0; i < n; ++i)
+            if (!isnan(scores[i])) kp_out[count++] = i;
+    } else {
+        count = kplo_nms(g, xyz, scores, n, r_nms, threshold, draws_remove, draws_threshold,
+                         kp_out, n_threads);
+    }
+    if (!scores_out) free(scores);
+    kplo_grid_free(g);
+    return count;
+}
+
+void kplo_alg_counters(const kplo_grid *g, const float *xyz, const float *nrm, int n,
+                       int n_annulus, int n_bins, double r_feat, double r_nms, double threshold,
+                       const kplo_forest *f, int64_t *sum_kf, int64_t *sum_kn,
+                       int64_t *sum_depth, int64_t *n_scored, int64_t *n_thresholded)
+{
+    const int F = n_annulus * n_bins;
+    float *H = (float *)malloc(sizeof(float) * (size_t)F);
+    int64_t kf = 0, kn = 0, dp = 0, ns = 0, nt = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!(finite3(xyz + 3 * (size_t)i) && finite3(nrm + 3 * (size_t)i))) continue;
+        kf += point_features(g, xyz, nrm, i, n_annulus, n_bins, r_feat, H);
+        int d;
+        float sum = kplo_forest_predict_sum(f, H, &d);
+        dp += d;
+        ++ns;
+        float score = 1 - (sum / (f->ntrees * 1.0f));
+        if (!((double)score < threshold)) {
+            ++nt;
+            kn += kplo_radius_search(g, xyz, i, r_nms, NULL, NULL, 0);
+        }
+    }
+    free(H);
+    *sum_kf = kf; *sum_kn = kn; *sum_depth = dp; *n_scored = ns; *n_thresholded = nt;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * computeCloudResolution, include/impl/point_cloud_utilities.hpp:120-151: mean over points
+ * with finite x of sqrt(second smallest squared distance), double accumulator.
+ * ---------------------------------------------------------------------------------------- */
+double kplo_cloud_resolution(const float *xyz, int n)
+{
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    int nf = 0;
+    for (int i = 0; i < n; ++i) {
+        const float *p = xyz + 3 * (size_t)i;
+        if (!finite3(p)) continue;
+        ++nf;
+        for (int k = 0; k < 3; ++k) {
+            if (p[k] < mn[k]) mn[k] = p[k];
+            if (p[k] > mx[k]) mx[k] = p[k];
+        }
+    }
+    if (nf < 2) return 0.0;
+    /* cell size heuristic: about two points per cell on a surface-like cloud */
+    double ext[3] = {mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]};
+    double e0 = ext[0], e1 = ext[1], e2 = ext[2], t;
+    if (e0 < e1) { t = e0; e0 = e1; e1 = t; }
+    if (e1 < e2) { t = e1; e1 = e2; e2 = t; }
+    if (e0 < e1) { t = e0; e0 = e1; e1 = t; }
+    double cell = sqrt((e0 * (e1 > 0 ? e1 : e0)) / (double)nf * 2.0);
+    if (!(cell > 0)) cell = 1.0;
+    kplo_grid *g = NULL;
+    while (!(g = kplo_grid_create(xyz, n, cell))) cell *= 2.0;
+    double res = 0.0;
+    int n_points = 0;
+    for (int i = 0; i < n; ++i) {
+        const float *p = xyz + 3 * (size_t)i;
+        if (!finite3(p)) continue;
+        int c[3];
+        for (int k = 0; k < 3; ++k) c[k] = cell_coord(p[k], g->mn[k], g->h, g->dims[k]);
+        float best0 = INFINITY, best1 = INFINITY;
+        int maxring = g->dims[0] > g->dims[1] ? g->dims[0] : g->dims[1];
+        if (g->dims[2] > maxring) maxring = g->dims[2];
+        for (int ring = 1; ring <= maxring; ++ring) {
+            search_box b;
+            b.r2 = 0;
+            for (int k = 0; k < 3; ++k) {
+                b.lo[k] = c[k] - ring < 0 ? 0 : c[k] - ring;
+                b.hi[k] = c[k] + ring >= g->dims[k] ? g->dims[k] - 1 : c[k] + ring;
+            }
+            best0 = best1 = INFINITY;
+            FOR_EACH_CANDIDATE(g, b, j, {
+                float d2 = dist2(p, xyz + 3 * (size_t)j);
+                if (d2 < best0) { best1 = best0; best0 = d2; }
+                else if (d2 < best1) best1 = d2;
+            })
+            double safe = ring * (double)g->h * 0.999;
+            if (isfinite(best1) && (double)sqrtf(best1) <= safe) break;
+            if (b.lo[0] == 0 && b.lo[1] == 0 && b.lo[2] == 0 && b.hi[0] == g->dims[0] - 1 &&
+                b.hi[1] == g->dims[1] - 1 && b.hi[2] == g->dims[2] - 1)
+                break;
+        }
+        if (isfinite(best1)) {
+            res += sqrtf(best1);                                          /* :141 */
+            ++n_points;
+        }
+    }
+    kplo_grid_free(g);
+    if (n_points != 0) res /= n_points;                                   /* :145-148 */
+    return res;
+}

@@ -1,0 +1,197 @@
+"""GPU parity: libkpl (HIP, through the C-ABI) against the CPU oracle on the same seeded inputs.
+Features bit-exact, scores bit-exact (tolerance allowed by the north star: 1e-5), keypoint
+index lists identical."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def make_det(kpl, A, B, r_feat, r_nms, thr, fa=None, draws_remove=False):
+    det = kpl.KeypointLearningDetector()
+    det.setNAnnulus(A)
+    det.setNBins(B)
+    det.setNonMaxima(True)
+    det.setNonMaxRadius(r_nms)
+    det.setNonMaximaDrawsRemove(draws_remove)
+    det.setPredictionThreshold(thr)
+    det.setRadiusSearch(r_feat)
+    if fa is not None:
+        from tests.helpers import load_arrays
+        load_arrays(det, fa)
+    return det
+
+
+@pytest.mark.parametrize("A,B", [(5, 6), (5, 10), (8, 10), (1, 1), (3, 2)])
+def test_features_bit_exact(kpl, oracle, cases, A, B):
+    xyz, nrm = cases.cloud()
+    mr = cases.resolution()
+    r = float(np.float32(6 * mr))
+    det = make_det(kpl, A, B, r, 0.0, 0.5)
+    det.setInputCloud(xyz)
+    det.setNormals(nrm)
+    q = np.arange(len(xyz), dtype=np.int32)
+    got = det.computePointsForTrainingFeatures(q)
+    want = oracle.Grid(xyz, r).features(nrm, A, B, r, q)
+    assert cases.same_bits(got, want)
+    # sparse, unordered, repeated query list (the training entry point)
+    q2 = np.array([5, 0, len(xyz) - 1, 5, 17, 1234], dtype=np.int32)
+    assert cases.same_bits(det.computePointsForTrainingFeatures(q2), want[q2])
+
+
+@pytest.mark.parametrize("thr", [0.0, 0.5, 0.85, 1.0])
+def test_detect_matches_oracle(kpl, oracle, cases, thr):
+    A, B = 5, 6
+    xyz, nrm = cases.cloud()
+    mr = cases.resolution()
+    r, rn = float(np.float32(6 * mr)), float(np.float32(4 * mr))
+    fa = cases.trained_forest(A, B)
+    det = make_det(kpl, A, B, r, rn, float(np.float32(thr)), fa)
+    det.setInputCloud(xyz)
+    det.setNormals(nrm)
+    kp_xyzi, scores = det.compute()
+    o_scores, o_kp = oracle.detect(xyz, nrm, A, B, r, rn, float(np.float32(thr)), cases.oracle_forest(fa))
+    assert cases.same_bits(scores, o_scores)
+    assert np.array_equal(det.getKeypointsIndices(), o_kp)
+    assert len(o_kp) > 0
+    assert cases.same_bits(kp_xyzi[:, 3], o_scores[o_kp])
+    # run twice: deterministic
+    det.compute()
+    assert np.array_equal(det.getKeypointsIndices(), o_kp)
+
+
+def test_non_finite_points_and_normals(kpl, oracle, cases):
+    A, B = 5, 6
+    xyz, nrm = cases.cloud(nan_points=40, nan_normals=60)
+    mr = cases.resolution()
+    r, rn = 6 * mr, 4 * mr
+    fa = cases.trained_forest(A, B)
+    det = make_det(kpl, A, B, r, rn, 0.5, fa)
+    det.setInputCloud(xyz)
+    det.setNormals(nrm)
+    _, scores = det.compute()
+    o_scores, o_kp = oracle.detect(xyz, nrm, A, B, r, rn, 0.5, cases.oracle_forest(fa))
+    assert np.isnan(o_scores).sum() >= 60
+    assert cases.same_bits(scores, o_scores)
+    assert np.array_equal(det.getKeypointsIndices(), o_kp)
+
+
+@pytest.mark.parametrize("rf,rn", [(4.0, 4.0), (10.0, 4.0), (3.0, 7.5), (6.0, 0.0)])
+def test_radius_combinations(kpl, oracle, cases, rf, rn):
+    A, B = 5, 6
+    xyz, nrm = cases.cloud()
+    mr = cases.resolution()
+    fa = cases.trained_forest(A, B)
+    det = make_det(kpl, A, B, rf * mr, rn * mr, 0.6, fa)
+    det.setInputCloud(xyz)
+    det.setNormals(nrm)
+    _, scores = det.compute()
+    o_scores, o_kp = oracle.detect(xyz, nrm, A, B, rf * mr, rn * mr, 0.6, cases.oracle_forest(fa))
+    assert cases.same_bits(scores, o_scores)
+    assert np.array_equal(det.getKeypointsIndices(), o_kp)
+
+
+def test_no_nms_returns_every_scoreable_point(kpl, oracle, cases):
+    A, B = 5, 6
+    xyz, nrm = cases.cloud(nan_points=10, nan_normals=10)
+    mr = cases.resolution()
+    fa = cases.trained_forest(A, B)
+    det = make_det(kpl, A, B, 6 * mr, 4 * mr, 0.85, fa)
+    det.setNonMaxima(False)
+    det.setInputCloud(xyz)
+    det.setNormals(nrm)
+    _, scores = det.compute()
+    o_scores, o_kp = oracle.detect(xyz, nrm, A, B, 6 * mr, 4 * mr, 0.85, cases.oracle_forest(fa), non_maxima=False)
+    assert np.array_equal(det.getKeypointsIndices(), o_kp)
+    assert np.array_equal(o_kp, np.flatnonzero(~np.isnan(o_scores)))
+
+
+def test_edge_sizes(kpl, oracle, cases):
+    A, B = 5, 6
+    fa = cases.trained_forest(A, B)
+    of = cases.oracle_forest(fa)
+    det = make_det(kpl, A, B, 2.0, 1.0, 0.0, fa)
+    for n in (0, 1, 2, 63, 64, 65):
+        xyz, nrm = cases.cloud()
+        xyz, nrm = xyz[:n].copy(), nrm[:n].copy()
+        det.setInputCloud(xyz.reshape(-1, 3))
+        det.setNormals(nrm.reshape(-1, 3))
+        _, scores = det.compute()
+        o_scores, o_kp = oracle.detect(xyz, nrm, A, B, 2.0, 1.0, 0.0, of)
+        assert cases.same_bits(scores, o_scores), n
+        assert np.array_equal(det.getKeypointsIndices(), o_kp), n
+    # all points identical (one cell, every distance 0)
+    xyz = np.ones((100, 3), dtype=np.float32)
+    nrm = np.tile(np.array([[0, 0, 1]], dtype=np.float32), (100, 1))
+    det.setInputCloud(xyz)
+    det.setNormals(nrm)
+    _, scores = det.compute()
+    o_scores, o_kp = oracle.detect(xyz, nrm, A, B, 2.0, 1.0, 0.0, of)
+    assert cases.same_bits(scores, o_scores)
+    assert np.array_equal(det.getKeypointsIndices(), o_kp)
+
+
+def test_strided_pcl_layouts(kpl, oracle, cases):
+    """PointXYZ (16 B) and Normal (32 B) arrays are passed as they are."""
+    A, B = 5, 6
+    xyz, nrm = cases.cloud()
+    mr = cases.resolution()
+    fa = cases.trained_forest(A, B)
+    p16 = np.full((len(xyz), 4), 1.0, dtype=np.float32)
+    p16[:, :3] = xyz
+    n32 = np.full((len(xyz), 8), np.nan, dtype=np.float32)   # padding must never be read as data
+    n32[:, :3] = nrm
+    det = make_det(kpl, A, B, 6 * mr, 4 * mr, 0.85, fa)
+    det.setInputCloud(p16)
+    det.setNormals(n32)
+    _, scores = det.compute()
+    o_scores, o_kp = oracle.detect(xyz, nrm, A, B, 6 * mr, 4 * mr, 0.85, cases.oracle_forest(fa))
+    assert cases.same_bits(scores, o_scores)
+    assert np.array_equal(det.getKeypointsIndices(), o_kp)
+
+
+def test_yaml_gz_forest_file_equals_arrays(kpl, oracle, cases, tmp_path):
+    from tools import forest_yaml
+    A, B = 5, 6
+    xyz, nrm = cases.cloud()
+    mr = cases.resolution()
+    fa = cases.trained_forest(A, B)
+    path = tmp_path / "forest.yaml.gz"
+    forest_yaml.save_forest(fa, str(path))
+    det = make_det(kpl, A, B, 6 * mr, 4 * mr, 0.85)
+    assert det.loadForest(str(path))
+    info = det.forestInfo()
+    assert info["ntrees"] == fa.ntrees and info["var_count"] == A * B and info["nnodes"] == fa.nnodes
+    det.setInputCloud(xyz)
+    det.setNormals(nrm)
+    _, scores = det.compute()
+    o_scores, o_kp = oracle.detect(xyz, nrm, A, B, 6 * mr, 4 * mr, 0.85, cases.oracle_forest(fa))
+    assert cases.same_bits(scores, o_scores)
+    assert np.array_equal(det.getKeypointsIndices(), o_kp)
+
+
+def test_errors(kpl, cases):
+    A, B = 5, 6
+    xyz, nrm = cases.cloud()
+    fa = cases.trained_forest(A, B)
+    det = make_det(kpl, A, B, 3.0, 2.0, 0.5)
+    det.setInputCloud(xyz)
+    det.setNormals(nrm)
+    with pytest.raises(kpl.KplError) as e:
+        det.compute()
+    assert e.value.status == kpl.ERR_NO_FOREST
+    cases.load_arrays(det, fa)
+    det.setNBins(10)
+    with pytest.raises(kpl.KplError) as e:
+        det.compute()
+    assert e.value.status == kpl.ERR_VAR_COUNT
+    det.setNBins(B)
+    det.setRadiusSearch(0.0)
+    with pytest.raises(kpl.KplError) as e:
+        det.compute()
+    assert e.value.status == kpl.ERR_INVALID_ARG
+    det.setRadiusSearch(1e-6)
+    with pytest.raises(kpl.KplError) as e:
+        det.compute()
+    assert e.value.status == kpl.ERR_GRID_TOO_LARGE
+    assert not det.loadForest("/nonexistent/forest.yaml.gz")
