@@ -131,6 +131,19 @@ int kpl_compute_device(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_c
 int kpl_compute_features_device(kpl_detector *h, const int *d_indices, int m,
                                 float *d_features, void *stream);
 
+/* Per-phase device timing with HIP events recorded on the caller's stream, around the kernels of
+ * each phase, for every kpl_build_index_device / kpl_detect_device / kpl_compute_device call made
+ * while it is enabled (up to 4096 calls, later ones are not recorded).  kpl_get_timing waits for
+ * the recorded events, adds them up and clears the record. */
+typedef struct kpl_timing {
+    int calls;            /* detect calls summed                                              */
+    float index_ms;       /* bbox + cell count + scan + scatter + rank/store                  */
+    float score_ms;       /* the feature + forest kernel (the dominant kernel)                */
+    float nms_ms;         /* NMS + flag scan + compaction                                     */
+} kpl_timing;
+int kpl_enable_timing(kpl_detector *h, int enable);
+int kpl_get_timing(kpl_detector *h, kpl_timing *out);
+
 /* Instrumented pass over the bound cloud (not for timing): fills the counters above. */
 int kpl_collect_stats(kpl_detector *h, kpl_stats *out, void *stream);
 

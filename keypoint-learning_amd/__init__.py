@@ -32,6 +32,11 @@ class Params(C.Structure):
                 ("non_maxima_draws_threshold", C.c_float)]
 
 
+class Timing(C.Structure):
+    _fields_ = [("calls", C.c_int), ("index_ms", C.c_float), ("score_ms", C.c_float),
+                ("nms_ms", C.c_float)]
+
+
 class Stats(C.Structure):
     _fields_ = [(k, C.c_int64) for k in ("n_points", "n_scored", "n_thresholded", "sum_kf",
                                          "sum_kn", "sum_depth", "n_keypoints", "n_cells")]
@@ -64,6 +69,8 @@ SYMBOLS = {
     "kpl_detect_device": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
     "kpl_compute_device": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
     "kpl_compute_features_device": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),
+    "kpl_enable_timing": (C.c_int, [_vp, C.c_int]),
+    "kpl_get_timing": (C.c_int, [_vp, C.POINTER(Timing)]),
     "kpl_collect_stats": (C.c_int, [_vp, C.POINTER(Stats), _vp]),
     "kpl_cloud_resolution": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
 }
@@ -265,6 +272,14 @@ class KeypointLearningDetector:
     def computeDevice(self, d_scores, d_kp_idx, kp_cap, d_kp_count, stream=None):
         self._push()
         self._check(self._lib.kpl_compute_device(self._h, d_scores, d_kp_idx, kp_cap, d_kp_count, stream))
+
+    def enableTiming(self, on=True):
+        self._check(self._lib.kpl_enable_timing(self._h, int(on)))
+
+    def getTiming(self):
+        t = Timing()
+        self._check(self._lib.kpl_get_timing(self._h, C.byref(t)))
+        return {"calls": t.calls, "index_ms": t.index_ms, "score_ms": t.score_ms, "nms_ms": t.nms_ms}
 
     def collectStats(self, stream=None):
         self._push()

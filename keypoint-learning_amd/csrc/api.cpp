@@ -14,6 +14,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "forest.h"
 #include "kernels.h"
@@ -71,6 +72,13 @@ struct kpl_detector {
     DevBuf score_sorted, flags, prefix, stats, out_scores, out_kp, out_count;
     uint32_t *h_bbox = nullptr;   // pinned
     int *h_count = nullptr;       // pinned
+
+    // optional per-phase event timing (kpl_enable_timing)
+    bool timing = false;
+    std::vector<hipEvent_t> ev_pool;   // created lazily, reused
+    size_t ev_used = 0;
+    struct Span { int phase; size_t a, b; };
+    std::vector<Span> spans;
 };
 
 namespace {
@@ -93,6 +101,25 @@ int fail(kpl_detector *h, int code, const char *fmt, ...) {
         if (e_ != hipSuccess)                                                                  \
             return fail(h, KPL_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(e_));     \
     } while (0)
+
+constexpr size_t kMaxSpans = 3 * 4096;
+
+// records an event on `st`; returns its pool slot or SIZE_MAX when timing is off / full
+size_t mark(kpl_detector *h, hipStream_t st) {
+    if (!h->timing || h->spans.size() >= kMaxSpans) return SIZE_MAX;
+    if (h->ev_used == h->ev_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return SIZE_MAX;
+        h->ev_pool.push_back(e);
+    }
+    const size_t slot = h->ev_used++;
+    if (hipEventRecord(h->ev_pool[slot], st) != hipSuccess) return SIZE_MAX;
+    return slot;
+}
+
+void span(kpl_detector *h, int phase, size_t a, size_t b) {
+    if (a != SIZE_MAX && b != SIZE_MAX) h->spans.push_back({phase, a, b});
+}
 
 int use_device(kpl_detector *h) {
     KPL_HIP(h, hipSetDevice(h->device));
@@ -200,12 +227,14 @@ int build_index(kpl_detector *h, hipStream_t st) {
     KPL_HIP(h, h->pts.ensure(sizeof(float4) * nn));
     KPL_HIP(h, h->nrm.ensure(sizeof(float4) * nn));
     KPL_HIP(h, h->pos_of.ensure(sizeof(int) * nn));
+    const size_t ev0 = mark(h, st);
     launch_cell_count(h->d_xyz, h->xs, n, g, h->cid.as<int>(), h->cnt.as<int>(), st);
     launch_exclusive_scan(h->cnt.as<int>(), h->cell_start.as<int>(), g.ncells, h->scan_tmp.as<int>(), st);
     KPL_HIP(h, hipMemcpyAsync(h->cursor.p, h->cell_start.p, sizeof(int) * ((size_t)nc + 1), hipMemcpyDeviceToDevice, st));
     launch_scatter(h->cid.as<int>(), n, h->cell_start.as<int>(), h->cursor.as<int>(), h->tmp_idx.as<int>(), st);
     launch_rank_store(h->d_xyz, h->xs, h->d_nrm, h->ns, n, g, h->cid.as<int>(), h->cell_start.as<int>(),
                       h->tmp_idx.as<int>(), h->pts.as<float4>(), h->nrm.as<float4>(), h->pos_of.as<int>(), st);
+    span(h, 0, ev0, mark(h, st));
     KPL_HIP(h, hipGetLastError());
     h->grid = g;
     h->index_valid = true;
@@ -241,12 +270,16 @@ int detect_on_device(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap
     const NmsDesc nd = make_nms(h->prm);
     ForestDev fd{h->d_nodes.as<uint2>(), h->d_roots.as<uint32_t>(), h->flat.ntrees};
     if (d_scores) launch_fill_f32(d_scores, NAN, n, st);
+    const size_t ev1 = mark(h, st);
     launch_score(h->pts.as<float4>(), h->nrm.as<float4>(), h->cell_start.as<int>(), h->grid, f, fd, n,
                  h->score_sorted.as<float>(), d_scores, d_stats, st);
+    const size_t ev2 = mark(h, st);
+    span(h, 1, ev1, ev2);
     launch_nms(h->pts.as<float4>(), h->cell_start.as<int>(), h->grid, nd, h->score_sorted.as<float>(), n,
                h->flags.as<int>(), d_stats, st);
     launch_exclusive_scan(h->flags.as<int>(), h->prefix.as<int>(), n, h->scan_tmp.as<int>(), st);
     launch_compact(h->flags.as<int>(), h->prefix.as<int>(), n, d_kp_idx, kp_cap, d_kp_count, st);
+    span(h, 2, ev2, mark(h, st));
     KPL_HIP(h, hipGetLastError());
     return KPL_OK;
 }
@@ -339,6 +372,7 @@ void kpl_destroy(kpl_detector *h) {
                       &h->pts, &h->nrm, &h->pos_of, &h->score_sorted, &h->flags, &h->prefix, &h->stats,
                       &h->out_scores, &h->out_kp, &h->out_count};
     for (DevBuf *b : bufs) b->release();
+    for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->h_bbox) (void)hipHostFree(h->h_bbox);
     if (h->h_count) (void)hipHostFree(h->h_count);
     delete h;
@@ -508,6 +542,32 @@ int kpl_compute_features(kpl_detector *h, const void *xyz, size_t xyz_stride, co
     if (rc) return rc;
     KPL_HIP(h, hipStreamSynchronize(nullptr));
     KPL_HIP(h, hipMemcpy(features_out, h->stage_feat.p, sizeof(float) * (size_t)m * F, hipMemcpyDeviceToHost));
+    return KPL_OK;
+}
+
+int kpl_enable_timing(kpl_detector *h, int enable) {
+    if (!h) return KPL_ERR_INVALID_ARG;
+    h->timing = enable != 0;
+    h->spans.clear();
+    h->ev_used = 0;
+    return KPL_OK;
+}
+
+int kpl_get_timing(kpl_detector *h, kpl_timing *out) {
+    if (!h || !out) return KPL_ERR_INVALID_ARG;
+    memset(out, 0, sizeof(*out));
+    int rc = use_device(h);
+    if (rc) return rc;
+    for (const auto &sp : h->spans) {
+        KPL_HIP(h, hipEventSynchronize(h->ev_pool[sp.b]));
+        float ms = 0.0f;
+        KPL_HIP(h, hipEventElapsedTime(&ms, h->ev_pool[sp.a], h->ev_pool[sp.b]));
+        if (sp.phase == 0) out->index_ms += ms;
+        else if (sp.phase == 1) { out->score_ms += ms; out->calls++; }
+        else out->nms_ms += ms;
+    }
+    h->spans.clear();
+    h->ev_used = 0;
     return KPL_OK;
 }
 
