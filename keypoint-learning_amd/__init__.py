@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkpl.so")
+LIB_PATH = os.environ.get("KPL_LIB_PATH") or os.path.join(_HERE, "libkpl.so")
 
 OK, ERR_INVALID_ARG, ERR_NO_FOREST, ERR_FOREST_PARSE, ERR_VAR_COUNT, ERR_GRID_TOO_LARGE, \
     ERR_CAPACITY, ERR_DEVICE, ERR_UNSUPPORTED, ERR_IO, ERR_NO_CLOUD = range(11)

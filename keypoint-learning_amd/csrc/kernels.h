@@ -7,6 +7,7 @@
 //   cell_start[c]    first storage position of grid cell c, c = (cz*ny + cy)*nx + cx; a run of
 //                    cells along x is therefore ONE contiguous range of pts/nrm
 //   pos_of[i]        storage position of original point i, -1 if its xyz is not finite
+//   nbr.ent          per-point neighbor lists {storage position, d2}, see NbrLists
 //   score_sorted[s]  forest response in storage order (what the NMS kernel gathers)
 //   flags[i]         1 if original point i is a keypoint (compacted in ascending i)
 // Canonical storage order = ascending (cell id, original index); it is what makes the float
@@ -31,8 +32,10 @@ struct FeatDesc {
     float support;   // (float)radius_search, the `support` argument of findAnnulusPair
     float ann_dim;   // support / A
     float ann_half;  // ann_dim / 2
+    float ann_rdim;  // RN(1 / ann_dim), for the exact 3-instruction division (kernels.hip div_rn)
     float bin_dim;   // 2 / (float)B
     float bin_half;
+    float bin_rdim;
     float r2;        // (float)(r*r), product in double -- KdTreeFLANN::radiusSearch
     float rr;        // (float)(r*(1+2^-10)): half width of the cell box that is searched
 };
@@ -47,6 +50,15 @@ struct ForestDev {
     const uint2 *nodes;
     const uint32_t *roots;
     int ntrees;
+};
+
+// Per-point neighbor lists written by the search half of the score kernel and re-read by its
+// accumulate half (and by the NMS kernel): entry e of the 64 lanes of wave w is the 512-byte
+// segment ent[(w * cap + e) * 64 .. +64); x = storage position of the neighbor, y = bits of d2.
+struct NbrLists {
+    uint2 *ent;
+    int *count;   // [storage position] K_f when the list in memory is the complete neighborhood, else -1
+    int cap;      // entries per lane, multiple of 4, >= 8
 };
 
 struct StatsDev {
@@ -70,13 +82,13 @@ void launch_rank_store(const char *xyz, size_t xs, const char *nrm, size_t ns, i
 // ---- scoring ("runForest") ----------------------------------------------------------------
 // scores[i] (original order, may be null) and score_sorted[s]; NaN where not scoreable.
 void launch_score(const float4 *pts, const float4 *nrm, const int *cell_start, GridDesc g,
-                  FeatDesc f, ForestDev forest, int n, float *score_sorted, float *scores,
-                  StatsDev *stats, hipStream_t st);
+                  FeatDesc f, ForestDev forest, NbrLists lists, int n, float *score_sorted,
+                  float *scores, StatsDev *stats, hipStream_t st);
 int score_block_size(int F);
 // features of listed points -> out[m*F]
 void launch_features(const float4 *pts, const float4 *nrm, const int *cell_start,
-                     const int *pos_of, GridDesc g, FeatDesc f, const int *query, int m, int n,
-                     float *out, hipStream_t st);
+                     const int *pos_of, GridDesc g, FeatDesc f, NbrLists lists, const int *query,
+                     int m, int n, float *out, hipStream_t st);
 void launch_fill_f32(float *p, float v, int n, hipStream_t st);
 
 // ---- NMS + compaction ("detectKeypoints") -------------------------------------------------

@@ -9,6 +9,7 @@
 #include "kernels.h"
 
 #include <cmath>
+#include <cstdlib>
 
 namespace kpl {
 
@@ -67,13 +68,27 @@ __global__ __launch_bounds__(256) void bbox_kernel(const char *xyz, size_t strid
             mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], off));
         }
     }
+    // one atomic per block and component: tens of thousands of same-address atomics serialise
+    __shared__ float red[2][3][256 / kWave];
+    const int wid = threadIdx.x / kWave;
     if ((threadIdx.x & (kWave - 1)) == 0) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            if (mn[k] <= mx[k]) {
-                atomicMin(&bbox[k], enc_f32(mn[k]));
-                atomicMax(&bbox[3 + k], enc_f32(mx[k]));
-            }
+            red[0][k][wid] = mn[k];
+            red[1][k][wid] = mx[k];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int k = threadIdx.x;
+        float a = red[0][k][0], b = red[1][k][0];
+        for (int w = 1; w < 256 / kWave; ++w) {
+            a = fminf(a, red[0][k][w]);
+            b = fmaxf(b, red[1][k][w]);
+        }
+        if (a <= b) {
+            atomicMin(&bbox[k], enc_f32(a));
+            atomicMax(&bbox[3 + k], enc_f32(b));
         }
     }
 }
@@ -208,18 +223,32 @@ __global__ __launch_bounds__(256) void rank_store_kernel(const char *xyz, size_t
 }
 
 // ---------------------------------------------------------------------------------------------
-// Soft assignment, /root/reference/src/KeypointLearning.cpp:41-65 and :68-92.  dim and dim/2
-// are per-launch constants computed on the host with the same float operations.  The
+// Soft assignment, /root/reference/src/KeypointLearning.cpp:41-65 and :68-92.  dim, dim/2 and
+// RN(1/dim) are per-launch constants computed on the host with float operations.  The
 // reference's assert on the index range is replaced by a clamp (no effect on in-range values).
+//
+// div_rn(a, b, rb) returns the correctly rounded float quotient a / b, bit-identical to the IEEE
+// division the reference performs, in 3 instructions instead of hipcc's ~11-instruction
+// expansion: with rb = RN(1/b), q = RN(a*rb) is within one ulp of a/b, r = a - q*b is exact in
+// one FMA, and RN(q + r*rb) is the correctly rounded quotient (Markstein's division theorem;
+// b is a positive normal constant here and a/b stays far from overflow; a quotient that
+// underflows is only ever floored to 0).  The FMAs are explicit, -ffp-contract=off stays in force
+// for everything else.  tests/test_division.py checks it against true division.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void soft_pair(int n, float v, float dim, float half_dim, int &k,
-                                          int &p, float &w) {
-    k = (int)floorf(v / dim);
+__device__ __forceinline__ float div_rn(float a, float b, float rb) {
+    const float q = a * rb;
+    const float r = __builtin_fmaf(-q, b, a);
+    return __builtin_fmaf(r, rb, q);
+}
+
+__device__ __forceinline__ void soft_pair(int n, float v, float dim, float half_dim, float rdim,
+                                          int &k, int &p, float &w) {
+    k = (int)floorf(div_rn(v, dim, rdim));
     if (k == n) k--;
     k = min(max(k, 0), n - 1);
     float center = ((float)k * dim) + half_dim;
     float wt = v - center;
-    wt = wt / dim;
+    wt = div_rn(wt, dim, rdim);
     p = (wt > 0) ? k + 1 : k - 1;
     if (p == -1) p = 0;
     if (p == n) p = k;
@@ -251,104 +280,255 @@ __device__ __forceinline__ float dist2(float px, float py, float pz, const float
     return d;
 }
 
-// computePointFeatures, hpp:321-376.  One lane = one query point; the A x B histogram of the
-// lane lives in LDS as H[c * BLOCK + tid] (bank = tid mod 32: conflict free).  Neighbors are
-// visited in canonical order (rows of cells ascending, storage positions ascending), the first
-// accepted one is dropped (hpp:336 starts at neigh_indx = 1).  Returns K_f.
-template <int BLOCK>
+// computePointFeatures, hpp:321-376.  One lane = one query point, one wave = 64 consecutive
+// storage positions (spatially coherent: same or adjacent cells).
+//   H[c * 64 + lane]          LDS: the lane's A x B histogram       (bank = lane mod 32: no conflicts)
+//   ent[e * 64 + lane]        HBM/L2: the lane's neighbor list, entry = {storage position, d2 bits};
+//                             entry e of the 64 lanes of a wave is one 512-byte segment, so a wave
+//                             whose lanes advance together writes and re-reads it coalesced
+// Neighbors are visited in canonical order (rows of cells ascending, storage positions
+// ascending); the first accepted one is dropped (hpp:336 starts at neigh_indx = 1).
+//
+// The work is split so that the expensive part only ever runs on accepted neighbors, with the
+// lanes of a wave in step:
+//   search   distance tests only, 4 candidates per step, the next 4 candidates' 16-B loads already
+//            in flight; accepted candidates are appended to the lane's list.  The wave keeps
+//            searching while ANY lane still has room and candidates in the current row of cells;
+//   drain    every lane walks its list in order: sqrt, two soft assignments, 4 histogram adds,
+//            with the next entries and the next normal already in flight.  With the default list
+//            capacity a lane's whole neighborhood fits, so there is one drain per point and the
+//            wave runs max-K iterations, not a per-row or per-queue maximum each time.
+// The 4 adds of one neighbor may hit the same cell (pair == index at the range ends -- the common
+// case for bin 0); the cells are read once, the adds are forwarded through registers in the
+// reference's order (hpp:350-355) and written back in order, so the float result is exactly the
+// one the sequential "+=" chain gives while only one LDS round trip sits on the critical path.
+constexpr int kLanes = 64;   // one wave per workgroup: waves never synchronise with each other
+
+__device__ __forceinline__ void accumulate_neighbor(const FeatDesc &f, float *H, float d2,
+                                                    const float4 &np, const float4 &nq) {
+    const float dot = np.x * nq.x + (np.y * nq.y + np.z * nq.z);                   // hpp:342
+    float cosine = 1 - dot;
+    int a, ap, bi, bp;
+    float aw, bw;
+    soft_pair(f.A, sqrtf(d2), f.ann_dim, f.ann_half, f.ann_rdim, a, ap, aw);       // hpp:345
+    if (cosine < 0) cosine = 0;                                                    // cpp:70-73
+    if (cosine > 2) cosine = 2;
+    soft_pair(f.B, cosine, f.bin_dim, f.bin_half, f.bin_rdim, bi, bp, bw);         // hpp:348
+    const float w00 = (1 - bw) * (1 - aw);
+    const float w01 = bw * (1 - aw);
+    const float w10 = (1 - bw) * aw;
+    const float w11 = bw * aw;
+    const int c0 = a * f.B + bi, c1 = a * f.B + bp, c2 = ap * f.B + bi, c3 = ap * f.B + bp;
+    float *h = H + threadIdx.x;
+#if defined(KPL_ABLATE) && (KPL_ABLATE & 8)
+    h[0] += (w00 + w01 + w10 + w11) * (float)(c0 + c1 + c2 + c3);   // timing experiment: math only
+    return;
+#endif
+    const float v0 = h[c0 * kLanes], v1 = h[c1 * kLanes], v2 = h[c2 * kLanes], v3 = h[c3 * kLanes];
+    const float x0 = v0 + w00;                                                     // hpp:350
+    const float x1 = ((c1 == c0) ? x0 : v1) + w01;                                 // hpp:351
+    const float x2 = ((c2 == c1) ? x1 : (c2 == c0) ? x0 : v2) + w10;               // hpp:354
+    const float x3 = ((c3 == c2) ? x2 : (c3 == c1) ? x1 : (c3 == c0) ? x0 : v3) + w11;  // hpp:355
+    h[c0 * kLanes] = x0;
+    h[c1 * kLanes] = x1;
+    h[c2 * kLanes] = x2;
+    h[c3 * kLanes] = x3;
+}
+
+// drains the lane's list entries [first, count) in order; `ent` already points at the lane's column
+__device__ __forceinline__ void drain_list(const float4 *__restrict__ nrm, const FeatDesc &f,
+                                           float *H, const uint2 *ent, int first, int count,
+                                           const float4 &np) {
+    if (first >= count) return;
+#if defined(KPL_ABLATE) && (KPL_ABLATE & 2)
+    return;   // timing experiment only: no accumulation
+#endif
+    uint2 e0 = ent[first * kLanes];
+    uint2 e1 = ent[min(first + 1, count - 1) * kLanes];
+    float4 nq = nrm[e0.x];
+    for (int e = first; e < count; ++e) {
+        const uint2 cur = e0;
+        const float4 nc = nq;
+        e0 = e1;
+        if (e + 1 < count) nq = nrm[e0.x];                 // next normal in flight
+        if (e + 2 < count) e1 = ent[(e + 2) * kLanes];     // list entry two ahead in flight
+        if (nc.w != 0.0f)                                                          // hpp:338
+            accumulate_neighbor(f, H, __uint_as_float(cur.y), np, nc);
+    }
+}
+
+struct Cand4 {
+    float4 q0, q1, q2, q3;
+};
+
+__device__ __forceinline__ Cand4 load_cand4(const float4 *__restrict__ pts, int t, int t1) {
+    const int last = t1 - 1;
+    Cand4 c;
+    c.q0 = pts[t];
+    c.q1 = pts[min(t + 1, last)];
+    c.q2 = pts[min(t + 2, last)];
+    c.q3 = pts[min(t + 3, last)];
+    return c;
+}
+
+// Returns K_f.  *reusable is set to 0 when the list had to be drained before the end (the list
+// left in memory is then not the complete neighborhood).
 __device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
                                               const float4 *__restrict__ nrm,
                                               const int *__restrict__ cell_start,
                                               const GridDesc &g, const FeatDesc &f, float4 p,
-                                              float4 np, float *H) {
+                                              float4 np, float *H, uint2 *ent, int cap,
+                                              bool active, int *reusable) {
     const int tid = threadIdx.x;
-    for (int c = 0; c < f.F; ++c) H[c * BLOCK + tid] = 0.0f;                     // hpp:325
+    for (int c = 0; c < f.F; ++c) H[c * kLanes + tid] = 0.0f;                    // hpp:325
     const CellBox b = make_box(g, p.x, p.y, p.z, f.rr);
-    int seen = 0;
-    for (int cz = b.lo[2]; cz <= b.hi[2]; ++cz) {
-        for (int cy = b.lo[1]; cy <= b.hi[1]; ++cy) {
+    const int ny = active ? b.hi[1] - b.lo[1] + 1 : 0;
+    const int nrows = active ? ny * (b.hi[2] - b.lo[2] + 1) : 0;
+    const int room = cap - 4;   // a lane may take another 4-candidate step while count <= room
+    int kf = 0;          // accepted so far (K_f, including the dropped first one)
+    int count = 0;       // entries in the list
+    int first = 1;       // 1 until the first accepted neighbor has been dropped (hpp:336)
+    *reusable = 1;
+    for (int ri = 0; __any(ri < nrows); ++ri) {
+        int t = 0, t1 = 0;
+        if (ri < nrows) {
+            const int cz = b.lo[2] + ri / ny, cy = b.lo[1] + ri % ny;
             const int row = (cz * g.dims[1] + cy) * g.dims[0];
-            const int t0 = cell_start[row + b.lo[0]];
-            const int t1 = cell_start[row + b.hi[0] + 1];
-            for (int t = t0; t < t1; ++t) {
-                const float4 q = pts[t];
-                const float d2 = dist2(p.x, p.y, p.z, q);
-                if (!(d2 < f.r2)) continue;                                        // strict
-                if (seen++ == 0) continue;                                         // hpp:336
-                const float4 nq = nrm[t];
-                if (nq.w == 0.0f) continue;                                        // hpp:338
-                const float dot = np.x * nq.x + (np.y * nq.y + np.z * nq.z);       // hpp:342
-                float cosine = 1 - dot;
-                int a, ap, bi, bp;
-                float aw, bw;
-                soft_pair(f.A, sqrtf(d2), f.ann_dim, f.ann_half, a, ap, aw);       // hpp:345
-                if (cosine < 0) cosine = 0;                                        // cpp:70-73
-                if (cosine > 2) cosine = 2;
-                soft_pair(f.B, cosine, f.bin_dim, f.bin_half, bi, bp, bw);         // hpp:348
-                const float w00 = (1 - bw) * (1 - aw);
-                const float w01 = bw * (1 - aw);
-                const float w10 = (1 - bw) * aw;
-                const float w11 = bw * aw;
-                float *h0 = H + (a * f.B) * BLOCK + tid;
-                float *h1 = H + (ap * f.B) * BLOCK + tid;
-                h0[bi * BLOCK] += w00;                                             // hpp:350
-                h0[bp * BLOCK] += w01;                                             // hpp:351
-                h1[bi * BLOCK] += w10;                                             // hpp:354
-                h1[bp * BLOCK] += w11;                                             // hpp:355
+            t = cell_start[row + b.lo[0]];
+            t1 = cell_start[row + b.hi[0] + 1];
+        }
+        Cand4 pre;
+        if (t < t1) pre = load_cand4(pts, t, t1);
+        for (;;) {
+            // search: strict d2 < r2 (KdTreeFLANN::radiusSearch)
+            while (__any((t < t1) & (count <= room))) {
+                if ((t < t1) & (count <= room)) {
+                    const Cand4 c = pre;
+                    const int tc = t;
+                    t += 4;
+                    if (t < t1) pre = load_cand4(pts, t, t1);     // next step's loads in flight
+                    const float d0 = dist2(p.x, p.y, p.z, c.q0);
+                    const float d1 = dist2(p.x, p.y, p.z, c.q1);
+                    const float d2 = dist2(p.x, p.y, p.z, c.q2);
+                    const float d3 = dist2(p.x, p.y, p.z, c.q3);
+                    const bool h0 = d0 < f.r2;
+                    const bool h1 = (d1 < f.r2) & (tc + 1 < t1);
+                    const bool h2 = (d2 < f.r2) & (tc + 2 < t1);
+                    const bool h3 = (d3 < f.r2) & (tc + 3 < t1);
+                    if (h0) { ent[count * kLanes] = make_uint2((unsigned)tc, __float_as_uint(d0)); ++count; }
+                    if (h1) { ent[count * kLanes] = make_uint2((unsigned)(tc + 1), __float_as_uint(d1)); ++count; }
+                    if (h2) { ent[count * kLanes] = make_uint2((unsigned)(tc + 2), __float_as_uint(d2)); ++count; }
+                    if (h3) { ent[count * kLanes] = make_uint2((unsigned)(tc + 3), __float_as_uint(d3)); ++count; }
+                }
             }
+            if (!__any(count > room)) break;   // nobody is full: the row is finished
+            drain_list(nrm, f, H, ent, first, count, np);
+            kf += count;
+            if (count > 0) first = 0;
+            count = 0;
+            *reusable = 0;
         }
     }
+    drain_list(nrm, f, H, ent, first, count, np);
+    kf += count;
     for (int a = 0; a < f.A; ++a) {                                                // hpp:360-370
-        float *h = H + (a * f.B) * BLOCK + tid;
+        float *h = H + (a * f.B) * kLanes + tid;
         float s = 0.0f;
         for (int k = 0; k < f.B; ++k) {
-            float v = h[k * BLOCK];
+            float v = h[k * kLanes];
             s += v * v;
         }
         const float nr = sqrtf(s);
         if (nr > 0)
-            for (int k = 0; k < f.B; ++k) h[k * BLOCK] = h[k * BLOCK] / nr;
+            for (int k = 0; k < f.B; ++k) h[k * kLanes] = h[k * kLanes] / nr;
     }
-    return seen;
+    return kf;
 }
 
 // runForest, hpp:267-296 + cv::ml::RTrees::predict(PREDICT_SUM) restated (hpp:281): per tree
-// walk "val <= thr ? left : right", double sum of leaf values, (float)sum,
-// score = 1 - sum / (T * 1.0f).
-template <int BLOCK, bool STATS>
-__global__ __launch_bounds__(BLOCK) void score_kernel(const float4 *__restrict__ pts,
-                                                      const float4 *__restrict__ nrm,
-                                                      const int *__restrict__ cell_start,
-                                                      GridDesc g, FeatDesc f, ForestDev forest,
-                                                      float *__restrict__ score_sorted,
-                                                      float *__restrict__ scores,
-                                                      StatsDev *stats) {
-    extern __shared__ float H[];
-    const int s = blockIdx.x * BLOCK + threadIdx.x;
-    const int nfinite = cell_start[g.ncells];
-    if (s >= nfinite) return;
-    const float4 p = pts[s];
-    const float4 np = nrm[s];
-    float score = NAN;
-    if (np.w != 0.0f) {                                                            // hpp:277
-        const int kf = point_features<BLOCK>(pts, nrm, cell_start, g, f, p, np, H);
-        double sum = 0.0;
-        int depth = 0;
-        for (int t = 0; t < forest.ntrees; ++t) {
-            uint32_t nd = forest.roots[t];
-            for (;;) {
-                const uint2 node = forest.nodes[nd];
-                const uint32_t var = node.y >> 24;
-                if (STATS) ++depth;
-                if (var == 255u) {
-                    sum += (double)__uint_as_float(node.x);
-                    break;
-                }
-                const float val = H[var * BLOCK + threadIdx.x];
-                nd = (node.y & 0x00ffffffu) + (val <= __uint_as_float(node.x) ? 0u : 1u);
-            }
+// walk "val <= thr ? left : right", double sum of leaf values in tree order, (float)sum,
+// score = 1 - sum / (T * 1.0f).  kTreeWays trees are walked at once per lane so that several
+// dependent node loads are in flight; a finished walk re-reads its leaf until the others end.
+constexpr int kTreeWays = 4;
+
+template <bool STATS>
+__device__ __forceinline__ float forest_sum(const ForestDev &forest, const float *H, int &depth) {
+    double sum = 0.0;
+    const float *x = H + threadIdx.x;
+    for (int t0 = 0; t0 < forest.ntrees; t0 += kTreeWays) {
+        uint32_t nd[kTreeWays];
+        float leaf[kTreeWays];
+        bool done[kTreeWays];
+#pragma unroll
+        for (int k = 0; k < kTreeWays; ++k) {
+            done[k] = t0 + k >= forest.ntrees;
+            nd[k] = forest.roots[done[k] ? t0 : t0 + k];
+            leaf[k] = 0.0f;
         }
-        const float fsum = (float)sum;
+        for (;;) {
+            uint2 node[kTreeWays];
+#pragma unroll
+            for (int k = 0; k < kTreeWays; ++k) node[k] = forest.nodes[nd[k]];
+            bool all_done = true;
+#pragma unroll
+            for (int k = 0; k < kTreeWays; ++k) {
+                const uint32_t var = node[k].y >> 24;
+                if (!done[k]) {
+                    if (STATS) ++depth;
+                    if (var == 255u) {
+                        leaf[k] = __uint_as_float(node[k].x);
+                        done[k] = true;
+                    } else {
+                        const float val = x[var * kLanes];
+                        nd[k] = (node[k].y & 0x00ffffffu) + (val <= __uint_as_float(node[k].x) ? 0u : 1u);
+                    }
+                }
+                all_done &= done[k];
+            }
+            if (all_done) break;
+        }
+#pragma unroll
+        for (int k = 0; k < kTreeWays; ++k)
+            if (t0 + k < forest.ntrees) sum += (double)leaf[k];
+    }
+    return (float)sum;
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(kLanes) void score_kernel(const float4 *__restrict__ pts,
+                                                       const float4 *__restrict__ nrm,
+                                                       const int *__restrict__ cell_start,
+                                                       GridDesc g, FeatDesc f, ForestDev forest,
+                                                       NbrLists lists,
+                                                       float *__restrict__ score_sorted,
+                                                       float *__restrict__ scores,
+                                                       StatsDev *stats) {
+    extern __shared__ float H[];
+#if defined(KPL_ABLATE) && (KPL_ABLATE & 16)
+    const unsigned long long stamp0 = __builtin_amdgcn_s_memtime();   // diagnostic build only
+#endif
+    const int s = blockIdx.x * kLanes + threadIdx.x;
+    const int nfinite = cell_start[g.ncells];
+    const bool in_range = s < nfinite;
+    const float4 p = in_range ? pts[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 np = in_range ? nrm[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool scoreable = in_range && np.w != 0.0f;                               // hpp:277
+    uint2 *ent = lists.ent + (size_t)blockIdx.x * lists.cap * kLanes + threadIdx.x;
+    // every lane of the wave runs the feature code (wave-level votes inside); lanes without a
+    // scoreable point simply have no rows
+    int reusable;
+    const int kf = point_features(pts, nrm, cell_start, g, f, p, np, H, ent, lists.cap, scoreable,
+                                  &reusable);
+    if (!in_range) return;
+    lists.count[s] = (scoreable && reusable) ? kf : -1;
+    float score = NAN;
+    if (scoreable) {
+        int depth = 0;
+#if defined(KPL_ABLATE) && (KPL_ABLATE & 1)
+        const float fsum = 0.0f;   // timing experiment only: no forest walk
+#else
+        const float fsum = forest_sum<STATS>(forest, H, depth);
+#endif
         score = 1 - (fsum / (forest.ntrees * 1.0f));                               // hpp:287
         if (STATS) {
             atomicAdd(&stats->sum_kf, (unsigned long long)kf);
@@ -356,31 +536,36 @@ __global__ __launch_bounds__(BLOCK) void score_kernel(const float4 *__restrict__
             atomicAdd(&stats->n_scored, 1ull);
         }
     }
+#if defined(KPL_ABLATE) && (KPL_ABLATE & 16)
+    score = (float)(__builtin_amdgcn_s_memtime() - stamp0);   // diagnostic build only
+#endif
     score_sorted[s] = score;
     if (scores) scores[__float_as_int(p.w)] = score;
 }
 
 // computePointsForTrainingFeatures, hpp:299-318: same feature code, sparse query list.
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void features_kernel(const float4 *__restrict__ pts,
-                                                         const float4 *__restrict__ nrm,
-                                                         const int *__restrict__ cell_start,
-                                                         const int *__restrict__ pos_of,
-                                                         GridDesc g, FeatDesc f,
-                                                         const int *__restrict__ query, int m,
-                                                         int n, float *__restrict__ out) {
+__global__ __launch_bounds__(kLanes) void features_kernel(const float4 *__restrict__ pts,
+                                                          const float4 *__restrict__ nrm,
+                                                          const int *__restrict__ cell_start,
+                                                          const int *__restrict__ pos_of,
+                                                          GridDesc g, FeatDesc f, NbrLists lists,
+                                                          const int *__restrict__ query, int m,
+                                                          int n, float *__restrict__ out) {
     extern __shared__ float H[];
-    const int qi = blockIdx.x * BLOCK + threadIdx.x;
-    if (qi >= m) return;
-    const int i = query[qi];
-    const int s = (i >= 0 && i < n) ? pos_of[i] : -1;
-    float *o = out + (size_t)qi * f.F;
-    if (s < 0) {
-        for (int c = 0; c < f.F; ++c) o[c] = NAN;
-        return;
+    const int qi = blockIdx.x * kLanes + threadIdx.x;
+    int s = -1;
+    if (qi < m) {
+        const int i = query[qi];
+        s = (i >= 0 && i < n) ? pos_of[i] : -1;
     }
-    point_features<BLOCK>(pts, nrm, cell_start, g, f, pts[s], nrm[s], H);
-    for (int c = 0; c < f.F; ++c) o[c] = H[c * BLOCK + threadIdx.x];
+    const float4 p = s >= 0 ? pts[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 np = s >= 0 ? nrm[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+    uint2 *ent = lists.ent + (size_t)blockIdx.x * lists.cap * kLanes + threadIdx.x;
+    int reusable;
+    point_features(pts, nrm, cell_start, g, f, p, np, H, ent, lists.cap, s >= 0, &reusable);
+    if (qi >= m) return;
+    float *o = out + (size_t)qi * f.F;
+    for (int c = 0; c < f.F; ++c) o[c] = s >= 0 ? H[c * kLanes + threadIdx.x] : NAN;
 }
 
 __global__ void fill_f32_kernel(float *p, float v, int n) {
@@ -457,7 +642,7 @@ void launch_bbox(const char *xyz, size_t stride, int n, uint32_t *bbox, hipStrea
     (void)hipMemcpyAsync(bbox, init, sizeof(init), hipMemcpyHostToDevice, st);
     if (n <= 0) return;
     int blocks = div_up(n, 256);
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 512) blocks = 512;
     bbox_kernel<<<blocks, 256, 0, st>>>(xyz, stride, n, bbox);
 }
 
@@ -497,61 +682,28 @@ void launch_rank_store(const char *xyz, size_t xs, const char *nrm, size_t ns, i
                                                       tmp_idx, pts, nrmo, pos_of);
 }
 
-int score_block_size(int F) {
-    if (F <= 32) return 256;
-    if (F <= 64) return 128;
-    return 64;
-}
-
-template <int BLOCK>
-static void launch_score_b(const float4 *pts, const float4 *nrm, const int *cell_start,
-                           GridDesc g, FeatDesc f, ForestDev forest, int n, float *score_sorted,
-                           float *scores, StatsDev *stats, hipStream_t st) {
-    const size_t lds = sizeof(float) * (size_t)f.F * BLOCK;
-    if (stats) {
-        (void)hipFuncSetAttribute((const void *)score_kernel<BLOCK, true>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        score_kernel<BLOCK, true><<<div_up(n, BLOCK), BLOCK, lds, st>>>(
-            pts, nrm, cell_start, g, f, forest, score_sorted, scores, stats);
-    } else {
-        (void)hipFuncSetAttribute((const void *)score_kernel<BLOCK, false>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        score_kernel<BLOCK, false><<<div_up(n, BLOCK), BLOCK, lds, st>>>(
-            pts, nrm, cell_start, g, f, forest, score_sorted, scores, stats);
-    }
-}
+int score_block_size(int F) { (void)F; return kLanes; }
 
 void launch_score(const float4 *pts, const float4 *nrm, const int *cell_start, GridDesc g,
-                  FeatDesc f, ForestDev forest, int n, float *score_sorted, float *scores,
-                  StatsDev *stats, hipStream_t st) {
+                  FeatDesc f, ForestDev forest, NbrLists lists, int n, float *score_sorted,
+                  float *scores, StatsDev *stats, hipStream_t st) {
     if (n <= 0) return;
-    switch (score_block_size(f.F)) {
-        case 256: launch_score_b<256>(pts, nrm, cell_start, g, f, forest, n, score_sorted, scores, stats, st); break;
-        case 128: launch_score_b<128>(pts, nrm, cell_start, g, f, forest, n, score_sorted, scores, stats, st); break;
-        default:  launch_score_b<64>(pts, nrm, cell_start, g, f, forest, n, score_sorted, scores, stats, st); break;
-    }
-}
-
-template <int BLOCK>
-static void launch_features_b(const float4 *pts, const float4 *nrm, const int *cell_start,
-                              const int *pos_of, GridDesc g, FeatDesc f, const int *query, int m,
-                              int n, float *out, hipStream_t st) {
-    const size_t lds = sizeof(float) * (size_t)f.F * BLOCK;
-    (void)hipFuncSetAttribute((const void *)features_kernel<BLOCK>,
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    features_kernel<BLOCK><<<div_up(m, BLOCK), BLOCK, lds, st>>>(pts, nrm, cell_start, pos_of, g,
-                                                                  f, query, m, n, out);
+    const size_t lds = sizeof(float) * (size_t)f.F * kLanes;
+    if (stats)
+        score_kernel<true><<<div_up(n, kLanes), kLanes, lds, st>>>(pts, nrm, cell_start, g, f, forest, lists,
+                                                                    score_sorted, scores, stats);
+    else
+        score_kernel<false><<<div_up(n, kLanes), kLanes, lds, st>>>(pts, nrm, cell_start, g, f, forest, lists,
+                                                                     score_sorted, scores, stats);
 }
 
 void launch_features(const float4 *pts, const float4 *nrm, const int *cell_start,
-                     const int *pos_of, GridDesc g, FeatDesc f, const int *query, int m, int n,
-                     float *out, hipStream_t st) {
+                     const int *pos_of, GridDesc g, FeatDesc f, NbrLists lists, const int *query,
+                     int m, int n, float *out, hipStream_t st) {
     if (m <= 0) return;
-    switch (score_block_size(f.F)) {
-        case 256: launch_features_b<256>(pts, nrm, cell_start, pos_of, g, f, query, m, n, out, st); break;
-        case 128: launch_features_b<128>(pts, nrm, cell_start, pos_of, g, f, query, m, n, out, st); break;
-        default:  launch_features_b<64>(pts, nrm, cell_start, pos_of, g, f, query, m, n, out, st); break;
-    }
+    const size_t lds = sizeof(float) * (size_t)f.F * kLanes;
+    features_kernel<<<div_up(m, kLanes), kLanes, lds, st>>>(pts, nrm, cell_start, pos_of, g, f, lists,
+                                                            query, m, n, out);
 }
 
 void launch_fill_f32(float *p, float v, int n, hipStream_t st) {
