@@ -70,7 +70,6 @@ struct kpl_detector {
     DevBuf stage_xyz, stage_nrm, stage_idx, stage_feat;
     DevBuf bbox, cid, cnt, cell_start, cursor, tmp_idx, scan_tmp, pts, nrm, pos_of;
     DevBuf score_sorted, flags, prefix, stats, out_scores, out_kp, out_count;
-    DevBuf nbr_ent, nbr_count, nbr_ent_q;
     uint32_t *h_bbox = nullptr;   // pinned
     int *h_count = nullptr;       // pinned
 
@@ -189,27 +188,6 @@ int install_forest(kpl_detector *h, ForestModel &&m) {
     return KPL_OK;
 }
 
-// Capacity (entries per lane) of the neighbor lists for `nq` query slots: as many as fit a 2 GiB
-// buffer, at most 256 (a deeper list only matters for neighborhoods above 256 points, which are
-// then drained in several passes), at least 16.
-int list_capacity(size_t nq) {
-    const size_t budget = (size_t)2 << 30;
-    size_t cap = budget / (sizeof(uint2) * (nq ? nq : 1));
-    if (cap > 256) cap = 256;
-    if (cap < 16) cap = 16;
-    return (int)(cap & ~(size_t)3);
-}
-
-int ensure_lists(kpl_detector *h, DevBuf &ent, size_t nq, NbrLists &out) {
-    const size_t nchunks = (nq + 63) / 64;
-    out.cap = list_capacity(nchunks * 64);
-    KPL_HIP(h, ent.ensure(sizeof(uint2) * nchunks * 64 * (size_t)out.cap));
-    KPL_HIP(h, h->nbr_count.ensure(sizeof(int) * (nchunks * 64 + 64)));
-    out.ent = ent.as<uint2>();
-    out.count = h->nbr_count.as<int>();
-    return KPL_OK;
-}
-
 int build_index(kpl_detector *h, hipStream_t st) {
     int rc = check_params_for_compute(h, false);
     if (rc) return rc;
@@ -293,12 +271,10 @@ int detect_on_device(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap
     const FeatDesc f = make_feat(h->prm);
     const NmsDesc nd = make_nms(h->prm);
     ForestDev fd{h->d_nodes.as<uint2>(), h->d_roots.as<uint32_t>(), h->flat.ntrees};
-    NbrLists lists{};
-    rc = ensure_lists(h, h->nbr_ent, nn, lists);
-    if (rc) return rc;
+
     if (d_scores) launch_fill_f32(d_scores, NAN, n, st);
     const size_t ev1 = mark(h, st);
-    launch_score(h->pts.as<float4>(), h->nrm.as<float4>(), h->cell_start.as<int>(), h->grid, f, fd, lists, n,
+    launch_score(h->pts.as<float4>(), h->nrm.as<float4>(), h->cell_start.as<int>(), h->grid, f, fd, n,
                  h->score_sorted.as<float>(), d_scores, d_stats, st);
     const size_t ev2 = mark(h, st);
     span(h, 1, ev1, ev2);
@@ -397,7 +373,7 @@ void kpl_destroy(kpl_detector *h) {
     DevBuf *bufs[] = {&h->d_nodes, &h->d_roots, &h->stage_xyz, &h->stage_nrm, &h->stage_idx, &h->stage_feat,
                       &h->bbox, &h->cid, &h->cnt, &h->cell_start, &h->cursor, &h->tmp_idx, &h->scan_tmp,
                       &h->pts, &h->nrm, &h->pos_of, &h->score_sorted, &h->flags, &h->prefix, &h->stats,
-                      &h->out_scores, &h->out_kp, &h->out_count, &h->nbr_ent, &h->nbr_count, &h->nbr_ent_q};
+                      &h->out_scores, &h->out_kp, &h->out_count};
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->h_bbox) (void)hipHostFree(h->h_bbox);
@@ -516,11 +492,8 @@ int kpl_compute_features_device(kpl_detector *h, const int *d_indices, int m, fl
     hipStream_t st = (hipStream_t)stream;
     rc = ensure_index(h, st);
     if (rc) return rc;
-    NbrLists lists{};
-    rc = ensure_lists(h, h->nbr_ent_q, (size_t)(m > 0 ? m : 1), lists);
-    if (rc) return rc;
     launch_features(h->pts.as<float4>(), h->nrm.as<float4>(), h->cell_start.as<int>(), h->pos_of.as<int>(),
-                    h->grid, make_feat(h->prm), lists, d_indices, m, h->n, d_features, st);
+                    h->grid, make_feat(h->prm), d_indices, m, h->n, d_features, st);
     KPL_HIP(h, hipGetLastError());
     return KPL_OK;
 }

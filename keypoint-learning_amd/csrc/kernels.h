@@ -7,7 +7,6 @@
 //   cell_start[c]    first storage position of grid cell c, c = (cz*ny + cy)*nx + cx; a run of
 //                    cells along x is therefore ONE contiguous range of pts/nrm
 //   pos_of[i]        storage position of original point i, -1 if its xyz is not finite
-//   nbr.ent          per-point neighbor lists {storage position, d2}, see NbrLists
 //   score_sorted[s]  forest response in storage order (what the NMS kernel gathers)
 //   flags[i]         1 if original point i is a keypoint (compacted in ascending i)
 // Canonical storage order = ascending (cell id, original index); it is what makes the float
@@ -52,15 +51,6 @@ struct ForestDev {
     int ntrees;
 };
 
-// Per-point neighbor lists written by the search half of the score kernel and re-read by its
-// accumulate half (and by the NMS kernel): entry e of the 64 lanes of wave w is the 512-byte
-// segment ent[(w * cap + e) * 64 .. +64); x = storage position of the neighbor, y = bits of d2.
-struct NbrLists {
-    uint2 *ent;
-    int *count;   // [storage position] K_f when the list in memory is the complete neighborhood, else -1
-    int cap;      // entries per lane, multiple of 4, >= 8
-};
-
 struct StatsDev {
     unsigned long long sum_kf, sum_kn, sum_depth, n_scored, n_thresholded;
 };
@@ -82,12 +72,12 @@ void launch_rank_store(const char *xyz, size_t xs, const char *nrm, size_t ns, i
 // ---- scoring ("runForest") ----------------------------------------------------------------
 // scores[i] (original order, may be null) and score_sorted[s]; NaN where not scoreable.
 void launch_score(const float4 *pts, const float4 *nrm, const int *cell_start, GridDesc g,
-                  FeatDesc f, ForestDev forest, NbrLists lists, int n, float *score_sorted,
+                  FeatDesc f, ForestDev forest, int n, float *score_sorted,
                   float *scores, StatsDev *stats, hipStream_t st);
 int score_block_size(int F);
 // features of listed points -> out[m*F]
 void launch_features(const float4 *pts, const float4 *nrm, const int *cell_start,
-                     const int *pos_of, GridDesc g, FeatDesc f, NbrLists lists, const int *query,
+                     const int *pos_of, GridDesc g, FeatDesc f, const int *query,
                      int m, int n, float *out, hipStream_t st);
 void launch_fill_f32(float *p, float v, int n, hipStream_t st);
 

@@ -283,21 +283,11 @@ __device__ __forceinline__ float dist2(float px, float py, float pz, const float
 // computePointFeatures, hpp:321-376.  One lane = one query point, one wave = 64 consecutive
 // storage positions (spatially coherent: same or adjacent cells).
 //   H[c * 64 + lane]          LDS: the lane's A x B histogram       (bank = lane mod 32: no conflicts)
-//   ent[e * 64 + lane]        HBM/L2: the lane's neighbor list, entry = {storage position, d2 bits};
-//                             entry e of the 64 lanes of a wave is one 512-byte segment, so a wave
-//                             whose lanes advance together writes and re-reads it coalesced
 // Neighbors are visited in canonical order (rows of cells ascending, storage positions
-// ascending); the first accepted one is dropped (hpp:336 starts at neigh_indx = 1).
-//
-// The work is split so that the expensive part only ever runs on accepted neighbors, with the
-// lanes of a wave in step:
-//   search   distance tests only, 4 candidates per step, the next 4 candidates' 16-B loads already
-//            in flight; accepted candidates are appended to the lane's list.  The wave keeps
-//            searching while ANY lane still has room and candidates in the current row of cells;
-//   drain    every lane walks its list in order: sqrt, two soft assignments, 4 histogram adds,
-//            with the next entries and the next normal already in flight.  With the default list
-//            capacity a lane's whole neighborhood fits, so there is one drain per point and the
-//            wave runs max-K iterations, not a per-row or per-queue maximum each time.
+// ascending); the first accepted one is dropped (hpp:336 starts at neigh_indx = 1).  Every lane
+// walks its own rows of cells back to back (the next two rows' ranges are requested ahead) with
+// the next 4 candidates' 16-B loads always in flight; the expensive part (sqrt, two soft
+// assignments, 4 histogram adds) only ever runs on accepted neighbors -- see point_features.
 // The 4 adds of one neighbor may hit the same cell (pair == index at the range ends -- the common
 // case for bin 0); the cells are read once, the adds are forwarded through registers in the
 // reference's order (hpp:350-355) and written back in order, so the float result is exactly the
@@ -335,28 +325,6 @@ __device__ __forceinline__ void accumulate_neighbor(const FeatDesc &f, float *H,
     h[c3 * kLanes] = x3;
 }
 
-// drains the lane's list entries [first, count) in order; `ent` already points at the lane's column
-__device__ __forceinline__ void drain_list(const float4 *__restrict__ nrm, const FeatDesc &f,
-                                           float *H, const uint2 *ent, int first, int count,
-                                           const float4 &np) {
-    if (first >= count) return;
-#if defined(KPL_ABLATE) && (KPL_ABLATE & 2)
-    return;   // timing experiment only: no accumulation
-#endif
-    uint2 e0 = ent[first * kLanes];
-    uint2 e1 = ent[min(first + 1, count - 1) * kLanes];
-    float4 nq = nrm[e0.x];
-    for (int e = first; e < count; ++e) {
-        const uint2 cur = e0;
-        const float4 nc = nq;
-        e0 = e1;
-        if (e + 1 < count) nq = nrm[e0.x];                 // next normal in flight
-        if (e + 2 < count) e1 = ent[(e + 2) * kLanes];     // list entry two ahead in flight
-        if (nc.w != 0.0f)                                                          // hpp:338
-            accumulate_neighbor(f, H, __uint_as_float(cur.y), np, nc);
-    }
-}
-
 struct Cand4 {
     float4 q0, q1, q2, q3;
 };
@@ -371,66 +339,104 @@ __device__ __forceinline__ Cand4 load_cand4(const float4 *__restrict__ pts, int 
     return c;
 }
 
-// Returns K_f.  *reusable is set to 0 when the list had to be drained before the end (the list
-// left in memory is then not the complete neighborhood).
+// the rows of cells of a lane's search box, visited in ascending (cz, cy); range() gives the
+// storage positions [x, y) of row (cy, cz), or an empty range past the last row
+struct RowCursor {
+    int cy, cz;
+    __device__ __forceinline__ int2 fetch(const int *__restrict__ cell_start, const GridDesc &g,
+                                          const CellBox &b) {
+        int2 r = make_int2(0, 0);
+        if (cz <= b.hi[2]) {
+            const int row = (cz * g.dims[1] + cy) * g.dims[0];
+            r.x = cell_start[row + b.lo[0]];
+            r.y = cell_start[row + b.hi[0] + 1];
+            if (++cy > b.hi[1]) {
+                cy = b.lo[1];
+                ++cz;
+            }
+        }
+        return r;
+    }
+};
+
+// Returns K_f.
+//
+// One loop, three stages per iteration, each lane taking part in the stages it has work for:
+//   A  accumulate the neighbor accepted one iteration ago (its normal was requested then);
+//   B  if the lane has no accepted candidates pending: one search step (4 distance tests on the
+//      candidates requested one step ago, next 4 requested), or move to its next row of cells;
+//   C  take the lowest pending accepted candidate, request its normal, hand it to stage A.
+// A lane therefore needs about (accepted neighbors + search steps that accept nothing)
+// iterations and the wave as many as its busiest lane; neighbors never go through memory.
 __device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
                                               const float4 *__restrict__ nrm,
                                               const int *__restrict__ cell_start,
                                               const GridDesc &g, const FeatDesc &f, float4 p,
-                                              float4 np, float *H, uint2 *ent, int cap,
-                                              bool active, int *reusable) {
+                                              float4 np, float *H, bool active) {
     const int tid = threadIdx.x;
     for (int c = 0; c < f.F; ++c) H[c * kLanes + tid] = 0.0f;                    // hpp:325
-    const CellBox b = make_box(g, p.x, p.y, p.z, f.rr);
-    const int ny = active ? b.hi[1] - b.lo[1] + 1 : 0;
-    const int nrows = active ? ny * (b.hi[2] - b.lo[2] + 1) : 0;
-    const int room = cap - 4;   // a lane may take another 4-candidate step while count <= room
-    int kf = 0;          // accepted so far (K_f, including the dropped first one)
-    int count = 0;       // entries in the list
-    int first = 1;       // 1 until the first accepted neighbor has been dropped (hpp:336)
-    *reusable = 1;
-    for (int ri = 0; __any(ri < nrows); ++ri) {
-        int t = 0, t1 = 0;
-        if (ri < nrows) {
-            const int cz = b.lo[2] + ri / ny, cy = b.lo[1] + ri % ny;
-            const int row = (cz * g.dims[1] + cy) * g.dims[0];
-            t = cell_start[row + b.lo[0]];
-            t1 = cell_start[row + b.hi[0] + 1];
-        }
-        Cand4 pre;
-        if (t < t1) pre = load_cand4(pts, t, t1);
-        for (;;) {
-            // search: strict d2 < r2 (KdTreeFLANN::radiusSearch)
-            while (__any((t < t1) & (count <= room))) {
-                if ((t < t1) & (count <= room)) {
-                    const Cand4 c = pre;
-                    const int tc = t;
-                    t += 4;
-                    if (t < t1) pre = load_cand4(pts, t, t1);     // next step's loads in flight
-                    const float d0 = dist2(p.x, p.y, p.z, c.q0);
-                    const float d1 = dist2(p.x, p.y, p.z, c.q1);
-                    const float d2 = dist2(p.x, p.y, p.z, c.q2);
-                    const float d3 = dist2(p.x, p.y, p.z, c.q3);
-                    const bool h0 = d0 < f.r2;
-                    const bool h1 = (d1 < f.r2) & (tc + 1 < t1);
-                    const bool h2 = (d2 < f.r2) & (tc + 2 < t1);
-                    const bool h3 = (d3 < f.r2) & (tc + 3 < t1);
-                    if (h0) { ent[count * kLanes] = make_uint2((unsigned)tc, __float_as_uint(d0)); ++count; }
-                    if (h1) { ent[count * kLanes] = make_uint2((unsigned)(tc + 1), __float_as_uint(d1)); ++count; }
-                    if (h2) { ent[count * kLanes] = make_uint2((unsigned)(tc + 2), __float_as_uint(d2)); ++count; }
-                    if (h3) { ent[count * kLanes] = make_uint2((unsigned)(tc + 3), __float_as_uint(d3)); ++count; }
+    CellBox b = make_box(g, p.x, p.y, p.z, f.rr);
+    if (!active) b.hi[2] = b.lo[2] - 1;          // no rows
+    int rows_left = active ? (b.hi[1] - b.lo[1] + 1) * (b.hi[2] - b.lo[2] + 1) : 0;
+    RowCursor cur{b.lo[1], b.lo[2]};
+    // current row and two rows ahead (their cell_start loads are in flight long before use)
+    int2 r0 = cur.fetch(cell_start, g, b);
+    int2 r1 = cur.fetch(cell_start, g, b);
+    int2 r2 = cur.fetch(cell_start, g, b);
+    int t = r0.x, t1 = r0.y;
+    Cand4 pre;
+    if (t < t1) pre = load_cand4(pts, t, t1);
+    int kf = 0;
+    bool first_pending = true;   // the first accepted neighbor has not been dropped yet (hpp:336)
+    unsigned mask = 0u;          // accepted, not yet taken candidates of the last search step
+    int tc = 0;                  // storage position of that step's first candidate
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+    bool pend = false;           // stage A has a neighbor to accumulate
+    float pend_d2 = 0.f;
+    float4 pend_n = make_float4(0.f, 0.f, 0.f, 0.f);
+    while (__any((rows_left > 0) | (mask != 0u) | pend)) {
+        // ---- A ------------------------------------------------------------------------------
+        if (pend & (pend_n.w != 0.0f))                                             // hpp:338
+            accumulate_neighbor(f, H, pend_d2, np, pend_n);
+        // ---- B: strict d2 < r2 (KdTreeFLANN::radiusSearch) -----------------------------------
+        if ((mask == 0u) & (rows_left > 0)) {
+            if (t >= t1) {                      // next row of cells
+                --rows_left;
+                r0 = r1;
+                r1 = r2;
+                r2 = cur.fetch(cell_start, g, b);
+                t = r0.x;
+                t1 = r0.y;
+                if ((rows_left > 0) & (t < t1)) pre = load_cand4(pts, t, t1);
+            } else {
+                const Cand4 c = pre;
+                tc = t;
+                t += 4;
+                if (t < t1) pre = load_cand4(pts, t, t1);     // next step's loads in flight
+                d0 = dist2(p.x, p.y, p.z, c.q0);
+                d1 = dist2(p.x, p.y, p.z, c.q1);
+                d2 = dist2(p.x, p.y, p.z, c.q2);
+                d3 = dist2(p.x, p.y, p.z, c.q3);
+                mask = (unsigned)(d0 < f.r2);
+                mask |= (unsigned)((d1 < f.r2) & (tc + 1 < t1)) << 1;
+                mask |= (unsigned)((d2 < f.r2) & (tc + 2 < t1)) << 2;
+                mask |= (unsigned)((d3 < f.r2) & (tc + 3 < t1)) << 3;
+                kf += __popc(mask);
+                if (first_pending & (mask != 0u)) {                                // hpp:336
+                    mask &= mask - 1u;
+                    first_pending = false;
                 }
             }
-            if (!__any(count > room)) break;   // nobody is full: the row is finished
-            drain_list(nrm, f, H, ent, first, count, np);
-            kf += count;
-            if (count > 0) first = 0;
-            count = 0;
-            *reusable = 0;
+        }
+        // ---- C ------------------------------------------------------------------------------
+        pend = mask != 0u;
+        if (pend) {
+            const int k = __ffs((int)mask) - 1;
+            mask &= mask - 1u;
+            pend_d2 = k == 0 ? d0 : k == 1 ? d1 : k == 2 ? d2 : d3;
+            pend_n = nrm[tc + k];
         }
     }
-    drain_list(nrm, f, H, ent, first, count, np);
-    kf += count;
     for (int a = 0; a < f.A; ++a) {                                                // hpp:360-370
         float *h = H + (a * f.B) * kLanes + tid;
         float s = 0.0f;
@@ -499,7 +505,6 @@ __global__ __launch_bounds__(kLanes) void score_kernel(const float4 *__restrict_
                                                        const float4 *__restrict__ nrm,
                                                        const int *__restrict__ cell_start,
                                                        GridDesc g, FeatDesc f, ForestDev forest,
-                                                       NbrLists lists,
                                                        float *__restrict__ score_sorted,
                                                        float *__restrict__ scores,
                                                        StatsDev *stats) {
@@ -513,14 +518,10 @@ __global__ __launch_bounds__(kLanes) void score_kernel(const float4 *__restrict_
     const float4 p = in_range ? pts[s] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 np = in_range ? nrm[s] : make_float4(0.f, 0.f, 0.f, 0.f);
     const bool scoreable = in_range && np.w != 0.0f;                               // hpp:277
-    uint2 *ent = lists.ent + (size_t)blockIdx.x * lists.cap * kLanes + threadIdx.x;
     // every lane of the wave runs the feature code (wave-level votes inside); lanes without a
     // scoreable point simply have no rows
-    int reusable;
-    const int kf = point_features(pts, nrm, cell_start, g, f, p, np, H, ent, lists.cap, scoreable,
-                                  &reusable);
+    const int kf = point_features(pts, nrm, cell_start, g, f, p, np, H, scoreable);
     if (!in_range) return;
-    lists.count[s] = (scoreable && reusable) ? kf : -1;
     float score = NAN;
     if (scoreable) {
         int depth = 0;
@@ -548,7 +549,7 @@ __global__ __launch_bounds__(kLanes) void features_kernel(const float4 *__restri
                                                           const float4 *__restrict__ nrm,
                                                           const int *__restrict__ cell_start,
                                                           const int *__restrict__ pos_of,
-                                                          GridDesc g, FeatDesc f, NbrLists lists,
+                                                          GridDesc g, FeatDesc f,
                                                           const int *__restrict__ query, int m,
                                                           int n, float *__restrict__ out) {
     extern __shared__ float H[];
@@ -560,9 +561,7 @@ __global__ __launch_bounds__(kLanes) void features_kernel(const float4 *__restri
     }
     const float4 p = s >= 0 ? pts[s] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 np = s >= 0 ? nrm[s] : make_float4(0.f, 0.f, 0.f, 0.f);
-    uint2 *ent = lists.ent + (size_t)blockIdx.x * lists.cap * kLanes + threadIdx.x;
-    int reusable;
-    point_features(pts, nrm, cell_start, g, f, p, np, H, ent, lists.cap, s >= 0, &reusable);
+    point_features(pts, nrm, cell_start, g, f, p, np, H, s >= 0);
     if (qi >= m) return;
     float *o = out + (size_t)qi * f.F;
     for (int c = 0; c < f.F; ++c) o[c] = s >= 0 ? H[c * kLanes + threadIdx.x] : NAN;
@@ -685,24 +684,24 @@ void launch_rank_store(const char *xyz, size_t xs, const char *nrm, size_t ns, i
 int score_block_size(int F) { (void)F; return kLanes; }
 
 void launch_score(const float4 *pts, const float4 *nrm, const int *cell_start, GridDesc g,
-                  FeatDesc f, ForestDev forest, NbrLists lists, int n, float *score_sorted,
+                  FeatDesc f, ForestDev forest, int n, float *score_sorted,
                   float *scores, StatsDev *stats, hipStream_t st) {
     if (n <= 0) return;
     const size_t lds = sizeof(float) * (size_t)f.F * kLanes;
     if (stats)
-        score_kernel<true><<<div_up(n, kLanes), kLanes, lds, st>>>(pts, nrm, cell_start, g, f, forest, lists,
+        score_kernel<true><<<div_up(n, kLanes), kLanes, lds, st>>>(pts, nrm, cell_start, g, f, forest,
                                                                     score_sorted, scores, stats);
     else
-        score_kernel<false><<<div_up(n, kLanes), kLanes, lds, st>>>(pts, nrm, cell_start, g, f, forest, lists,
+        score_kernel<false><<<div_up(n, kLanes), kLanes, lds, st>>>(pts, nrm, cell_start, g, f, forest,
                                                                      score_sorted, scores, stats);
 }
 
 void launch_features(const float4 *pts, const float4 *nrm, const int *cell_start,
-                     const int *pos_of, GridDesc g, FeatDesc f, NbrLists lists, const int *query,
+                     const int *pos_of, GridDesc g, FeatDesc f, const int *query,
                      int m, int n, float *out, hipStream_t st) {
     if (m <= 0) return;
     const size_t lds = sizeof(float) * (size_t)f.F * kLanes;
-    features_kernel<<<div_up(m, kLanes), kLanes, lds, st>>>(pts, nrm, cell_start, pos_of, g, f, lists,
+    features_kernel<<<div_up(m, kLanes), kLanes, lds, st>>>(pts, nrm, cell_start, pos_of, g, f,
                                                             query, m, n, out);
 }
 
