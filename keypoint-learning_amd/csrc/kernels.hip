@@ -339,35 +339,40 @@ __device__ __forceinline__ Cand4 load_cand4(const float4 *__restrict__ pts, int 
     return c;
 }
 
-// the rows of cells of a lane's search box, visited in ascending (cz, cy); range() gives the
-// storage positions [x, y) of row (cy, cz), or an empty range past the last row
+// the rows of cells of a lane's search box, visited in ascending (cz, cy).  peek() gives the
+// storage positions [x, y) of the cursor's row, or an empty range past the last row; the two
+// cell_start loads are always issued (clamped row) so that no load sits behind a branch.
 struct RowCursor {
     int cy, cz;
-    __device__ __forceinline__ int2 fetch(const int *__restrict__ cell_start, const GridDesc &g,
-                                          const CellBox &b) {
-        int2 r = make_int2(0, 0);
-        if (cz <= b.hi[2]) {
-            const int row = (cz * g.dims[1] + cy) * g.dims[0];
-            r.x = cell_start[row + b.lo[0]];
-            r.y = cell_start[row + b.hi[0] + 1];
-            if (++cy > b.hi[1]) {
-                cy = b.lo[1];
-                ++cz;
-            }
-        }
-        return r;
+    __device__ __forceinline__ int2 peek(const int *__restrict__ cell_start, const GridDesc &g,
+                                         const CellBox &b) const {
+        const bool valid = cz <= b.hi[2];
+        const int row = ((valid ? cz : b.lo[2]) * g.dims[1] + cy) * g.dims[0];
+        const int x = cell_start[row + b.lo[0]];
+        const int y = cell_start[row + b.hi[0] + 1];
+        return valid ? make_int2(x, y) : make_int2(0, 0);
+    }
+    __device__ __forceinline__ void advance(const CellBox &b) {
+        const bool wrap = cy >= b.hi[1];
+        cy = wrap ? b.lo[1] : cy + 1;
+        cz += wrap ? 1 : 0;
     }
 };
 
 // Returns K_f.
 //
 // One loop, three stages per iteration, each lane taking part in the stages it has work for:
-//   A  accumulate the neighbor accepted one iteration ago (its normal was requested then);
-//   B  if the lane has no accepted candidates pending: one search step (4 distance tests on the
-//      candidates requested one step ago, next 4 requested), or move to its next row of cells;
-//   C  take the lowest pending accepted candidate, request its normal, hand it to stage A.
-// A lane therefore needs about (accepted neighbors + search steps that accept nothing)
-// iterations and the wave as many as its busiest lane; neighbors never go through memory.
+//   C  take the lowest accepted candidate of the current slot (refilled from the look-ahead
+//      slot when it runs dry) and request its normal -- it is accumulated NEXT iteration;
+//   A  accumulate the neighbor taken one iteration ago (its normal has had a whole iteration
+//      to arrive);
+//   B  if the lane's look-ahead slot is free: one search step (4 distance tests on the
+//      candidates requested one step ago, next 4 requested) into that slot, or a move to its
+//      next non-empty row of cells.
+// The look-ahead slot decouples the two rates: a search step that accepts nothing, or a row
+// change, does not idle stage A.  A lane needs about max(accepted neighbors, search steps + row
+// changes) iterations and the wave as many as its busiest lane; neighbors never go through
+// memory.
 __device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
                                               const float4 *__restrict__ nrm,
                                               const int *__restrict__ cell_start,
@@ -376,67 +381,123 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
     const int tid = threadIdx.x;
     for (int c = 0; c < f.F; ++c) H[c * kLanes + tid] = 0.0f;                    // hpp:325
     CellBox b = make_box(g, p.x, p.y, p.z, f.rr);
-    if (!active) b.hi[2] = b.lo[2] - 1;          // no rows
     int rows_left = active ? (b.hi[1] - b.lo[1] + 1) * (b.hi[2] - b.lo[2] + 1) : 0;
+    if (!active) {               // no rows: every range the cursor produces is empty
+        b.lo[0] = b.hi[0] = b.lo[1] = b.hi[1] = b.lo[2] = 0;
+        b.hi[2] = -1;
+    }
+    const int t_max = max(cell_start[g.ncells] - 1, 0);   // last valid storage position
     RowCursor cur{b.lo[1], b.lo[2]};
     // current row and two rows ahead (their cell_start loads are in flight long before use)
-    int2 r0 = cur.fetch(cell_start, g, b);
-    int2 r1 = cur.fetch(cell_start, g, b);
-    int2 r2 = cur.fetch(cell_start, g, b);
+    int2 r0 = cur.peek(cell_start, g, b);
+    cur.advance(b);
+    int2 r1 = cur.peek(cell_start, g, b);
+    cur.advance(b);
+    int2 r2 = cur.peek(cell_start, g, b);
+    cur.advance(b);
+    int2 rn = cur.peek(cell_start, g, b);   // the row after r2, requested one iteration before use
     int t = r0.x, t1 = r0.y;
-    Cand4 pre;
-    if (t < t1) pre = load_cand4(pts, t, t1);
+    Cand4 pre = load_cand4(pts, min(t, t_max), max(t1, 1));
     int kf = 0;
     bool first_pending = true;   // the first accepted neighbor has not been dropped yet (hpp:336)
-    unsigned mask = 0u;          // accepted, not yet taken candidates of the last search step
-    int tc = 0;                  // storage position of that step's first candidate
-    float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
-    bool pend = false;           // stage A has a neighbor to accumulate
-    float pend_d2 = 0.f;
-    float4 pend_n = make_float4(0.f, 0.f, 0.f, 0.f);
-    while (__any((rows_left > 0) | (mask != 0u) | pend)) {
-        // ---- A ------------------------------------------------------------------------------
-        if (pend & (pend_n.w != 0.0f))                                             // hpp:338
-            accumulate_neighbor(f, H, pend_d2, np, pend_n);
-        // ---- B: strict d2 < r2 (KdTreeFLANN::radiusSearch) -----------------------------------
-        if ((mask == 0u) & (rows_left > 0)) {
-            if (t >= t1) {                      // next row of cells
-                --rows_left;
-                r0 = r1;
-                r1 = r2;
-                r2 = cur.fetch(cell_start, g, b);
-                t = r0.x;
-                t1 = r0.y;
-                if ((rows_left > 0) & (t < t1)) pre = load_cand4(pts, t, t1);
-            } else {
-                const Cand4 c = pre;
-                tc = t;
-                t += 4;
-                if (t < t1) pre = load_cand4(pts, t, t1);     // next step's loads in flight
-                d0 = dist2(p.x, p.y, p.z, c.q0);
-                d1 = dist2(p.x, p.y, p.z, c.q1);
-                d2 = dist2(p.x, p.y, p.z, c.q2);
-                d3 = dist2(p.x, p.y, p.z, c.q3);
-                mask = (unsigned)(d0 < f.r2);
-                mask |= (unsigned)((d1 < f.r2) & (tc + 1 < t1)) << 1;
-                mask |= (unsigned)((d2 < f.r2) & (tc + 2 < t1)) << 2;
-                mask |= (unsigned)((d3 < f.r2) & (tc + 3 < t1)) << 3;
-                kf += __popc(mask);
-                if (first_pending & (mask != 0u)) {                                // hpp:336
-                    mask &= mask - 1u;
-                    first_pending = false;
-                }
-            }
-        }
-        // ---- C ------------------------------------------------------------------------------
-        pend = mask != 0u;
-        if (pend) {
-            const int k = __ffs((int)mask) - 1;
-            mask &= mask - 1u;
-            pend_d2 = k == 0 ? d0 : k == 1 ? d1 : k == 2 ? d2 : d3;
-            pend_n = nrm[tc + k];
-        }
+    // current slot (m0) and look-ahead slot (m1): accept bits, first position, 4 squared distances
+    unsigned m0 = 0u, m1 = 0u;
+    int tc0 = 0, tc1 = 0;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;
+    // two neighbor registers used alternately: while one is accumulated, the other one's normal
+    // is on its way (no register copy between iterations, so no wait on a load in flight)
+    struct Taken {
+        bool valid;
+        float d2;
+        float4 n;
+    };
+    Taken pa{false, 0.f, make_float4(0.f, 0.f, 0.f, 0.f)}, pb = pa;
+#if defined(KPL_ABLATE) && (KPL_ABLATE & 64)
+    int dbg_iters = 0;
+#endif
+    // One iteration: C (take the next neighbor into `nxt`), A (accumulate `now`), B (search).
+    // Every global load is issued unconditionally with a clamped address and its result selected
+    // afterwards: a load behind a branch makes the compiler wait for it at the join.
+#if defined(KPL_ABLATE) && (KPL_ABLATE & 0x380)
+    unsigned long long dbg_t[4] = {0, 0, 0, 0};
+#define KPL_STAMP(i)                                                                               \
+    {                                                                                              \
+        unsigned long long st_;                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_)::"memory");               \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        dbg_t[i] += st_ - dbg_last;                                                                \
+        dbg_last = st_;                                                                            \
     }
+    unsigned long long dbg_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dbg_last)::"memory");
+#else
+#define KPL_STAMP(i)
+#endif
+#define KPL_FEATURE_ITERATION(now, nxt)                                                            \
+    {                                                                                              \
+        KPL_STAMP(3)                                                                               \
+        { /* ---- C ---- */                                                                        \
+            const bool dry = m0 == 0u; /* current slot dry: take over the look-ahead slot */      \
+            m0 = dry ? m1 : m0;                                                                    \
+            tc0 = dry ? tc1 : tc0;                                                                 \
+            a0 = dry ? e0 : a0; a1 = dry ? e1 : a1; a2 = dry ? e2 : a2; a3 = dry ? e3 : a3;        \
+            m1 = dry ? 0u : m1;                                                                    \
+            nxt.valid = m0 != 0u;                                                                  \
+            const int k = nxt.valid ? __ffs((int)m0) - 1 : 0;                                      \
+            m0 &= m0 - (nxt.valid ? 1u : 0u);                                                      \
+            nxt.d2 = k == 0 ? a0 : k == 1 ? a1 : k == 2 ? a2 : a3;                                 \
+            nxt.n = nrm[nxt.valid ? tc0 + k : 0];                                                  \
+        }                                                                                          \
+        KPL_STAMP(0)                                                                               \
+        if (now.valid & (now.n.w != 0.0f)) /* ---- A ---- hpp:338 */                               \
+            accumulate_neighbor(f, H, now.d2, np, now.n);                                          \
+        now.valid = false;                                                                         \
+        KPL_STAMP(1)                                                                               \
+        { /* ---- B ---- */                                                                        \
+            const bool free_slot = (m1 == 0u) & (rows_left > 0);                                   \
+            const bool adv = free_slot & (t >= t1);   /* move to the next row of cells */           \
+            const bool stp = free_slot & (t < t1);    /* one search step */                         \
+            /* search step on the candidates requested last iteration; strict d2 < r2 */           \
+            const float s0 = dist2(p.x, p.y, p.z, pre.q0);                                         \
+            const float s1 = dist2(p.x, p.y, p.z, pre.q1);                                         \
+            const float s2 = dist2(p.x, p.y, p.z, pre.q2);                                         \
+            const float s3 = dist2(p.x, p.y, p.z, pre.q3);                                         \
+            unsigned m = (unsigned)(s0 < f.r2);                                                    \
+            m |= (unsigned)((s1 < f.r2) & (t + 1 < t1)) << 1;                                      \
+            m |= (unsigned)((s2 < f.r2) & (t + 2 < t1)) << 2;                                      \
+            m |= (unsigned)((s3 < f.r2) & (t + 3 < t1)) << 3;                                      \
+            m = stp ? m : 0u;                                                                      \
+            kf += __popc(m);                                                                       \
+            const bool drop = first_pending & (m != 0u); /* hpp:336 */                             \
+            m &= m - (drop ? 1u : 0u);                                                             \
+            first_pending = first_pending & !drop;                                                 \
+            m1 = stp ? m : m1;                                                                     \
+            tc1 = stp ? t : tc1;                                                                   \
+            e0 = stp ? s0 : e0; e1 = stp ? s1 : e1; e2 = stp ? s2 : e2; e3 = stp ? s3 : e3;        \
+            /* row change: rn was requested during the previous iteration */                       \
+            rows_left -= adv ? 1 : 0;                                                              \
+            r0 = adv ? r1 : r0;                                                                    \
+            r1 = adv ? r2 : r1;                                                                    \
+            r2 = adv ? rn : r2;                                                                    \
+            if (adv) cur.advance(b);                                                               \
+            rn = cur.peek(cell_start, g, b);                                                       \
+            t = adv ? r0.x : (stp ? t + 4 : t);                                                    \
+            t1 = adv ? r0.y : t1;                                                                  \
+            t1 = rows_left > 0 ? t1 : t; /* past the last row: nothing left */                     \
+            pre = load_cand4(pts, min(t, t_max), max(min(t1, t_max + 1), 1));                      \
+        }                                                                                          \
+        KPL_STAMP(2)                                                                               \
+    }
+    while (__any((rows_left > 0) | ((m0 | m1) != 0u) | pa.valid | pb.valid)) {
+#if defined(KPL_ABLATE) && (KPL_ABLATE & 64)
+        dbg_iters += 2;
+#endif
+        KPL_FEATURE_ITERATION(pa, pb)
+        KPL_FEATURE_ITERATION(pb, pa)
+    }
+#undef KPL_FEATURE_ITERATION
+#undef KPL_STAMP
     for (int a = 0; a < f.A; ++a) {                                                // hpp:360-370
         float *h = H + (a * f.B) * kLanes + tid;
         float s = 0.0f;
@@ -448,6 +509,13 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
         if (nr > 0)
             for (int k = 0; k < f.B; ++k) h[k * kLanes] = h[k * kLanes] / nr;
     }
+#if defined(KPL_ABLATE) && (KPL_ABLATE & 64)
+    return dbg_iters;   // diagnostic build only
+#endif
+#if defined(KPL_ABLATE) && (KPL_ABLATE & 0x380)
+    // diagnostic build only: cycles spent in stage C (0x80), A (0x100), B (0x200)
+    return (int)dbg_t[(KPL_ABLATE & 0x80) ? 0 : (KPL_ABLATE & 0x100) ? 1 : 2];
+#endif
     return kf;
 }
 
@@ -539,6 +607,9 @@ __global__ __launch_bounds__(kLanes) void score_kernel(const float4 *__restrict_
     }
 #if defined(KPL_ABLATE) && (KPL_ABLATE & 16)
     score = (float)(__builtin_amdgcn_s_memtime() - stamp0);   // diagnostic build only
+#endif
+#if defined(KPL_ABLATE) && (KPL_ABLATE & (64 | 0x380))
+    score = (float)kf;   // diagnostic build only: loop iterations / stage cycles of the wave
 #endif
     score_sorted[s] = score;
     if (scores) scores[__float_as_int(p.w)] = score;

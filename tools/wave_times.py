@@ -15,5 +15,5 @@ det.setInputCloud(xyz); det.setNormals(nrm)
 for _ in range(3):
     _, cyc = det.compute()
 c = np.sort(cyc)
-print("per-point wave cycles: min %.0f p10 %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f mean %.0f"
+print("per-point value: min %.0f p10 %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f mean %.0f"
       % (c[0], c[len(c)//10], c[len(c)//2], c[9*len(c)//10], c[99*len(c)//100], c[-1], c.mean()))
