@@ -96,6 +96,22 @@ int kpl_load_forest_arrays(kpl_detector *h, int ntrees, int nnodes, int var_coun
 int kpl_forest_info(const kpl_detector *h, int *ntrees, int *var_count, int64_t *nnodes,
                     int *max_depth);
 
+/* Host-only forest inspection (no device needed): parses the same YAML / YAML.gz bytes as
+ * kpl_load_forest_memory and reports the model, or copies its node arrays out (children by global
+ * node index, var = -1 for a leaf; trees in file order, nodes in file (pre-)order).  Arrays may be
+ * NULL to query sizes only.  err (optional) receives the parser message on failure. */
+typedef struct kpl_forest_summary {
+    int ntrees;
+    int var_count;
+    int64_t nnodes;
+    int max_depth;      /* longest root->leaf path counted in nodes */
+} kpl_forest_summary;
+int kpl_forest_inspect(const void *data, size_t len, kpl_forest_summary *out,
+                       char *err, size_t err_cap);
+int kpl_forest_export_arrays(const void *data, size_t len, int64_t node_cap, int tree_cap,
+                             int *root, int *var, float *thr, int *left, int *right,
+                             double *value, char *err, size_t err_cap);
+
 /* ---- compute(): host buffers ------------------------------------------------------------
  * pcl::Keypoint::compute -> initCompute (hpp:116-156) + detectKeypoints (hpp:179-263).
  * xyz / normals point at the first float of element 0; strides are in bytes (>= 12), so

@@ -32,6 +32,11 @@ class Params(C.Structure):
                 ("non_maxima_draws_threshold", C.c_float)]
 
 
+class ForestSummary(C.Structure):
+    _fields_ = [("ntrees", C.c_int), ("var_count", C.c_int), ("nnodes", C.c_int64),
+                ("max_depth", C.c_int)]
+
+
 class Timing(C.Structure):
     _fields_ = [("calls", C.c_int), ("index_ms", C.c_float), ("score_ms", C.c_float),
                 ("nms_ms", C.c_float)]
@@ -61,6 +66,9 @@ SYMBOLS = {
     "kpl_load_forest_arrays": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _ip, _ip, _fp, _ip, _ip,
                                          C.POINTER(C.c_double)]),
     "kpl_forest_info": (C.c_int, [_vp, _ip, _ip, C.POINTER(C.c_int64), _ip]),
+    "kpl_forest_inspect": (C.c_int, [_vp, C.c_size_t, C.POINTER(ForestSummary), C.c_char_p, C.c_size_t]),
+    "kpl_forest_export_arrays": (C.c_int, [_vp, C.c_size_t, C.c_int64, C.c_int, _vp, _vp, _vp, _vp, _vp,
+                                           _vp, C.c_char_p, C.c_size_t]),
     "kpl_detect": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_int, _vp, _vp, C.c_int, _ip]),
     "kpl_compute_features": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_int, _vp,
                                        C.c_int, _vp]),
@@ -97,6 +105,36 @@ def load_library():
 
 def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def forest_inspect(data):
+    """Host-only: parse YAML / YAML.gz bytes with libkpl's reader.  Returns a dict or raises."""
+    lib = load_library()
+    buf = C.create_string_buffer(bytes(data), len(data))
+    out, err = ForestSummary(), C.create_string_buffer(512)
+    rc = lib.kpl_forest_inspect(C.cast(buf, _vp), len(data), C.byref(out), err, 512)
+    if rc != OK:
+        raise KplError(rc, err.value.decode())
+    return {"ntrees": out.ntrees, "var_count": out.var_count, "nnodes": out.nnodes,
+            "max_depth": out.max_depth}
+
+
+def forest_export_arrays(data):
+    """Host-only: node arrays (root, var, thr, left, right, value) as libkpl's reader sees them."""
+    lib = load_library()
+    info = forest_inspect(data)
+    nn, nt = info["nnodes"], info["ntrees"]
+    buf = C.create_string_buffer(bytes(data), len(data))
+    root, var, left, right = (np.empty(k, dtype=np.int32) for k in (nt, nn, nn, nn))
+    thr, value = np.empty(nn, dtype=np.float32), np.empty(nn, dtype=np.float64)
+    err = C.create_string_buffer(512)
+    rc = lib.kpl_forest_export_arrays(C.cast(buf, _vp), len(data), nn, nt, root.ctypes.data,
+                                      var.ctypes.data, thr.ctypes.data, left.ctypes.data,
+                                      right.ctypes.data, value.ctypes.data, err, 512)
+    if rc != OK:
+        raise KplError(rc, err.value.decode())
+    return {"root": root, "var": var, "thr": thr, "left": left, "right": right, "value": value,
+            "var_count": info["var_count"]}
 
 
 class KeypointLearningDetector:

@@ -446,6 +446,57 @@ int kpl_forest_info(const kpl_detector *h, int *ntrees, int *var_count, int64_t 
     return KPL_OK;
 }
 
+static int parse_bytes(const void *data, size_t len, ForestModel &m, char *err, size_t err_cap) {
+    std::string text, msg;
+    bool ok = data && len && inflate_if_gzip(data, len, text, msg) &&
+              parse_forest_yaml(text.data(), text.size(), m, msg);
+    if (!ok) {
+        if (msg.empty()) msg = "empty forest buffer";
+        if (err && err_cap) snprintf(err, err_cap, "%s", msg.c_str());
+        return (!data || !len) ? KPL_ERR_INVALID_ARG : KPL_ERR_FOREST_PARSE;
+    }
+    return KPL_OK;
+}
+
+int kpl_forest_inspect(const void *data, size_t len, kpl_forest_summary *out, char *err, size_t err_cap) {
+    if (!out) return KPL_ERR_INVALID_ARG;
+    memset(out, 0, sizeof(*out));
+    ForestModel m;
+    int rc = parse_bytes(data, len, m, err, err_cap);
+    if (rc) return rc;
+    FlatForest flat;
+    std::string msg;
+    if (!flatten_forest(m, flat, msg)) {
+        if (err && err_cap) snprintf(err, err_cap, "%s", msg.c_str());
+        return KPL_ERR_FOREST_PARSE;
+    }
+    out->ntrees = flat.ntrees;
+    out->var_count = flat.var_count;
+    out->nnodes = (int64_t)flat.nodes.size();
+    out->max_depth = flat.max_depth;
+    return KPL_OK;
+}
+
+int kpl_forest_export_arrays(const void *data, size_t len, int64_t node_cap, int tree_cap, int *root,
+                             int *var, float *thr, int *left, int *right, double *value, char *err,
+                             size_t err_cap) {
+    ForestModel m;
+    int rc = parse_bytes(data, len, m, err, err_cap);
+    if (rc) return rc;
+    if (m.nnodes() > node_cap || m.ntrees() > tree_cap) {
+        if (err && err_cap) snprintf(err, err_cap, "need room for %lld nodes, %d trees", (long long)m.nnodes(), m.ntrees());
+        return KPL_ERR_CAPACITY;
+    }
+    const size_t nn = (size_t)m.nnodes();
+    if (root) memcpy(root, m.root.data(), sizeof(int) * m.root.size());
+    if (var) memcpy(var, m.var.data(), sizeof(int) * nn);
+    if (thr) memcpy(thr, m.thr.data(), sizeof(float) * nn);
+    if (left) memcpy(left, m.left.data(), sizeof(int) * nn);
+    if (right) memcpy(right, m.right.data(), sizeof(int) * nn);
+    if (value) memcpy(value, m.value.data(), sizeof(double) * nn);
+    return KPL_OK;
+}
+
 int kpl_bind_cloud_device(kpl_detector *h, const void *d_xyz, size_t xyz_stride, const void *d_normals,
                           size_t normals_stride, int n) {
     if (!h) return KPL_ERR_INVALID_ARG;
