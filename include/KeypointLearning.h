@@ -1,0 +1,242 @@
+// KeypointLearning.h -- drop-in pcl::keypoints::KeypointLearningDetector on top of libkpl.
+//
+// Same class name, namespace, template parameters, constructor defaults and public methods as
+// /root/reference/include/KeypointLearning.h:55-206; the bodies marshal to the C-ABI of
+// include/kpl.h, whose HIP kernels run the feature -> forest -> NMS path on an MI355X.
+// Header-only: a TestDetector written against the reference header compiles against this one
+// (src/main_test_detector.cpp:123-187 uses setNAnnulus/setNBins/setNonMaxima/setNonMaxRadius/
+// setNonMaximaDrawsRemove/setPredictionThreshold/setRadiusSearch/loadForest/setInputCloud/
+// setNormals/compute).
+//
+//   -DKPL_USE_PCL      derive from the real pcl::Keypoint (PCL >= 1.8 headers required)
+//   -DKPL_USE_OPENCV   computePointsForTrainingFeatures returns cv::Mat (CV_32F) like the reference
+// Without them a minimal in-repo shim (kpl_pcl_shim.h) and kpl::FeatureMatrix are used.
+//
+// Differences to the reference, all documented in DESIGN.md:
+//   * normals must be given with setNormals (TestDetector does); the reference's fallback normal
+//     estimation inside initCompute (impl/KeypointLearning.hpp:125-148) is outside this engine;
+//   * only radius search with search surface == input is supported (the reference's k-search mode
+//     divides by a zero support, hpp:345; a separate surface mixes index spaces, hpp:332 vs :149);
+//   * points with non-finite xyz or normal get score NaN and keep their input index (the
+//     reference compacts them away and then indexes with tree indices, hpp:277 vs :213);
+//   * n_annulus * n_bins must equal the forest's var_count (checked; OpenCV would read past the
+//     sample).
+#pragma once
+
+#include <cmath>
+#include <string>
+#include <vector>
+
+#include "kpl.h"
+
+#ifdef KPL_USE_PCL
+#include <pcl/keypoints/keypoint.h>
+#include <pcl/point_types.h>
+#else
+#include "kpl_pcl_shim.h"
+#endif
+#ifdef KPL_USE_OPENCV
+#include <opencv2/core.hpp>
+#endif
+
+namespace kpl {
+
+// What computePointsForTrainingFeatures returns when OpenCV is not around: M x F row-major
+// float matrix with the cv::Mat accessors the reference's caller uses
+// (/root/reference/src/main_train_detector.cpp:439-446).
+struct FeatureMatrix {
+    int rows = 0, cols = 0;
+    std::vector<float> data;
+    template <typename T> T *ptr(int r = 0) { return reinterpret_cast<T *>(data.data() + (size_t)r * cols); }
+    template <typename T> const T *ptr(int r = 0) const { return reinterpret_cast<const T *>(data.data() + (size_t)r * cols); }
+    template <typename T> T &at(int r, int c) { return reinterpret_cast<T &>(data[(size_t)r * cols + c]); }
+    bool empty() const { return rows == 0; }
+};
+
+#ifdef KPL_USE_OPENCV
+typedef cv::Mat FeatureMat;
+#else
+typedef FeatureMatrix FeatureMat;
+#endif
+
+}  // namespace kpl
+
+namespace pcl {
+namespace keypoints {
+
+template <typename PointInT, typename PointOutT, typename NormalT = pcl::Normal>
+class KeypointLearningDetector : public Keypoint<PointInT, PointOutT> {
+public:
+#ifdef KPL_USE_PCL
+    typedef boost::shared_ptr<KeypointLearningDetector<PointInT, PointOutT, NormalT>> Ptr;
+    typedef boost::shared_ptr<const KeypointLearningDetector<PointInT, PointOutT, NormalT>> ConstPtr;
+#else
+    typedef std::shared_ptr<KeypointLearningDetector<PointInT, PointOutT, NormalT>> Ptr;
+    typedef std::shared_ptr<const KeypointLearningDetector<PointInT, PointOutT, NormalT>> ConstPtr;
+#endif
+    typedef typename Keypoint<PointInT, PointOutT>::PointCloudIn PointCloudIn;
+    typedef typename Keypoint<PointInT, PointOutT>::PointCloudOut PointCloudOut;
+    typedef typename PointCloudIn::ConstPtr PointCloudInConstPtr;
+    typedef pcl::PointCloud<NormalT> PointCloudN;
+    typedef typename PointCloudN::Ptr PointCloudNPtr;
+    typedef typename PointCloudN::ConstPtr PointCloudNConstPtr;
+
+    // KeypointLearning.h:81 of the reference: same defaults.  `device` = HIP device ordinal.
+    KeypointLearningDetector(double prediction_th = 0.5f, bool non_maxima = true,
+                             bool non_maxima_draws_remove = true, double non_max_radius = 0.0f,
+                             int n_annulus = 5, int n_bins = 10, int device = 0)
+        : non_maxima_(non_maxima), non_maxima_draws_remove_(non_maxima_draws_remove),
+          non_maxima_draws_threshold_(0.0f), prediction_th_(prediction_th),
+          non_maxima_radius_(non_max_radius), n_annulus_(n_annulus), n_bins_(n_bins) {
+        this->name_ = "Keypoint_Learnining_Detector";
+        create_status_ = kpl_create(&handle_, device);
+    }
+
+    virtual ~KeypointLearningDetector() { kpl_destroy(handle_); }
+    KeypointLearningDetector(const KeypointLearningDetector &) = delete;
+    KeypointLearningDetector &operator=(const KeypointLearningDetector &) = delete;
+
+    virtual void setInputCloud(const PointCloudInConstPtr &cloud) {        // hpp:49-57
+        if (normals_ && this->input_ && (cloud != this->input_)) normals_.reset();
+        this->input_ = cloud;
+    }
+    virtual void setNormals(const PointCloudNConstPtr &normals) { normals_ = normals; }
+    virtual void setNonMaxima(bool non_maxima) { non_maxima_ = non_maxima; }
+    virtual void setNonMaximaDrawsRemove(bool v) { non_maxima_draws_remove_ = v; }
+    virtual void setNonMaximaDrawsThreshold(float v) { non_maxima_draws_threshold_ = v; }
+    virtual void setPredictionThreshold(double th) { prediction_th_ = th; }
+    virtual void setNonMaxRadius(double r) { non_maxima_radius_ = r; }
+    virtual void setNAnnulus(int n) { n_annulus_ = n; }
+    virtual void setNBins(int n) { n_bins_ = n; }
+
+    // hpp:159-176: false when the file cannot be loaded or holds no tree
+    virtual bool loadForest(const std::string &path) {
+        if (!handle_) return report("loadForest", create_status_);
+        int rc = kpl_load_forest_file(handle_, path.c_str());
+        if (rc != KPL_OK) {
+            PCL_ERROR("[pcl::%s::loadForest] impossible to load random forest with path %s (%s)\n",
+                      this->name_.c_str(), path.c_str(), kpl_last_error(handle_));
+            return false;
+        }
+        int ntrees = 0;
+        kpl_forest_info(handle_, &ntrees, nullptr, nullptr, nullptr);
+        return ntrees != 0;
+    }
+
+    // hpp:299-318
+    kpl::FeatureMat computePointsForTrainingFeatures(pcl::PointIndicesConstPtr indices) {
+        kpl::FeatureMat features;
+        if (!this->initCompute()) return features;
+        const int m = (int)indices->indices.size();
+        const int F = n_annulus_ * n_bins_;
+        std::vector<float> buf((size_t)m * F);
+        int rc = kpl_compute_features(handle_, &this->input_->points[0].x, sizeof(PointInT),
+                                      &normals_->points[0].normal_x, sizeof(NormalT),
+                                      (int)this->input_->points.size(), indices->indices.data(), m, buf.data());
+        if (this->input_ == this->surface_) this->surface_.reset();
+        if (rc != KPL_OK) {
+            report("computePointsForTrainingFeatures", rc);
+            return features;
+        }
+#ifdef KPL_USE_OPENCV
+        features = cv::Mat(m, F, CV_32F);
+        for (int r = 0; r < m; ++r) std::copy(buf.begin() + (size_t)r * F, buf.begin() + (size_t)(r + 1) * F, features.ptr<float>(r));
+#else
+        features.rows = m;
+        features.cols = F;
+        features.data.swap(buf);
+#endif
+        return features;
+    }
+
+    // forest responses of the last compute(), one per input point (NaN where not scoreable)
+    const std::vector<float> &getScores() const { return scores_; }
+    const char *lastError() const { return handle_ ? kpl_last_error(handle_) : kpl_status_string(create_status_); }
+
+protected:
+    bool initCompute() {                                                     // hpp:116-156
+        if (!handle_) return report("initCompute", create_status_);
+        if (!Keypoint<PointInT, PointOutT>::initCompute()) {
+            PCL_ERROR("[pcl::%s::initCompute] init failed!\n", this->name_.c_str());
+            return false;
+        }
+        if (this->surface_ != this->input_) {
+            PCL_ERROR("[pcl::%s::initCompute] a search surface different from the input is not supported\n", this->name_.c_str());
+            return false;
+        }
+        if (this->k_ != 0 || !(this->search_radius_ > 0.0)) {
+            PCL_ERROR("[pcl::%s::initCompute] only setRadiusSearch(r > 0) is supported\n", this->name_.c_str());
+            return false;
+        }
+        if (!normals_) {
+            PCL_ERROR("[pcl::%s::initCompute] normals are required (setNormals): normal estimation is outside the accelerated path\n", this->name_.c_str());
+            return false;
+        }
+        if (normals_->size() != this->surface_->size()) {                   // hpp:149-153
+            PCL_ERROR("[pcl::%s::initCompute] normals given, but the number of normals does not match the number of input points!\n", this->name_.c_str());
+            return false;
+        }
+        kpl_params p;
+        kpl_default_params(&p);
+        p.n_annulus = n_annulus_;
+        p.n_bins = n_bins_;
+        p.radius_search = this->search_radius_;
+        p.non_max_radius = non_maxima_radius_;
+        p.prediction_th = prediction_th_;
+        p.non_maxima = non_maxima_ ? 1 : 0;
+        p.non_maxima_draws_remove = non_maxima_draws_remove_ ? 1 : 0;
+        p.non_maxima_draws_threshold = non_maxima_draws_threshold_;
+        int rc = kpl_set_params(handle_, &p);
+        return rc == KPL_OK || report("initCompute", rc);
+    }
+
+    virtual void detectKeypoints(PointCloudOut &output) {                   // hpp:179-263
+        const int n = (int)this->input_->points.size();
+        scores_.assign((size_t)n, 0.0f);
+        std::vector<int> kp((size_t)(n > 0 ? n : 1));
+        int count = 0;
+        int rc = kpl_detect(handle_, n ? &this->input_->points[0].x : nullptr, sizeof(PointInT),
+                            n ? &normals_->points[0].normal_x : nullptr, sizeof(NormalT), n,
+                            scores_.data(), kp.data(), n, &count);
+        if (rc != KPL_OK) {
+            report("detectKeypoints", rc);
+            return;
+        }
+        output.points.clear();
+        output.points.reserve((size_t)count);
+        for (int k = 0; k < count; ++k) {
+            const PointInT &in = this->input_->points[kp[k]];
+            PointOutT out;
+            out.x = in.x;
+            out.y = in.y;
+            out.z = in.z;
+            out.intensity = scores_[kp[k]];                                  // hpp:284-287
+            output.points.push_back(out);
+            this->keypoints_indices_->indices.push_back(kp[k]);
+        }
+        output.height = 1;                                                   // hpp:258-260
+        output.width = static_cast<uint32_t>(output.points.size());
+        output.is_dense = non_maxima_ ? true : this->input_->is_dense;       // hpp:193
+    }
+
+    bool report(const char *where, int rc) const {
+        PCL_ERROR("[pcl::%s::%s] %s: %s\n", this->name_.c_str(), where, kpl_status_string(rc),
+                  handle_ ? kpl_last_error(handle_) : "no HIP device (there is no CPU fallback)");
+        return false;
+    }
+
+    bool non_maxima_;
+    bool non_maxima_draws_remove_;
+    float non_maxima_draws_threshold_;
+    double prediction_th_;
+    double non_maxima_radius_;
+    int n_annulus_;
+    int n_bins_;
+    PointCloudNConstPtr normals_;
+    std::vector<float> scores_;
+    kpl_detector *handle_ = nullptr;
+    int create_status_ = KPL_OK;
+};
+
+}  // namespace keypoints
+}  // namespace pcl

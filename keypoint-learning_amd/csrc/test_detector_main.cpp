@@ -1,0 +1,384 @@
+// TestDetector -- counterpart of /root/reference/src/main_test_detector.cpp on top of the drop-in
+// header include/KeypointLearning.h (libkpl, MI355X).  Same option names (:58-67): pathCloud,
+// pathRF, pathKP, radiusFeatures, radiusNMS, threshold, flipNormals, subSampling, leaf; plus
+// annuli / bins (were #defines, :105-106), radiusInMr (radii given in units of the cloud
+// resolution) and json.  No viewer (:191-210 dropped).
+//
+// Everything before detector->compute() is host-side preparation exactly as in the reference
+// main (PCD load :143, UniformSampling :145-157, k = 10 normals :162-169, flip :173-179); it is
+// not part of the accelerated path and is written for clarity, not speed.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "KeypointLearning.h"
+
+typedef pcl::PointXYZ PointInT;
+typedef pcl::Normal PointNormalT;
+typedef pcl::PointXYZI KeypointT;
+
+namespace {
+
+struct Options {
+    std::map<std::string, std::string> kv;
+    bool has(const std::string &k) const { return kv.count(k) != 0; }
+    std::string str(const std::string &k, const std::string &d) const { return has(k) ? kv.at(k) : d; }
+    double num(const std::string &k, double d) const { return has(k) ? atof(kv.at(k).c_str()) : d; }
+};
+
+const char *kUsage =
+    "Allowed options:\n"
+    "  -h [ --help ]                 produce help message\n"
+    "  --flipNormals                 If present flip normals, some dataset needs normal re-orientation.\n"
+    "  --subSampling                 If present, subsample cloud with leaf.\n"
+    "  --leaf arg                    Leaf size for subsampling.\n"
+    "  --pathCloud arg               Path to dataset (.pcd, fields x y z [normal_x normal_y normal_z]).\n"
+    "  --pathRF arg                  Path to Random Forest (OpenCV YAML, optionally gzipped).\n"
+    "  --pathKP arg                  Path for keypoints point cloud.\n"
+    "  --radiusFeatures arg (=20)    Radius for features computation.\n"
+    "  --radiusNMS arg (=4)          Radius for non maxima suppresion.\n"
+    "  -t [ --threshold ] arg (=0.85) Threshold for random forest prediction.\n"
+    "  --annuli arg (=5)             Number of annuli (reference: #define ANNULI 5).\n"
+    "  --bins arg (=10)              Number of bins (reference: #define BINS 10).\n"
+    "  --radiusInMr                  radiusFeatures / radiusNMS / leaf are multiples of the cloud resolution.\n"
+    "  --device arg (=0)             HIP device ordinal.\n"
+    "  --json                        print one JSON line with counts and timings.\n"
+    "  --printResolution             print the cloud resolution (mean 2nd-NN distance) and exit.\n";
+
+bool parse(int argc, char **argv, Options &o) {
+    static const char *flags[] = {"help", "flipNormals", "subSampling", "radiusInMr", "json", "printResolution"};
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        if (a == "-h") a = "--help";
+        if (a == "-t") a = "--threshold";
+        if (a.rfind("--", 0) != 0) { fprintf(stderr, "unrecognised option '%s'\n%s", a.c_str(), kUsage); return false; }
+        a = a.substr(2);
+        std::string val;
+        size_t eq = a.find('=');
+        bool has_val = eq != std::string::npos;
+        if (has_val) { val = a.substr(eq + 1); a = a.substr(0, eq); }
+        bool is_flag = std::find_if(std::begin(flags), std::end(flags), [&](const char *f) { return a == f; }) != std::end(flags);
+        if (!is_flag && !has_val) {
+            if (i + 1 >= argc) { fprintf(stderr, "the required argument for option '--%s' is missing\n%s", a.c_str(), kUsage); return false; }
+            val = argv[++i];
+        }
+        o.kv[a] = val;
+    }
+    if (o.has("help")) { printf("%s", kUsage); return false; }
+    if (o.has("subSampling") && !o.has("leaf")) { printf("Subsampling needs leaf.\n"); return false; }
+    return true;
+}
+
+// ---- PCD (ascii / binary; float32 fields) -------------------------------------------------------
+bool load_pcd(const std::string &path, pcl::PointCloud<PointInT> &cloud, pcl::PointCloud<PointNormalT> &normals) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) { fprintf(stderr, "cannot open %s\n", path.c_str()); return false; }
+    std::vector<std::string> fields;
+    std::vector<int> sizes, counts;
+    std::vector<char> types;
+    size_t npoints = 0;
+    std::string data_kind, line;
+    while (std::getline(f, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        std::istringstream ls(line);
+        std::string key;
+        ls >> key;
+        if (key == "FIELDS") { std::string s; while (ls >> s) fields.push_back(s); }
+        else if (key == "SIZE") { int s; while (ls >> s) sizes.push_back(s); }
+        else if (key == "TYPE") { char c; while (ls >> c) types.push_back(c); }
+        else if (key == "COUNT") { int c; while (ls >> c) counts.push_back(c); }
+        else if (key == "POINTS") ls >> npoints;
+        else if (key == "DATA") { ls >> data_kind; break; }
+    }
+    if (counts.empty()) counts.assign(fields.size(), 1);
+    if (fields.empty() || sizes.size() != fields.size() || types.size() != fields.size()) { fprintf(stderr, "%s: bad PCD header\n", path.c_str()); return false; }
+    auto find = [&](const char *n) { for (size_t i = 0; i < fields.size(); ++i) if (fields[i] == n) return (int)i; return -1; };
+    const int ix = find("x"), iy = find("y"), iz = find("z");
+    const int inx = find("normal_x"), iny = find("normal_y"), inz = find("normal_z");
+    if (ix < 0 || iy < 0 || iz < 0) { fprintf(stderr, "%s: no x y z fields\n", path.c_str()); return false; }
+    std::vector<size_t> offset(fields.size());
+    size_t rec = 0, ncols = 0;
+    std::vector<size_t> col(fields.size());
+    for (size_t i = 0; i < fields.size(); ++i) { offset[i] = rec; col[i] = ncols; rec += (size_t)sizes[i] * counts[i]; ncols += counts[i]; }
+    for (int i : {ix, iy, iz, inx, iny, inz}) if (i >= 0 && (sizes[i] != 4 || types[i] != 'F')) { fprintf(stderr, "%s: only float32 coordinates are supported\n", path.c_str()); return false; }
+    cloud.clear();
+    normals.clear();
+    const bool has_n = inx >= 0 && iny >= 0 && inz >= 0;
+    if (data_kind == "ascii") {
+        std::vector<double> row(ncols);
+        for (size_t p = 0; p < npoints; ++p) {
+            for (size_t c = 0; c < ncols; ++c) {
+                std::string tok;
+                if (!(f >> tok)) { fprintf(stderr, "%s: truncated data\n", path.c_str()); return false; }
+                row[c] = (tok == "nan" || tok == "NaN") ? NAN : atof(tok.c_str());
+            }
+            cloud.push_back(PointInT((float)row[col[ix]], (float)row[col[iy]], (float)row[col[iz]]));
+            if (has_n) { PointNormalT n; n.normal_x = (float)row[col[inx]]; n.normal_y = (float)row[col[iny]]; n.normal_z = (float)row[col[inz]]; normals.push_back(n); }
+        }
+    } else if (data_kind == "binary") {
+        std::vector<char> buf(rec * npoints);
+        f.read(buf.data(), (std::streamsize)buf.size());
+        if ((size_t)f.gcount() != buf.size()) { fprintf(stderr, "%s: truncated data\n", path.c_str()); return false; }
+        auto get = [&](size_t p, int fi) { float v; memcpy(&v, &buf[p * rec + offset[fi]], 4); return v; };
+        for (size_t p = 0; p < npoints; ++p) {
+            cloud.push_back(PointInT(get(p, ix), get(p, iy), get(p, iz)));
+            if (has_n) { PointNormalT n; n.normal_x = get(p, inx); n.normal_y = get(p, iny); n.normal_z = get(p, inz); normals.push_back(n); }
+        }
+    } else {
+        fprintf(stderr, "%s: PCD DATA '%s' is not supported (ascii and binary are)\n", path.c_str(), data_kind.c_str());
+        return false;
+    }
+    cloud.is_dense = true;
+    for (auto &p : cloud.points) if (!pcl::isFinite(p)) cloud.is_dense = false;
+    return true;
+}
+
+bool save_pcd_ascii(const std::string &path, const pcl::PointCloud<KeypointT> &kp) {   // :212-216
+    FILE *f = fopen(path.c_str(), "w");
+    if (!f) return false;
+    fprintf(f, "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z intensity\nSIZE 4 4 4 4\nTYPE F F F F\n"
+               "COUNT 1 1 1 1\nWIDTH %zu\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS %zu\nDATA ascii\n", kp.size(), kp.size());
+    for (auto &p : kp.points) fprintf(f, "%.9g %.9g %.9g %.9g\n", p.x, p.y, p.z, p.intensity);
+    fclose(f);
+    return true;
+}
+
+// ---- host-side helpers on a hash grid -----------------------------------------------------------
+struct HashGrid {
+    double cell;
+    std::unordered_map<long long, std::vector<int>> cells;
+    // exact key: 21 bits per axis around 0 (cells further out than 2^20 would alias; clouds that large
+    // relative to their resolution are not expected on this host-side helper)
+    static long long key(long long x, long long y, long long z) {
+        const long long m = (1LL << 21) - 1, o = 1LL << 20;
+        return (((x + o) & m) << 42) | (((y + o) & m) << 21) | ((z + o) & m);
+    }
+    long long c(double v) const { return (long long)std::floor(v / cell); }
+    HashGrid(const pcl::PointCloud<PointInT> &cloud, double cell_) : cell(cell_) {
+        for (int i = 0; i < (int)cloud.size(); ++i)
+            if (pcl::isFinite(cloud[i])) cells[key(c(cloud[i].x), c(cloud[i].y), c(cloud[i].z))].push_back(i);
+    }
+    // k nearest (squared distance, index), growing the searched block until it is safe
+    void knn(const pcl::PointCloud<PointInT> &cloud, int i, int k, std::vector<std::pair<double, int>> &out) const {
+        const PointInT &p = cloud[i];
+        const long long cx = c(p.x), cy = c(p.y), cz = c(p.z);
+        for (int ring = 1;; ++ring) {
+            out.clear();
+            for (long long z = cz - ring; z <= cz + ring; ++z)
+                for (long long y = cy - ring; y <= cy + ring; ++y)
+                    for (long long x = cx - ring; x <= cx + ring; ++x) {
+                        auto it = cells.find(key(x, y, z));
+                        if (it == cells.end()) continue;
+                        for (int j : it->second) {
+                            const double dx = cloud[j].x - p.x, dy = cloud[j].y - p.y, dz = cloud[j].z - p.z;
+                            out.emplace_back(dx * dx + dy * dy + dz * dz, j);
+                        }
+                    }
+            if ((int)out.size() >= k) {
+                std::partial_sort(out.begin(), out.begin() + k, out.end());
+                if (std::sqrt(out[k - 1].first) <= ring * cell || ring > 64) { out.resize(k); return; }
+            } else if (ring > 64) { std::sort(out.begin(), out.end()); return; }
+        }
+    }
+};
+
+double bbox_cell_guess(const pcl::PointCloud<PointInT> &cloud) {
+    double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+    size_t n = 0;
+    for (auto &p : cloud.points) if (pcl::isFinite(p)) { ++n; const double v[3] = {p.x, p.y, p.z}; for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], v[k]); mx[k] = std::max(mx[k], v[k]); } }
+    if (n < 2) return 1.0;
+    double e[3] = {mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]};
+    std::sort(e, e + 3);
+    const double area = e[2] * (e[1] > 0 ? e[1] : e[2]);
+    return area > 0 ? std::sqrt(area / n * 4.0) : 1.0;
+}
+
+// computeCloudResolution, /root/reference/include/impl/point_cloud_utilities.hpp:120-151
+double cloud_resolution(const pcl::PointCloud<PointInT> &cloud, const HashGrid &g) {
+    double res = 0.0;
+    int n = 0;
+    std::vector<std::pair<double, int>> nn;
+    for (int i = 0; i < (int)cloud.size(); ++i) {
+        if (!std::isfinite(cloud[i].x)) continue;
+        g.knn(cloud, i, 2, nn);
+        if (nn.size() == 2) { res += std::sqrt((float)nn[1].first); ++n; }
+    }
+    return n ? res / n : 0.0;
+}
+
+// smallest-eigenvalue eigenvector of a symmetric 3x3 matrix (cyclic Jacobi)
+void smallest_eigenvector(double a[3][3], double v[3]) {
+    double e[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 32; ++sweep) {
+        double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
+        if (off < 1e-30) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (std::fabs(a[p][q]) < 1e-300) continue;
+                const double theta = (a[q][q] - a[p][p]) / (2 * a[p][q]);
+                const double t = (theta >= 0 ? 1 : -1) / (std::fabs(theta) + std::sqrt(theta * theta + 1));
+                const double c = 1 / std::sqrt(t * t + 1), s = t * c;
+                for (int k = 0; k < 3; ++k) { const double akp = a[k][p], akq = a[k][q]; a[k][p] = c * akp - s * akq; a[k][q] = s * akp + c * akq; }
+                for (int k = 0; k < 3; ++k) { const double apk = a[p][k], aqk = a[q][k]; a[p][k] = c * apk - s * aqk; a[q][k] = s * apk + c * aqk; }
+                for (int k = 0; k < 3; ++k) { const double ekp = e[k][p], ekq = e[k][q]; e[k][p] = c * ekp - s * ekq; e[k][q] = s * ekp + c * ekq; }
+            }
+    }
+    int m = 0;
+    for (int k = 1; k < 3; ++k) if (a[k][k] < a[m][m]) m = k;
+    for (int k = 0; k < 3; ++k) v[k] = e[k][m];
+}
+
+// pcl::NormalEstimation with setKSearch(10), viewpoint (0,0,0) -- main_test_detector.cpp:162-169
+void estimate_normals(const pcl::PointCloud<PointInT> &cloud, const HashGrid &g, int k, pcl::PointCloud<PointNormalT> &out) {
+    out.clear();
+    out.points.resize(cloud.size());
+    std::vector<std::pair<double, int>> nn;
+    for (int i = 0; i < (int)cloud.size(); ++i) {
+        PointNormalT &n = out.points[i];
+        n.normal_x = n.normal_y = n.normal_z = NAN;
+        if (!pcl::isFinite(cloud[i])) continue;
+        g.knn(cloud, i, k, nn);
+        if (nn.size() < 3) continue;
+        double mean[3] = {0, 0, 0};
+        for (auto &e : nn) { mean[0] += cloud[e.second].x; mean[1] += cloud[e.second].y; mean[2] += cloud[e.second].z; }
+        for (double &m : mean) m /= nn.size();
+        double cov[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        for (auto &e : nn) {
+            const double d[3] = {cloud[e.second].x - mean[0], cloud[e.second].y - mean[1], cloud[e.second].z - mean[2]};
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) cov[r][c] += d[r] * d[c];
+        }
+        double v[3];
+        smallest_eigenvector(cov, v);
+        // flipNormalTowardsViewpoint with the default viewpoint (0, 0, 0)
+        if (v[0] * (0 - cloud[i].x) + v[1] * (0 - cloud[i].y) + v[2] * (0 - cloud[i].z) < 0) { v[0] = -v[0]; v[1] = -v[1]; v[2] = -v[2]; }
+        n.normal_x = (float)v[0]; n.normal_y = (float)v[1]; n.normal_z = (float)v[2];
+    }
+    out.width = (uint32_t)out.points.size();
+    out.height = 1;
+}
+
+// pcl::UniformSampling: one point per leaf-sized voxel, the one closest to the voxel centre
+void uniform_sampling(pcl::PointCloud<PointInT> &cloud, double leaf) {
+    std::unordered_map<long long, std::pair<double, int>> best;
+    for (int i = 0; i < (int)cloud.size(); ++i) {
+        const PointInT &p = cloud[i];
+        if (!pcl::isFinite(p)) continue;
+        const long long x = (long long)std::floor(p.x / leaf), y = (long long)std::floor(p.y / leaf), z = (long long)std::floor(p.z / leaf);
+        const double cx = (x + 0.5) * leaf, cy = (y + 0.5) * leaf, cz = (z + 0.5) * leaf;
+        const double d = (p.x - cx) * (p.x - cx) + (p.y - cy) * (p.y - cy) + (p.z - cz) * (p.z - cz);
+        auto it = best.find(HashGrid::key(x, y, z));
+        if (it == best.end() || d < it->second.first) best[HashGrid::key(x, y, z)] = {d, i};
+    }
+    std::vector<int> keep;
+    for (auto &kv : best) keep.push_back(kv.second.second);
+    std::sort(keep.begin(), keep.end());
+    pcl::PointCloud<PointInT> out;
+    for (int i : keep) out.push_back(cloud[i]);
+    cloud = out;
+}
+
+double seconds_since(std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    Options vm;
+    if (!parse(argc, argv, vm)) return 0;
+
+    float radius_nms = (float)vm.num("radiusNMS", 4.0);
+    float radius_features = (float)vm.num("radiusFeatures", 20.0);
+    const float threshold = (float)vm.num("threshold", 0.85);
+    const std::string path_rf = vm.str("pathRF", "../../../data/forest/SHOT-LaserScanner.yaml.gz");
+    const std::string path_cloud = vm.str("pathCloud", "../../../data/point_cloud_test/cheff001.pcd");
+    const int annuli = (int)vm.num("annuli", 5), bins = (int)vm.num("bins", 10);
+    const bool json = vm.has("json");
+
+    if (vm.has("printResolution")) {           // host-only helper, no device needed
+        pcl::PointCloud<PointInT> c;
+        pcl::PointCloud<PointNormalT> nn;
+        if (!load_pcd(path_cloud, c, nn)) return -1;
+        HashGrid g(c, bbox_cell_guess(c));
+        printf("%.17g\n", cloud_resolution(c, g));
+        return 0;
+    }
+
+    // create detector (:123-130)
+    pcl::keypoints::KeypointLearningDetector<PointInT, KeypointT>::Ptr detector(
+        new pcl::keypoints::KeypointLearningDetector<PointInT, KeypointT>(0.5, true, true, 0.0, 5, 10, (int)vm.num("device", 0)));
+    detector->setNAnnulus(annuli);
+    detector->setNBins(bins);
+    detector->setNonMaxima(true);
+    detector->setNonMaximaDrawsRemove(false);
+    detector->setPredictionThreshold(threshold);
+    if (detector->loadForest(path_rf)) {
+        if (!json) printf("Detector created.\n");
+    } else {
+        return -1;
+    }
+
+    // load and subsample point cloud (:142-157)
+    pcl::PointCloud<PointInT>::Ptr cloud(new pcl::PointCloud<PointInT>());
+    pcl::PointCloud<PointNormalT>::Ptr normals(new pcl::PointCloud<PointNormalT>());
+    if (!load_pcd(path_cloud, *cloud, *normals)) return -1;
+    auto t_prep = std::chrono::steady_clock::now();
+    std::unique_ptr<HashGrid> grid(new HashGrid(*cloud, bbox_cell_guess(*cloud)));
+    double mr = 0.0;
+    float leaf = (float)vm.num("leaf", 0.0);
+    if (vm.has("radiusInMr")) {
+        mr = cloud_resolution(*cloud, *grid);
+        radius_features = (float)(radius_features * mr);
+        radius_nms = (float)(radius_nms * mr);
+        leaf = (float)(leaf * mr);
+    }
+    if (vm.has("subSampling")) {
+        uniform_sampling(*cloud, leaf);
+        normals->clear();
+        grid.reset(new HashGrid(*cloud, bbox_cell_guess(*cloud)));
+    }
+    if (!json) printf("Point cloud loaded\n");
+
+    // Compute normals (:162-169) unless the file carried them
+    if (normals->size() != cloud->size()) estimate_normals(*cloud, *grid, 10, *normals);
+    if (!json) printf("Normals Computed\n");
+    if (vm.has("flipNormals")) {                                             // :172-179
+        if (!json) printf("Flipping \n");
+        for (auto &n : normals->points) { n.normal_x *= -1; n.normal_y *= -1; n.normal_z *= -1; }
+    }
+    const double prep_s = seconds_since(t_prep);
+
+    detector->setNonMaxRadius(radius_nms);
+    detector->setRadiusSearch(radius_features);
+    detector->setInputCloud(cloud);
+    detector->setNormals(normals);
+
+    // detect keypoints (:186-187)
+    pcl::PointCloud<KeypointT>::Ptr keypoint(new pcl::PointCloud<KeypointT>());
+    auto t0 = std::chrono::steady_clock::now();
+    detector->compute(*keypoint);
+    const double first_s = seconds_since(t0);
+    t0 = std::chrono::steady_clock::now();
+    detector->compute(*keypoint);                  // second call: scratch buffers already sized
+    const double warm_s = seconds_since(t0);
+    if (!json) printf("Keypoint computed\n");
+
+    if (vm.has("pathKP")) save_pcd_ascii(vm.str("pathKP", ""), *keypoint);
+    if (json)
+        printf("{\"points\": %zu, \"keypoints\": %zu, \"mr\": %.9g, \"radiusFeatures\": %.9g, \"radiusNMS\": %.9g, "
+               "\"threshold\": %.9g, \"annuli\": %d, \"bins\": %d, \"prepare_s\": %.6f, \"compute_first_s\": %.6f, "
+               "\"compute_s\": %.6f}\n",
+               cloud->size(), keypoint->size(), mr, radius_features, radius_nms, threshold, annuli, bins, prep_s, first_s, warm_s);
+    else
+        printf("%zu keypoints out of %zu points (compute: %.3f ms)\nDONE\n", keypoint->size(), cloud->size(), warm_s * 1e3);
+    return 0;
+}

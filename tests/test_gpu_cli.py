@@ -1,0 +1,74 @@
+"""The TestDetector counterpart (C++, include/KeypointLearning.h facade over the C-ABI) end to end
+on a PCD file: same keypoints as the committed fixture."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "keypoint-learning_amd", "TestDetector")
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def write_pcd(path, xyz, nrm=None, binary=True):
+    fields = "x y z" + (" normal_x normal_y normal_z" if nrm is not None else "")
+    k = 6 if nrm is not None else 3
+    arr = np.concatenate([xyz, nrm], axis=1).astype(np.float32) if nrm is not None else xyz.astype(np.float32)
+    hdr = ("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS %s\nSIZE %s\nTYPE %s\nCOUNT %s\n"
+           "WIDTH %d\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS %d\nDATA %s\n"
+           % (fields, " ".join(["4"] * k), " ".join(["F"] * k), " ".join(["1"] * k), len(arr), len(arr),
+              "binary" if binary else "ascii"))
+    with open(path, "wb") as f:
+        f.write(hdr.encode())
+        if binary:
+            f.write(arr.tobytes())
+        else:
+            for row in arr:
+                f.write((" ".join("%.9g" % v for v in row) + "\n").encode())
+
+
+@pytest.mark.parametrize("binary", [True, False])
+def test_cli_on_cheff_view(tmp_path, binary):
+    assert os.path.exists(EXE), "TestDetector is not built (python keypoint-learning_amd/build.py)"
+    z = np.load(os.path.join(GOLD, "cheff000.npz"))
+    n = 20000 if not binary else len(z["xyz"])          # keep the ascii file small
+    pcd, out = tmp_path / "view.pcd", tmp_path / "kp.pcd"
+    write_pcd(pcd, z["xyz"][:n], z["nrm"][:n], binary)
+    cmd = [EXE, "--pathCloud", str(pcd), "--pathRF", os.path.join(ROOT, "data", "forests", "synth200k_a5b6_t10.yaml.gz"),
+           "--pathKP=%s" % out, "--radiusFeatures", "%.9g" % float(z["r_feat"]), "--radiusNMS", "%.9g" % float(z["r_nms"]),
+           "-t", "0.85", "--annuli", "5", "--bins", "6", "--json"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    info = json.loads(res.stdout.strip().splitlines()[-1])
+    assert info["points"] == n
+    kp = np.loadtxt(out, skiprows=11, dtype=np.float32).reshape(-1, 4)
+    assert info["keypoints"] == len(kp)
+    if binary:
+        assert len(kp) == len(z["kp"])
+        assert np.array_equal(kp[:, :3], z["xyz"][z["kp"]])
+        assert np.array_equal(kp[:, 3], z["scores"][z["kp"]])
+
+
+def test_cli_estimates_normals_and_resolution(tmp_path):
+    """No normals in the file: the CLI estimates them (k = 10) like the reference main; radii in mr."""
+    z = np.load(os.path.join(GOLD, "small_case.npz"))
+    xyz = z["xyz"][np.isfinite(z["xyz"]).all(axis=1)]
+    pcd = tmp_path / "small.pcd"
+    write_pcd(pcd, xyz, None, True)
+    cmd = [EXE, "--pathCloud", str(pcd), "--pathRF", os.path.join(GOLD, "small_forest.yaml.gz"), "--radiusFeatures", "6",
+           "--radiusNMS", "4", "--radiusInMr", "--annuli", "5", "--bins", "6", "-t", "0.5", "--flipNormals", "--json"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    info = json.loads(res.stdout.strip().splitlines()[-1])
+    assert abs(info["mr"] - float(z["mr"])) < 1e-3 * float(z["mr"])
+    assert info["points"] == len(xyz) and 0 < info["keypoints"] < len(xyz)
+
+
+def test_cli_errors():
+    res = subprocess.run([EXE, "--pathRF", "/nonexistent.yaml.gz"], capture_output=True, text=True)
+    assert res.returncode != 0 and "impossible to load random forest" in res.stderr
+    res = subprocess.run([EXE, "--subSampling"], capture_output=True, text=True)
+    assert "Subsampling needs leaf." in res.stdout
