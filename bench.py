@@ -103,6 +103,9 @@ def main():
 
     # ---- parity gate (rank 0): keypoint list + scores must equal the oracle's ---------------------
     step()
+    if det.syncStatus(stream) == kpl.ERR_RETRY:     # first view of this size: cell tables were grown
+        step()
+        det.syncStatus(stream)
     torch.cuda.synchronize()
     n_kp = int(d_cnt.item())
     parity = None

@@ -38,7 +38,9 @@ typedef enum kpl_status {
     KPL_ERR_DEVICE = 7,        /* HIP error or no device                                       */
     KPL_ERR_UNSUPPORTED = 8,   /* k-search mode, surface != input, > 255 features ...          */
     KPL_ERR_IO = 9,            /* file cannot be read                                          */
-    KPL_ERR_NO_CLOUD = 10      /* compute before a cloud was bound                             */
+    KPL_ERR_NO_CLOUD = 10,     /* compute before a cloud was bound                             */
+    KPL_ERR_RETRY = 11         /* kpl_sync_status: the view needed larger cell tables; they have
+                                  been grown, enqueue the same call again                      */
 } kpl_status;
 
 typedef struct kpl_detector kpl_detector;
@@ -146,6 +148,13 @@ int kpl_compute_device(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_c
                        int *d_kp_count, void *stream);
 int kpl_compute_features_device(kpl_detector *h, const int *d_indices, int m,
                                 float *d_features, void *stream);
+/* The device entry points never wait for the GPU: the grid descriptor is computed on the device.
+ * Two conditions can therefore only be seen afterwards -- a view that needs more than 2^28 grid
+ * cells, or more cells than the handle's tables currently hold (they start at 8*n + 65536 cells).
+ * In both cases the enqueued call wrote *d_kp_count = -1.  kpl_sync_status waits for `stream` and
+ * returns KPL_OK, KPL_ERR_GRID_TOO_LARGE, or KPL_ERR_RETRY after growing the tables (enqueue the
+ * call again).  kpl_detect / kpl_compute_features do this internally. */
+int kpl_sync_status(kpl_detector *h, void *stream);
 
 /* Per-phase device timing with HIP events recorded on the caller's stream, around the kernels of
  * each phase, for every kpl_build_index_device / kpl_detect_device / kpl_compute_device call made

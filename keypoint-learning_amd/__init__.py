@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KPL_LIB_PATH") or os.path.join(_HERE, "libkpl.so")
 
 OK, ERR_INVALID_ARG, ERR_NO_FOREST, ERR_FOREST_PARSE, ERR_VAR_COUNT, ERR_GRID_TOO_LARGE, \
-    ERR_CAPACITY, ERR_DEVICE, ERR_UNSUPPORTED, ERR_IO, ERR_NO_CLOUD = range(11)
+    ERR_CAPACITY, ERR_DEVICE, ERR_UNSUPPORTED, ERR_IO, ERR_NO_CLOUD, ERR_RETRY = range(12)
 
 
 class KplError(RuntimeError):
@@ -77,6 +77,7 @@ SYMBOLS = {
     "kpl_detect_device": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
     "kpl_compute_device": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
     "kpl_compute_features_device": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),
+    "kpl_sync_status": (C.c_int, [_vp, _vp]),
     "kpl_enable_timing": (C.c_int, [_vp, C.c_int]),
     "kpl_get_timing": (C.c_int, [_vp, C.POINTER(Timing)]),
     "kpl_collect_stats": (C.c_int, [_vp, C.POINTER(Stats), _vp]),
@@ -310,6 +311,13 @@ class KeypointLearningDetector:
     def computeDevice(self, d_scores, d_kp_idx, kp_cap, d_kp_count, stream=None):
         self._push()
         self._check(self._lib.kpl_compute_device(self._h, d_scores, d_kp_idx, kp_cap, d_kp_count, stream))
+
+    def syncStatus(self, stream=None):
+        """Waits for `stream`; returns OK or ERR_RETRY (cell tables grown: enqueue again), raises otherwise."""
+        rc = self._lib.kpl_sync_status(self._h, stream)
+        if rc not in (OK, ERR_RETRY):
+            self._check(rc)
+        return rc
 
     def enableTiming(self, on=True):
         self._check(self._lib.kpl_enable_timing(self._h, int(on)))

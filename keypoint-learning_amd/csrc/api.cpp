@@ -23,7 +23,6 @@ using namespace kpl;
 
 namespace {
 
-constexpr int64_t kMaxCells = (int64_t)1 << 28;
 
 struct DevBuf {
     void *p = nullptr;
@@ -66,11 +65,11 @@ struct kpl_detector {
     bool index_valid = false;
     double index_radius = 0.0;
 
-    GridDesc grid{};
     DevBuf stage_xyz, stage_nrm, stage_idx, stage_feat;
-    DevBuf bbox, cid, cnt, cell_start, cursor, tmp_idx, scan_tmp, pts, nrm, pos_of;
+    DevBuf dstate, cid, cnt, cell_start, cursor, tmp_idx, scan_tmp, pts, nrm, pos_of;
     DevBuf score_sorted, flags, prefix, stats, out_scores, out_kp, out_count;
-    uint32_t *h_bbox = nullptr;   // pinned
+    int cells_cap = 0;            // capacity (cells) of cnt / cell_start / cursor
+    DevState *h_state = nullptr;  // pinned copy of the device state (status read-back)
     int *h_count = nullptr;       // pinned
 
     // optional per-phase event timing (kpl_enable_timing)
@@ -188,6 +187,24 @@ int install_forest(kpl_detector *h, ForestModel &&m) {
     return KPL_OK;
 }
 
+// (re)allocates the cell tables for `cap` cells; the population counters start zeroed and are
+// kept zeroed by the scan that consumes them, so this is the only memset they ever see
+int ensure_cells(kpl_detector *h, int64_t cap) {
+    if (cap <= h->cells_cap) return KPL_OK;
+    if (cap > kMaxGridCells) cap = kMaxGridCells;
+    KPL_HIP(h, hipDeviceSynchronize());
+    KPL_HIP(h, h->cnt.ensure(sizeof(int) * ((size_t)cap + 2)));
+    KPL_HIP(h, h->cell_start.ensure(sizeof(int) * ((size_t)cap + 2)));
+    KPL_HIP(h, h->cursor.ensure(sizeof(int) * ((size_t)cap + 2)));
+    KPL_HIP(h, hipMemset(h->cnt.p, 0, sizeof(int) * ((size_t)cap + 2)));
+    KPL_HIP(h, hipMemset(h->cell_start.p, 0, sizeof(int) * ((size_t)cap + 2)));
+    h->cells_cap = (int)cap;
+    return KPL_OK;
+}
+
+// Index build ("initCompute"), fully asynchronous: bounding box -> grid descriptor (on the device)
+// -> cell ids + counts -> scan -> scatter -> rank/store.  The host does not learn the grid size;
+// a view whose grid does not fit the current cell tables sets DevState::status (kpl_sync_status).
 int build_index(kpl_detector *h, hipStream_t st) {
     int rc = check_params_for_compute(h, false);
     if (rc) return rc;
@@ -195,50 +212,29 @@ int build_index(kpl_detector *h, hipStream_t st) {
     rc = use_device(h);
     if (rc) return rc;
     const int n = h->n;
-    KPL_HIP(h, h->bbox.ensure(6 * sizeof(uint32_t)));
-    launch_bbox(h->d_xyz, h->xs, n, h->bbox.as<uint32_t>(), st);
-    KPL_HIP(h, hipMemcpyAsync(h->h_bbox, h->bbox.p, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    KPL_HIP(h, hipStreamSynchronize(st));
-    float mn[3], mx[3];
-    decode_bbox(h->h_bbox, mn, mx);
-    GridDesc g{};
-    g.h = (float)h->prm.radius_search;
-    const bool any = h->h_bbox[0] != 0xffffffffu && n > 0;
-    int64_t nc = any ? 1 : 0;
-    for (int k = 0; k < 3; ++k) {
-        g.mn[k] = any ? mn[k] : 0.0f;
-        g.dims[k] = 0;
-        if (!any) continue;
-        const float t = std::floor((mx[k] - mn[k]) / g.h);
-        if (!(t < 1.0e9f))
-            return fail(h, KPL_ERR_GRID_TOO_LARGE, "extent / radius too large along axis %d", k);
-        g.dims[k] = (int)t + 1;
-        nc *= g.dims[k];
-        if (nc > kMaxCells)
-            return fail(h, KPL_ERR_GRID_TOO_LARGE, "grid would need more than 2^28 cells");
-    }
-    g.ncells = (int)nc;
     const size_t nn = (size_t)(n > 0 ? n : 1);
+    if (h->cells_cap == 0) {
+        rc = ensure_cells(h, (int64_t)8 * n + 65536);
+        if (rc) return rc;
+    }
     KPL_HIP(h, h->cid.ensure(sizeof(int) * nn));
-    KPL_HIP(h, h->cnt.ensure(sizeof(int) * ((size_t)nc + 2)));
-    KPL_HIP(h, h->cell_start.ensure(sizeof(int) * ((size_t)nc + 2)));
-    KPL_HIP(h, h->cursor.ensure(sizeof(int) * ((size_t)nc + 2)));
     KPL_HIP(h, h->tmp_idx.ensure(sizeof(int) * nn));
-    const size_t scan_len = (size_t)(nc > (int64_t)n ? nc : n) + 1;
+    const size_t scan_len = (size_t)(h->cells_cap > n ? h->cells_cap : n) + 1;
     KPL_HIP(h, h->scan_tmp.ensure(sizeof(int) * (scan_len / 4096 + 4)));
     KPL_HIP(h, h->pts.ensure(sizeof(float4) * nn));
     KPL_HIP(h, h->nrm.ensure(sizeof(float4) * nn));
     KPL_HIP(h, h->pos_of.ensure(sizeof(int) * nn));
+    DevState *ds = h->dstate.as<DevState>();
     const size_t ev0 = mark(h, st);
-    launch_cell_count(h->d_xyz, h->xs, n, g, h->cid.as<int>(), h->cnt.as<int>(), st);
-    launch_exclusive_scan(h->cnt.as<int>(), h->cell_start.as<int>(), g.ncells, h->scan_tmp.as<int>(), st);
-    KPL_HIP(h, hipMemcpyAsync(h->cursor.p, h->cell_start.p, sizeof(int) * ((size_t)nc + 1), hipMemcpyDeviceToDevice, st));
-    launch_scatter(h->cid.as<int>(), n, h->cell_start.as<int>(), h->cursor.as<int>(), h->tmp_idx.as<int>(), st);
-    launch_rank_store(h->d_xyz, h->xs, h->d_nrm, h->ns, n, g, h->cid.as<int>(), h->cell_start.as<int>(),
+    launch_grid_setup(h->d_xyz, h->xs, n, (float)h->prm.radius_search, h->cells_cap, ds, st);
+    launch_cell_count(h->d_xyz, h->xs, n, ds, h->cid.as<int>(), h->cnt.as<int>(), st);
+    launch_exclusive_scan(h->cnt.as<int>(), h->cell_start.as<int>(), h->cursor.as<int>(), &ds->grid.ncells,
+                          h->cells_cap, h->scan_tmp.as<int>(), true, st);
+    launch_scatter(h->cid.as<int>(), n, h->cursor.as<int>(), h->tmp_idx.as<int>(), st);
+    launch_rank_store(h->d_xyz, h->xs, h->d_nrm, h->ns, n, ds, h->cid.as<int>(), h->cell_start.as<int>(),
                       h->tmp_idx.as<int>(), h->pts.as<float4>(), h->nrm.as<float4>(), h->pos_of.as<int>(), st);
     span(h, 0, ev0, mark(h, st));
     KPL_HIP(h, hipGetLastError());
-    h->grid = g;
     h->index_valid = true;
     h->index_radius = h->prm.radius_search;
     return KPL_OK;
@@ -247,6 +243,23 @@ int build_index(kpl_detector *h, hipStream_t st) {
 int ensure_index(kpl_detector *h, hipStream_t st) {
     if (h->index_valid && h->index_radius == h->prm.radius_search) return KPL_OK;
     return build_index(h, st);
+}
+
+// waits for `st`, reads the device status of the last index build and turns it into a status
+// code; grows the cell tables when they were too small so that a retry succeeds
+int sync_status(kpl_detector *h, hipStream_t st) {
+    KPL_HIP(h, hipMemcpyAsync(h->h_state, h->dstate.p, sizeof(DevState), hipMemcpyDeviceToHost, st));
+    KPL_HIP(h, hipStreamSynchronize(st));
+    if (h->h_state->status == kStatusGridTooLarge)
+        return fail(h, KPL_ERR_GRID_TOO_LARGE, "bounding box / radius needs more than 2^28 grid cells");
+    if (h->h_state->status == kStatusCellCapacity) {
+        const int64_t need = h->h_state->ncells_needed;
+        h->index_valid = false;
+        int rc = ensure_cells(h, need + need / 4 + 1024);
+        if (rc) return rc;
+        return fail(h, KPL_ERR_RETRY, "grid needs %lld cells: tables grown, call again", (long long)need);
+    }
+    return KPL_OK;
 }
 
 int detect_on_device(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, int *d_kp_count,
@@ -267,21 +280,19 @@ int detect_on_device(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap
     KPL_HIP(h, h->score_sorted.ensure(sizeof(float) * nn));
     KPL_HIP(h, h->flags.ensure(sizeof(int) * (nn + 1)));
     KPL_HIP(h, h->prefix.ensure(sizeof(int) * (nn + 2)));
-    KPL_HIP(h, h->scan_tmp.ensure(sizeof(int) * (nn / 4096 + 4)));
     const FeatDesc f = make_feat(h->prm);
     const NmsDesc nd = make_nms(h->prm);
     ForestDev fd{h->d_nodes.as<uint2>(), h->d_roots.as<uint32_t>(), h->flat.ntrees};
-
-    if (d_scores) launch_fill_f32(d_scores, NAN, n, st);
+    const DevState *ds = h->dstate.as<DevState>();
     const size_t ev1 = mark(h, st);
-    launch_score(h->pts.as<float4>(), h->nrm.as<float4>(), h->cell_start.as<int>(), h->grid, f, fd, n,
-                 h->score_sorted.as<float>(), d_scores, d_stats, st);
+    launch_score(h->pts.as<float4>(), h->nrm.as<float4>(), h->cell_start.as<int>(), ds, f, fd, h->cid.as<int>(), n,
+                 h->score_sorted.as<float>(), d_scores, h->flags.as<int>(), d_stats, st);
     const size_t ev2 = mark(h, st);
     span(h, 1, ev1, ev2);
-    launch_nms(h->pts.as<float4>(), h->cell_start.as<int>(), h->grid, nd, h->score_sorted.as<float>(), n,
+    launch_nms(h->pts.as<float4>(), h->cell_start.as<int>(), ds, nd, h->score_sorted.as<float>(), n,
                h->flags.as<int>(), d_stats, st);
-    launch_exclusive_scan(h->flags.as<int>(), h->prefix.as<int>(), n, h->scan_tmp.as<int>(), st);
-    launch_compact(h->flags.as<int>(), h->prefix.as<int>(), n, d_kp_idx, kp_cap, d_kp_count, st);
+    launch_exclusive_scan(h->flags.as<int>(), h->prefix.as<int>(), nullptr, nullptr, n, h->scan_tmp.as<int>(), false, st);
+    launch_compact(ds, h->flags.as<int>(), h->prefix.as<int>(), n, d_kp_idx, kp_cap, d_kp_count, st);
     span(h, 2, ev2, mark(h, st));
     KPL_HIP(h, hipGetLastError());
     return KPL_OK;
@@ -331,6 +342,7 @@ const char *kpl_status_string(int s) {
         case KPL_ERR_UNSUPPORTED: return "unsupported";
         case KPL_ERR_IO: return "i/o error";
         case KPL_ERR_NO_CLOUD: return "no cloud bound";
+        case KPL_ERR_RETRY: return "cell tables grown, call again";
         default: return "unknown status";
     }
 }
@@ -358,9 +370,15 @@ int kpl_create(kpl_detector **out, int device) {
     h->device = device;
     kpl_default_params(&h->prm);
     if (hipSetDevice(device) != hipSuccess ||
-        hipHostMalloc((void **)&h->h_bbox, 6 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void **)&h->h_state, sizeof(DevState), hipHostMallocDefault) != hipSuccess ||
+        h->dstate.ensure(sizeof(DevState)) != hipSuccess ||
         hipHostMalloc((void **)&h->h_count, 16 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
-        delete h;
+        kpl_destroy(h);
+        return KPL_ERR_DEVICE;
+    }
+    init_dev_state(h->h_state);
+    if (hipMemcpy(h->dstate.p, h->h_state, sizeof(DevState), hipMemcpyHostToDevice) != hipSuccess) {
+        kpl_destroy(h);
         return KPL_ERR_DEVICE;
     }
     *out = h;
@@ -371,12 +389,12 @@ void kpl_destroy(kpl_detector *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     DevBuf *bufs[] = {&h->d_nodes, &h->d_roots, &h->stage_xyz, &h->stage_nrm, &h->stage_idx, &h->stage_feat,
-                      &h->bbox, &h->cid, &h->cnt, &h->cell_start, &h->cursor, &h->tmp_idx, &h->scan_tmp,
+                      &h->dstate, &h->cid, &h->cnt, &h->cell_start, &h->cursor, &h->tmp_idx, &h->scan_tmp,
                       &h->pts, &h->nrm, &h->pos_of, &h->score_sorted, &h->flags, &h->prefix, &h->stats,
                       &h->out_scores, &h->out_kp, &h->out_count};
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
-    if (h->h_bbox) (void)hipHostFree(h->h_bbox);
+    if (h->h_state) (void)hipHostFree(h->h_state);
     if (h->h_count) (void)hipHostFree(h->h_count);
     delete h;
 }
@@ -544,7 +562,7 @@ int kpl_compute_features_device(kpl_detector *h, const int *d_indices, int m, fl
     rc = ensure_index(h, st);
     if (rc) return rc;
     launch_features(h->pts.as<float4>(), h->nrm.as<float4>(), h->cell_start.as<int>(), h->pos_of.as<int>(),
-                    h->grid, make_feat(h->prm), d_indices, m, h->n, d_features, st);
+                    h->dstate.as<DevState>(), make_feat(h->prm), d_indices, m, h->n, d_features, st);
     KPL_HIP(h, hipGetLastError());
     return KPL_OK;
 }
@@ -563,13 +581,18 @@ int kpl_detect(kpl_detector *h, const void *xyz, size_t xyz_stride, const void *
     KPL_HIP(h, h->out_kp.ensure(sizeof(int) * nn));
     KPL_HIP(h, h->out_count.ensure(sizeof(int)));
     hipStream_t st = nullptr;
-    rc = build_index(h, st);
-    if (rc) return rc;
-    rc = detect_on_device(h, scores_out ? h->out_scores.as<float>() : nullptr, h->out_kp.as<int>(), n,
-                          h->out_count.as<int>(), st, nullptr);
-    if (rc) return rc;
-    KPL_HIP(h, hipMemcpyAsync(h->h_count, h->out_count.p, sizeof(int), hipMemcpyDeviceToHost, st));
-    KPL_HIP(h, hipStreamSynchronize(st));
+    for (int attempt = 0;; ++attempt) {
+        rc = build_index(h, st);
+        if (rc) return rc;
+        rc = detect_on_device(h, scores_out ? h->out_scores.as<float>() : nullptr, h->out_kp.as<int>(), n,
+                              h->out_count.as<int>(), st, nullptr);
+        if (rc) return rc;
+        KPL_HIP(h, hipMemcpyAsync(h->h_count, h->out_count.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        rc = sync_status(h, st);
+        if (rc == KPL_ERR_RETRY && attempt == 0) continue;   // cell tables were grown: run again
+        if (rc) return rc;
+        break;
+    }
     const int count = h->h_count[0];
     *kp_count = count;
     const int ncopy = count < kp_cap ? count : kp_cap;
@@ -577,6 +600,13 @@ int kpl_detect(kpl_detector *h, const void *xyz, size_t xyz_stride, const void *
     if (scores_out && n > 0) KPL_HIP(h, hipMemcpy(scores_out, h->out_scores.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
     if (count > kp_cap) return fail(h, KPL_ERR_CAPACITY, "%d keypoints but capacity %d", count, kp_cap);
     return KPL_OK;
+}
+
+int kpl_sync_status(kpl_detector *h, void *stream) {
+    if (!h) return KPL_ERR_INVALID_ARG;
+    int rc = use_device(h);
+    if (rc) return rc;
+    return sync_status(h, (hipStream_t)stream);
 }
 
 int kpl_compute_features(kpl_detector *h, const void *xyz, size_t xyz_stride, const void *normals,
@@ -592,9 +622,14 @@ int kpl_compute_features(kpl_detector *h, const void *xyz, size_t xyz_stride, co
     KPL_HIP(h, h->stage_idx.ensure(sizeof(int) * (size_t)m));
     KPL_HIP(h, h->stage_feat.ensure(sizeof(float) * (size_t)m * F));
     KPL_HIP(h, hipMemcpy(h->stage_idx.p, indices, sizeof(int) * (size_t)m, hipMemcpyHostToDevice));
-    rc = kpl_compute_features_device(h, h->stage_idx.as<int>(), m, h->stage_feat.as<float>(), nullptr);
-    if (rc) return rc;
-    KPL_HIP(h, hipStreamSynchronize(nullptr));
+    for (int attempt = 0;; ++attempt) {
+        rc = kpl_compute_features_device(h, h->stage_idx.as<int>(), m, h->stage_feat.as<float>(), nullptr);
+        if (rc) return rc;
+        rc = sync_status(h, nullptr);
+        if (rc == KPL_ERR_RETRY && attempt == 0) continue;
+        if (rc) return rc;
+        break;
+    }
     KPL_HIP(h, hipMemcpy(features_out, h->stage_feat.p, sizeof(float) * (size_t)m * F, hipMemcpyDeviceToHost));
     return KPL_OK;
 }
@@ -640,7 +675,8 @@ int kpl_collect_stats(kpl_detector *h, kpl_stats *out, void *stream) {
     if (rc) return rc;
     StatsDev sd;
     KPL_HIP(h, hipMemcpyAsync(h->h_count, h->out_count.p, sizeof(int), hipMemcpyDeviceToHost, st));
-    KPL_HIP(h, hipStreamSynchronize(st));
+    rc = sync_status(h, st);
+    if (rc) return rc;
     KPL_HIP(h, hipMemcpy(&sd, h->stats.p, sizeof(sd), hipMemcpyDeviceToHost));
     out->n_points = h->n;
     out->n_scored = (int64_t)sd.n_scored;
@@ -649,7 +685,7 @@ int kpl_collect_stats(kpl_detector *h, kpl_stats *out, void *stream) {
     out->sum_kn = (int64_t)sd.sum_kn;
     out->sum_depth = (int64_t)sd.sum_depth;
     out->n_keypoints = h->h_count[0];
-    out->n_cells = h->grid.ncells;
+    out->n_cells = h->h_state->grid.ncells;
     return KPL_OK;
 }
 

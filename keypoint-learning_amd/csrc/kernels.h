@@ -55,36 +55,49 @@ struct StatsDev {
     unsigned long long sum_kf, sum_kn, sum_depth, n_scored, n_thresholded;
 };
 
+// Device-resident state of one handle: the grid descriptor is computed ON the device from the
+// bounding box, so the host never waits between the kernels of a call.
+constexpr int kStatusOk = 0, kStatusGridTooLarge = 1, kStatusCellCapacity = 2;
+constexpr long long kMaxGridCells = 1ll << 28;
+struct DevState {
+    GridDesc grid;        // written by grid_setup_kernel, read by every later kernel
+    int status;           // kStatus*: on failure the grid is empty and kp_count becomes -1
+    int ncells_needed;    // what this view needs (to grow the cell tables before a retry)
+    uint32_t bbox[6];     // order-preserving encoded min / max accumulators (self re-arming)
+};
+void init_dev_state(DevState *host_copy);
+
 // ---- index build ("initCompute") ----------------------------------------------------------
-// bbox[0..2] = encoded min, bbox[3..5] = encoded max (order preserving uint encoding)
-void launch_bbox(const char *xyz, size_t stride, int n, uint32_t *bbox, hipStream_t st);
-void decode_bbox(const uint32_t *enc, float *mn, float *mx);
-void launch_cell_count(const char *xyz, size_t stride, int n, GridDesc g, int *cid, int *cnt,
+void launch_grid_setup(const char *xyz, size_t stride, int n, float h, int cells_cap, DevState *ds,
                        hipStream_t st);
-// exclusive scan of in[0..len) into out[0..len], out[len] = total; tmp holds >= len/4096+2 ints
-void launch_exclusive_scan(const int *in, int *out, int len, int *tmp, hipStream_t st);
-void launch_scatter(const int *cid, int n, const int *cell_start, int *cursor, int *tmp_idx,
-                    hipStream_t st);
-void launch_rank_store(const char *xyz, size_t xs, const char *nrm, size_t ns, int n, GridDesc g,
-                       const int *cid, const int *cell_start, const int *tmp_idx, float4 *pts,
-                       float4 *nrmo, int *pos_of, hipStream_t st);
+void launch_cell_count(const char *xyz, size_t stride, int n, const DevState *ds, int *cid, int *cnt,
+                       hipStream_t st);
+// exclusive scan of in[0..L) into out[0..L], out[L] = total (also into out2 if given), with
+// L = min(*dlen, len) when dlen is given (len = launch-time upper bound); tmp holds >= len/4096+2
+// ints; zero_in clears the input behind the read
+void launch_exclusive_scan(int *in, int *out, int *out2, const int *dlen, int len, int *tmp,
+                           bool zero_in, hipStream_t st);
+void launch_scatter(const int *cid, int n, int *cursor, int *tmp_idx, hipStream_t st);
+void launch_rank_store(const char *xyz, size_t xs, const char *nrm, size_t ns, int n,
+                       const DevState *ds, const int *cid, const int *cell_start, const int *tmp_idx,
+                       float4 *pts, float4 *nrmo, int *pos_of, hipStream_t st);
 
 // ---- scoring ("runForest") ----------------------------------------------------------------
-// scores[i] (original order, may be null) and score_sorted[s]; NaN where not scoreable.
-void launch_score(const float4 *pts, const float4 *nrm, const int *cell_start, GridDesc g,
-                  FeatDesc f, ForestDev forest, int n, float *score_sorted,
-                  float *scores, StatsDev *stats, hipStream_t st);
+// scores[i] (original order, may be null) and score_sorted[s]; NaN where not scoreable; also
+// clears flags[0..n)
+void launch_score(const float4 *pts, const float4 *nrm, const int *cell_start, const DevState *ds,
+                  FeatDesc f, ForestDev forest, const int *cid, int n, float *score_sorted,
+                  float *scores, int *flags, StatsDev *stats, hipStream_t st);
 int score_block_size(int F);
 // features of listed points -> out[m*F]
 void launch_features(const float4 *pts, const float4 *nrm, const int *cell_start,
-                     const int *pos_of, GridDesc g, FeatDesc f, const int *query,
-                     int m, int n, float *out, hipStream_t st);
-void launch_fill_f32(float *p, float v, int n, hipStream_t st);
+                     const int *pos_of, const DevState *ds, FeatDesc f, const int *query, int m, int n,
+                     float *out, hipStream_t st);
 
 // ---- NMS + compaction ("detectKeypoints") -------------------------------------------------
-void launch_nms(const float4 *pts, const int *cell_start, GridDesc g, NmsDesc nd,
+void launch_nms(const float4 *pts, const int *cell_start, const DevState *ds, NmsDesc nd,
                 const float *score_sorted, int n, int *flags, StatsDev *stats, hipStream_t st);
-void launch_compact(const int *flags, const int *prefix, int n, int *kp_idx, int kp_cap,
-                    int *kp_count, hipStream_t st);
+void launch_compact(const DevState *ds, const int *flags, const int *prefix, int n, int *kp_idx,
+                    int kp_cap, int *kp_count, hipStream_t st);
 
 }  // namespace kpl

@@ -10,6 +10,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 
 namespace kpl {
 
@@ -35,13 +36,6 @@ __device__ __forceinline__ uint32_t enc_f32(float f) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-inline float dec_f32(uint32_t u) {
-    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
-    union { uint32_t u; float f; } cvt;
-    cvt.u = u;
-    return cvt.f;
-}
-
 __device__ __forceinline__ const float *point_at(const char *base, size_t stride, int i) {
     return reinterpret_cast<const float *>(base + (size_t)i * stride);
 }
@@ -50,7 +44,8 @@ __device__ __forceinline__ const float *point_at(const char *base, size_t stride
 // bounding box of the finite points
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bbox_kernel(const char *xyz, size_t stride, int n,
-                                                   uint32_t *bbox) {
+                                                   DevState *ds) {
+    uint32_t *bbox = ds->bbox;
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float *p = point_at(xyz, stride, i);
@@ -94,12 +89,70 @@ __global__ __launch_bounds__(256) void bbox_kernel(const char *xyz, size_t strid
 }
 
 // ---------------------------------------------------------------------------------------------
+// grid descriptor from the bounding box, on the device (the host never waits for it).  Same float
+// operations as the CPU restatement: dims[k] = (int)floorf((max - min) / h) + 1.
+// Also re-arms the bounding-box accumulators for the next call.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dec_f32_dev(uint32_t u) {
+    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    return __uint_as_float(u);
+}
+
+__global__ void grid_setup_kernel(DevState *ds, float h, int n, int cells_cap) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    GridDesc g;
+    g.h = h;
+    const bool any = n > 0 && ds->bbox[0] != 0xffffffffu;
+    long long nc = any ? 1 : 0;
+    int status = 0;
+    for (int k = 0; k < 3; ++k) {
+        const float mn = any ? dec_f32_dev(ds->bbox[k]) : 0.0f;
+        const float mx = any ? dec_f32_dev(ds->bbox[3 + k]) : 0.0f;
+        g.mn[k] = mn;
+        g.dims[k] = 0;
+        if (!any) continue;
+        const float t = floorf((mx - mn) / h);
+        if (!(t < 1.0e9f)) {
+            status = kStatusGridTooLarge;
+            nc = 0;
+            break;
+        }
+        g.dims[k] = (int)t + 1;
+        nc *= g.dims[k];
+        if (nc > kMaxGridCells) {
+            status = kStatusGridTooLarge;
+            nc = 0;
+            break;
+        }
+    }
+    ds->ncells_needed = (int)nc;
+    if (status == 0 && nc > cells_cap) status = kStatusCellCapacity;
+    if (status != 0) {
+        nc = 0;
+        g.dims[0] = g.dims[1] = g.dims[2] = 0;
+    }
+    g.ncells = (int)nc;
+    ds->grid = g;
+    ds->status = status;
+    for (int k = 0; k < 3; ++k) {
+        ds->bbox[k] = 0xffffffffu;
+        ds->bbox[3 + k] = 0u;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // cell id per point + population count per cell
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void cell_count_kernel(const char *xyz, size_t stride, int n,
-                                                         GridDesc g, int *cid, int *cnt) {
+                                                         const DevState *__restrict__ ds, int *cid,
+                                                         int *cnt) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const GridDesc g = ds->grid;
+    if (g.ncells == 0) {           // empty view, or the grid could not be set up (ds->status)
+        cid[i] = -1;
+        return;
+    }
     const float *p = point_at(xyz, stride, i);
     float x = p[0], y = p[1], z = p[2];
     int c = -1;
@@ -141,7 +194,14 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *total) {
     return base + incl - v;
 }
 
-__global__ __launch_bounds__(kScanBlock) void scan_sums_kernel(const int *in, int len, int *sums) {
+// `len` is the launch-time upper bound; when dlen is given the actual length is min(*dlen, len)
+__device__ __forceinline__ int scan_len(const int *dlen, int len) {
+    return dlen ? min(*dlen, len) : len;
+}
+
+__global__ __launch_bounds__(kScanBlock) void scan_sums_kernel(const int *in, const int *dlen, int len,
+                                                               int *sums) {
+    len = scan_len(dlen, len);
     const int base = blockIdx.x * kScanChunk + threadIdx.x * kScanPerThread;
     int s = 0;
 #pragma unroll
@@ -165,24 +225,35 @@ __global__ __launch_bounds__(kScanBlock) void scan_top_kernel(int *sums, int nb)
     if (threadIdx.x == 0) sums[nb] = carry;
 }
 
-__global__ __launch_bounds__(kScanBlock) void scan_apply_kernel(const int *in, int *out, int len,
-                                                                const int *sums, int nb) {
+// out[i] = exclusive prefix, out[len] = total; the same goes to out2 when given; the input is
+// zeroed behind the read when zero_in is set (self-cleaning counters: no memset per call)
+__global__ __launch_bounds__(kScanBlock) void scan_apply_kernel(int *in, int *out, int *out2,
+                                                                const int *dlen, int len,
+                                                                const int *sums, int nb, int zero_in) {
+    len = scan_len(dlen, len);
     const int base = blockIdx.x * kScanChunk + threadIdx.x * kScanPerThread;
     int v[kScanPerThread];
     int s = 0;
 #pragma unroll
     for (int k = 0; k < kScanPerThread; ++k) {
         v[k] = base + k < len ? in[base + k] : 0;
+        if (zero_in && base + k < len) in[base + k] = 0;
         s += v[k];
     }
     int tot;
     int run = block_exclusive_scan(s, &tot) + sums[blockIdx.x];
 #pragma unroll
     for (int k = 0; k < kScanPerThread; ++k) {
-        if (base + k < len) out[base + k] = run;
+        if (base + k < len) {
+            out[base + k] = run;
+            if (out2) out2[base + k] = run;
+        }
         run += v[k];
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) out[len] = sums[nb];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        out[len] = sums[nb];
+        if (out2) out2[len] = sums[nb];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -201,10 +272,12 @@ __global__ __launch_bounds__(256) void scatter_kernel(const int *cid, int n, int
 
 __global__ __launch_bounds__(256) void rank_store_kernel(const char *xyz, size_t xs,
                                                          const char *nrm, size_t ns, int n,
-                                                         GridDesc g, const int *cid,
-                                                         const int *cell_start, const int *tmp_idx,
-                                                         float4 *pts, float4 *nrmo, int *pos_of) {
+                                                         const DevState *__restrict__ ds,
+                                                         const int *cid, const int *cell_start,
+                                                         const int *tmp_idx, float4 *pts, float4 *nrmo,
+                                                         int *pos_of) {
     int s = blockIdx.x * blockDim.x + threadIdx.x;
+    const GridDesc g = ds->grid;
     if (s < n && cid[s] < 0) pos_of[s] = -1;   // non-finite original point s
     const int nfinite = cell_start[g.ncells];
     if (s >= nfinite) return;
@@ -572,11 +645,20 @@ template <bool STATS>
 __global__ __launch_bounds__(kLanes) void score_kernel(const float4 *__restrict__ pts,
                                                        const float4 *__restrict__ nrm,
                                                        const int *__restrict__ cell_start,
-                                                       GridDesc g, FeatDesc f, ForestDev forest,
-                                                       float *__restrict__ score_sorted,
+                                                       const DevState *__restrict__ ds, FeatDesc f,
+                                                       ForestDev forest, const int *__restrict__ cid,
+                                                       int n, float *__restrict__ score_sorted,
                                                        float *__restrict__ scores,
-                                                       StatsDev *stats) {
+                                                       int *__restrict__ flags, StatsDev *stats) {
     extern __shared__ float H[];
+    const GridDesc g = ds->grid;
+    {   // per ORIGINAL point: clear the keypoint flag, and NaN for points that are not in the grid
+        const int i = blockIdx.x * kLanes + threadIdx.x;
+        if (i < n) {
+            flags[i] = 0;
+            if (scores && cid[i] < 0) scores[i] = NAN;
+        }
+    }
 #if defined(KPL_ABLATE) && (KPL_ABLATE & 16)
     const unsigned long long stamp0 = __builtin_amdgcn_s_memtime();   // diagnostic build only
 #endif
@@ -620,10 +702,11 @@ __global__ __launch_bounds__(kLanes) void features_kernel(const float4 *__restri
                                                           const float4 *__restrict__ nrm,
                                                           const int *__restrict__ cell_start,
                                                           const int *__restrict__ pos_of,
-                                                          GridDesc g, FeatDesc f,
+                                                          const DevState *__restrict__ ds, FeatDesc f,
                                                           const int *__restrict__ query, int m,
                                                           int n, float *__restrict__ out) {
     extern __shared__ float H[];
+    const GridDesc g = ds->grid;
     const int qi = blockIdx.x * kLanes + threadIdx.x;
     int s = -1;
     if (qi < m) {
@@ -638,20 +721,17 @@ __global__ __launch_bounds__(kLanes) void features_kernel(const float4 *__restri
     for (int c = 0; c < f.F; ++c) o[c] = s >= 0 ? H[c * kLanes + threadIdx.x] : NAN;
 }
 
-__global__ void fill_f32_kernel(float *p, float v, int n) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
-}
-
 // detectKeypoints, hpp:197-256 with draws_remove == false (order-independent predicate):
 // keypoint <=> score >= thr (float promoted to double, hpp:207) and no neighbor within r_nms
 // has a strictly greater score (hpp:219).  non_maxima == 0: every scoreable point (hpp:189-196).
 template <bool STATS>
 __global__ __launch_bounds__(256) void nms_kernel(const float4 *__restrict__ pts,
-                                                  const int *__restrict__ cell_start, GridDesc g,
-                                                  NmsDesc nd, const float *__restrict__ score_sorted,
+                                                  const int *__restrict__ cell_start,
+                                                  const DevState *__restrict__ ds, NmsDesc nd,
+                                                  const float *__restrict__ score_sorted,
                                                   int *__restrict__ flags, StatsDev *stats) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    const GridDesc g = ds->grid;
     const int nfinite = cell_start[g.ncells];
     if (s >= nfinite) return;
     const float si = score_sorted[s];
@@ -689,10 +769,11 @@ __global__ __launch_bounds__(256) void nms_kernel(const float4 *__restrict__ pts
     if (is_max) flags[orig] = 1;                                                   // hpp:252-253
 }
 
-__global__ __launch_bounds__(256) void compact_kernel(const int *flags, const int *prefix, int n,
+__global__ __launch_bounds__(256) void compact_kernel(const DevState *__restrict__ ds,
+                                                      const int *flags, const int *prefix, int n,
                                                       int *kp_idx, int kp_cap, int *kp_count) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) *kp_count = prefix[n];
+    if (i == 0) *kp_count = ds->status != 0 ? -1 : prefix[n];   // -1: see kpl_sync_status
     if (i >= n) return;
     if (flags[i]) {
         int pos = prefix[i];
@@ -707,93 +788,87 @@ inline int div_up(int a, int b) { return (a + b - 1) / b; }
 // =============================================================================================
 // launch wrappers
 // =============================================================================================
-void launch_bbox(const char *xyz, size_t stride, int n, uint32_t *bbox, hipStream_t st) {
-    static const uint32_t init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
-    (void)hipMemcpyAsync(bbox, init, sizeof(init), hipMemcpyHostToDevice, st);
-    if (n <= 0) return;
-    int blocks = div_up(n, 256);
-    if (blocks > 512) blocks = 512;
-    bbox_kernel<<<blocks, 256, 0, st>>>(xyz, stride, n, bbox);
-}
-
-void decode_bbox(const uint32_t *enc, float *mn, float *mx) {
+void init_dev_state(DevState *host_copy) {
+    memset(host_copy, 0, sizeof(*host_copy));
     for (int k = 0; k < 3; ++k) {
-        mn[k] = dec_f32(enc[k]);
-        mx[k] = dec_f32(enc[3 + k]);
+        host_copy->bbox[k] = 0xffffffffu;
+        host_copy->bbox[3 + k] = 0u;
     }
 }
 
-void launch_cell_count(const char *xyz, size_t stride, int n, GridDesc g, int *cid, int *cnt,
+void launch_grid_setup(const char *xyz, size_t stride, int n, float h, int cells_cap, DevState *ds,
                        hipStream_t st) {
-    (void)hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)(g.ncells + 1), st);
+    if (n > 0) {
+        int blocks = div_up(n, 256);
+        if (blocks > 512) blocks = 512;
+        bbox_kernel<<<blocks, 256, 0, st>>>(xyz, stride, n, ds);
+    }
+    grid_setup_kernel<<<1, 64, 0, st>>>(ds, h, n, cells_cap);
+}
+
+void launch_cell_count(const char *xyz, size_t stride, int n, const DevState *ds, int *cid, int *cnt,
+                       hipStream_t st) {
     if (n <= 0) return;
-    cell_count_kernel<<<div_up(n, 256), 256, 0, st>>>(xyz, stride, n, g, cid, cnt);
+    cell_count_kernel<<<div_up(n, 256), 256, 0, st>>>(xyz, stride, n, ds, cid, cnt);
 }
 
-void launch_exclusive_scan(const int *in, int *out, int len, int *tmp, hipStream_t st) {
+void launch_exclusive_scan(int *in, int *out, int *out2, const int *dlen, int len, int *tmp,
+                           bool zero_in, hipStream_t st) {
     const int nb = len > 0 ? div_up(len, kScanChunk) : 1;
-    scan_sums_kernel<<<nb, kScanBlock, 0, st>>>(in, len, tmp);
+    scan_sums_kernel<<<nb, kScanBlock, 0, st>>>(in, dlen, len, tmp);
     scan_top_kernel<<<1, kScanBlock, 0, st>>>(tmp, nb);
-    scan_apply_kernel<<<nb, kScanBlock, 0, st>>>(in, out, len, tmp, nb);
+    scan_apply_kernel<<<nb, kScanBlock, 0, st>>>(in, out, out2, dlen, len, tmp, nb, zero_in ? 1 : 0);
 }
 
-void launch_scatter(const int *cid, int n, const int *cell_start, int *cursor, int *tmp_idx,
-                    hipStream_t st) {
-    (void)cell_start;
+void launch_scatter(const int *cid, int n, int *cursor, int *tmp_idx, hipStream_t st) {
     if (n <= 0) return;
     scatter_kernel<<<div_up(n, 256), 256, 0, st>>>(cid, n, cursor, tmp_idx);
 }
 
-void launch_rank_store(const char *xyz, size_t xs, const char *nrm, size_t ns, int n, GridDesc g,
-                       const int *cid, const int *cell_start, const int *tmp_idx, float4 *pts,
-                       float4 *nrmo, int *pos_of, hipStream_t st) {
+void launch_rank_store(const char *xyz, size_t xs, const char *nrm, size_t ns, int n,
+                       const DevState *ds, const int *cid, const int *cell_start, const int *tmp_idx,
+                       float4 *pts, float4 *nrmo, int *pos_of, hipStream_t st) {
     if (n <= 0) return;
-    rank_store_kernel<<<div_up(n, 256), 256, 0, st>>>(xyz, xs, nrm, ns, n, g, cid, cell_start,
+    rank_store_kernel<<<div_up(n, 256), 256, 0, st>>>(xyz, xs, nrm, ns, n, ds, cid, cell_start,
                                                       tmp_idx, pts, nrmo, pos_of);
 }
 
 int score_block_size(int F) { (void)F; return kLanes; }
 
-void launch_score(const float4 *pts, const float4 *nrm, const int *cell_start, GridDesc g,
-                  FeatDesc f, ForestDev forest, int n, float *score_sorted,
-                  float *scores, StatsDev *stats, hipStream_t st) {
+void launch_score(const float4 *pts, const float4 *nrm, const int *cell_start, const DevState *ds,
+                  FeatDesc f, ForestDev forest, const int *cid, int n, float *score_sorted,
+                  float *scores, int *flags, StatsDev *stats, hipStream_t st) {
     if (n <= 0) return;
     const size_t lds = sizeof(float) * (size_t)f.F * kLanes;
     if (stats)
-        score_kernel<true><<<div_up(n, kLanes), kLanes, lds, st>>>(pts, nrm, cell_start, g, f, forest,
-                                                                    score_sorted, scores, stats);
+        score_kernel<true><<<div_up(n, kLanes), kLanes, lds, st>>>(pts, nrm, cell_start, ds, f, forest, cid, n,
+                                                                    score_sorted, scores, flags, stats);
     else
-        score_kernel<false><<<div_up(n, kLanes), kLanes, lds, st>>>(pts, nrm, cell_start, g, f, forest,
-                                                                     score_sorted, scores, stats);
+        score_kernel<false><<<div_up(n, kLanes), kLanes, lds, st>>>(pts, nrm, cell_start, ds, f, forest, cid, n,
+                                                                     score_sorted, scores, flags, stats);
 }
 
 void launch_features(const float4 *pts, const float4 *nrm, const int *cell_start,
-                     const int *pos_of, GridDesc g, FeatDesc f, const int *query,
-                     int m, int n, float *out, hipStream_t st) {
+                     const int *pos_of, const DevState *ds, FeatDesc f, const int *query, int m, int n,
+                     float *out, hipStream_t st) {
     if (m <= 0) return;
     const size_t lds = sizeof(float) * (size_t)f.F * kLanes;
-    features_kernel<<<div_up(m, kLanes), kLanes, lds, st>>>(pts, nrm, cell_start, pos_of, g, f,
+    features_kernel<<<div_up(m, kLanes), kLanes, lds, st>>>(pts, nrm, cell_start, pos_of, ds, f,
                                                             query, m, n, out);
 }
 
-void launch_fill_f32(float *p, float v, int n, hipStream_t st) {
-    if (n <= 0) return;
-    fill_f32_kernel<<<div_up(n, 256), 256, 0, st>>>(p, v, n);
-}
-
-void launch_nms(const float4 *pts, const int *cell_start, GridDesc g, NmsDesc nd,
+void launch_nms(const float4 *pts, const int *cell_start, const DevState *ds, NmsDesc nd,
                 const float *score_sorted, int n, int *flags, StatsDev *stats, hipStream_t st) {
-    (void)hipMemsetAsync(flags, 0, sizeof(int) * (size_t)(n + 1), st);
     if (n <= 0) return;
     if (stats)
-        nms_kernel<true><<<div_up(n, 256), 256, 0, st>>>(pts, cell_start, g, nd, score_sorted, flags, stats);
+        nms_kernel<true><<<div_up(n, 256), 256, 0, st>>>(pts, cell_start, ds, nd, score_sorted, flags, stats);
     else
-        nms_kernel<false><<<div_up(n, 256), 256, 0, st>>>(pts, cell_start, g, nd, score_sorted, flags, stats);
+        nms_kernel<false><<<div_up(n, 256), 256, 0, st>>>(pts, cell_start, ds, nd, score_sorted, flags, stats);
 }
 
-void launch_compact(const int *flags, const int *prefix, int n, int *kp_idx, int kp_cap,
-                    int *kp_count, hipStream_t st) {
-    compact_kernel<<<div_up(n > 0 ? n : 1, 256), 256, 0, st>>>(flags, prefix, n, kp_idx, kp_cap, kp_count);
+void launch_compact(const DevState *ds, const int *flags, const int *prefix, int n, int *kp_idx,
+                    int kp_cap, int *kp_count, hipStream_t st) {
+    compact_kernel<<<div_up(n > 0 ? n : 1, 256), 256, 0, st>>>(ds, flags, prefix, n, kp_idx, kp_cap, kp_count);
 }
 
 }  // namespace kpl
