@@ -67,7 +67,7 @@ struct kpl_detector {
 
     DevBuf stage_xyz, stage_nrm, stage_idx, stage_feat;
     DevBuf dstate, cid, cnt, cell_start, cursor, tmp_idx, scan_tmp, pts, nrm, pos_of;
-    DevBuf score_sorted, flags, prefix, stats, out_scores, out_kp, out_count;
+    DevBuf score_sorted, flags, prefix, stats, out_scores, out_kp, out_count, cand_list, cand_count;
     int cells_cap = 0;            // capacity (cells) of cnt / cell_start / cursor
     DevState *h_state = nullptr;  // pinned copy of the device state (status read-back)
     int *h_count = nullptr;       // pinned
@@ -278,21 +278,29 @@ int detect_on_device(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap
     const int n = h->n;
     const size_t nn = (size_t)(n > 0 ? n : 1);
     KPL_HIP(h, h->score_sorted.ensure(sizeof(float) * nn));
-    KPL_HIP(h, h->flags.ensure(sizeof(int) * (nn + 1)));
+    if (h->flags.cap < sizeof(int) * (nn + 1) || !h->cand_count.p) {
+        KPL_HIP(h, hipDeviceSynchronize());
+        KPL_HIP(h, h->flags.ensure(sizeof(int) * (nn + 1)));
+        KPL_HIP(h, h->cand_count.ensure(sizeof(int)));
+        KPL_HIP(h, hipMemset(h->flags.p, 0, h->flags.cap));       // kept zero by compact_kernel from here on
+        KPL_HIP(h, hipMemset(h->cand_count.p, 0, sizeof(int)));
+    }
+    KPL_HIP(h, h->cand_list.ensure(sizeof(int) * nn));
     KPL_HIP(h, h->prefix.ensure(sizeof(int) * (nn + 2)));
+    NmsList cand{h->cand_list.as<int>(), h->cand_count.as<int>()};
     const FeatDesc f = make_feat(h->prm);
     const NmsDesc nd = make_nms(h->prm);
     ForestDev fd{h->d_nodes.as<uint2>(), h->d_roots.as<uint32_t>(), h->flat.ntrees};
     const DevState *ds = h->dstate.as<DevState>();
     const size_t ev1 = mark(h, st);
-    launch_score(h->pts.as<float4>(), h->nrm.as<float4>(), h->cell_start.as<int>(), ds, f, fd, h->cid.as<int>(), n,
-                 h->score_sorted.as<float>(), d_scores, h->flags.as<int>(), d_stats, st);
+    launch_score(h->pts.as<float4>(), h->nrm.as<float4>(), h->cell_start.as<int>(), ds, f, fd, nd, h->cid.as<int>(), n,
+                 h->score_sorted.as<float>(), d_scores, h->flags.as<int>(), cand, d_stats, st);
     const size_t ev2 = mark(h, st);
     span(h, 1, ev1, ev2);
-    launch_nms(h->pts.as<float4>(), h->cell_start.as<int>(), ds, nd, h->score_sorted.as<float>(), n,
+    launch_nms(h->pts.as<float4>(), h->cell_start.as<int>(), ds, nd, h->score_sorted.as<float>(), cand, n,
                h->flags.as<int>(), d_stats, st);
     launch_exclusive_scan(h->flags.as<int>(), h->prefix.as<int>(), nullptr, nullptr, n, h->scan_tmp.as<int>(), false, st);
-    launch_compact(ds, h->flags.as<int>(), h->prefix.as<int>(), n, d_kp_idx, kp_cap, d_kp_count, st);
+    launch_compact(ds, h->flags.as<int>(), h->prefix.as<int>(), n, d_kp_idx, kp_cap, d_kp_count, cand.count, st);
     span(h, 2, ev2, mark(h, st));
     KPL_HIP(h, hipGetLastError());
     return KPL_OK;
@@ -391,7 +399,7 @@ void kpl_destroy(kpl_detector *h) {
     DevBuf *bufs[] = {&h->d_nodes, &h->d_roots, &h->stage_xyz, &h->stage_nrm, &h->stage_idx, &h->stage_feat,
                       &h->dstate, &h->cid, &h->cnt, &h->cell_start, &h->cursor, &h->tmp_idx, &h->scan_tmp,
                       &h->pts, &h->nrm, &h->pos_of, &h->score_sorted, &h->flags, &h->prefix, &h->stats,
-                      &h->out_scores, &h->out_kp, &h->out_count};
+                      &h->out_scores, &h->out_kp, &h->out_count, &h->cand_list, &h->cand_count};
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->h_state) (void)hipHostFree(h->h_state);

@@ -45,6 +45,13 @@ struct NmsDesc {
     int non_maxima;
 };
 
+// candidates of the NMS stage: storage positions of the points whose score passed the threshold,
+// appended by the score kernel in arbitrary order (the NMS predicate is order independent)
+struct NmsList {
+    int *list;    // [n]
+    int *count;   // zero between calls (compact_kernel resets it)
+};
+
 struct ForestDev {
     const uint2 *nodes;
     const uint32_t *roots;
@@ -83,11 +90,11 @@ void launch_rank_store(const char *xyz, size_t xs, const char *nrm, size_t ns, i
                        float4 *pts, float4 *nrmo, int *pos_of, hipStream_t st);
 
 // ---- scoring ("runForest") ----------------------------------------------------------------
-// scores[i] (original order, may be null) and score_sorted[s]; NaN where not scoreable; also
-// clears flags[0..n)
+// scores[i] (original order, may be null) and score_sorted[s]; NaN where not scoreable; appends
+// the points that pass the threshold to `cand` (or, without NMS, flags every scoreable point)
 void launch_score(const float4 *pts, const float4 *nrm, const int *cell_start, const DevState *ds,
-                  FeatDesc f, ForestDev forest, const int *cid, int n, float *score_sorted,
-                  float *scores, int *flags, StatsDev *stats, hipStream_t st);
+                  FeatDesc f, ForestDev forest, NmsDesc nd, const int *cid, int n, float *score_sorted,
+                  float *scores, int *flags, NmsList cand, StatsDev *stats, hipStream_t st);
 int score_block_size(int F);
 // features of listed points -> out[m*F]
 void launch_features(const float4 *pts, const float4 *nrm, const int *cell_start,
@@ -95,9 +102,10 @@ void launch_features(const float4 *pts, const float4 *nrm, const int *cell_start
                      float *out, hipStream_t st);
 
 // ---- NMS + compaction ("detectKeypoints") -------------------------------------------------
+// flags[] must be all zero on entry to a detect call; compact leaves it (and cand.count) zeroed
 void launch_nms(const float4 *pts, const int *cell_start, const DevState *ds, NmsDesc nd,
-                const float *score_sorted, int n, int *flags, StatsDev *stats, hipStream_t st);
-void launch_compact(const DevState *ds, const int *flags, const int *prefix, int n, int *kp_idx,
-                    int kp_cap, int *kp_count, hipStream_t st);
+                const float *score_sorted, NmsList cand, int n, int *flags, StatsDev *stats, hipStream_t st);
+void launch_compact(const DevState *ds, int *flags, const int *prefix, int n, int *kp_idx, int kp_cap,
+                    int *kp_count, int *cand_count, hipStream_t st);
 
 }  // namespace kpl

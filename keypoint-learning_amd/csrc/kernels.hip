@@ -646,18 +646,17 @@ __global__ __launch_bounds__(kLanes) void score_kernel(const float4 *__restrict_
                                                        const float4 *__restrict__ nrm,
                                                        const int *__restrict__ cell_start,
                                                        const DevState *__restrict__ ds, FeatDesc f,
-                                                       ForestDev forest, const int *__restrict__ cid,
-                                                       int n, float *__restrict__ score_sorted,
+                                                       ForestDev forest, NmsDesc nd,
+                                                       const int *__restrict__ cid, int n,
+                                                       float *__restrict__ score_sorted,
                                                        float *__restrict__ scores,
-                                                       int *__restrict__ flags, StatsDev *stats) {
+                                                       int *__restrict__ flags, NmsList cand,
+                                                       StatsDev *stats) {
     extern __shared__ float H[];
     const GridDesc g = ds->grid;
-    {   // per ORIGINAL point: clear the keypoint flag, and NaN for points that are not in the grid
+    {   // per ORIGINAL point: NaN for points that are not in the grid
         const int i = blockIdx.x * kLanes + threadIdx.x;
-        if (i < n) {
-            flags[i] = 0;
-            if (scores && cid[i] < 0) scores[i] = NAN;
-        }
+        if (i < n && scores && cid[i] < 0) scores[i] = NAN;
     }
 #if defined(KPL_ABLATE) && (KPL_ABLATE & 16)
     const unsigned long long stamp0 = __builtin_amdgcn_s_memtime();   // diagnostic build only
@@ -695,6 +694,12 @@ __global__ __launch_bounds__(kLanes) void score_kernel(const float4 *__restrict_
 #endif
     score_sorted[s] = score;
     if (scores) scores[__float_as_int(p.w)] = score;
+    // hand the point to the NMS stage (detectKeypoints, hpp:203-208): only scoreable points whose
+    // score, promoted to double, is not below the threshold are ever searched
+    if (scoreable) {
+        if (!nd.non_maxima) flags[__float_as_int(p.w)] = 1;                         // hpp:189-196
+        else if (!((double)score < nd.thr)) cand.list[atomicAdd(cand.count, 1)] = s;
+    }
 }
 
 // computePointsForTrainingFeatures, hpp:299-318: same feature code, sparse query list.
@@ -722,62 +727,75 @@ __global__ __launch_bounds__(kLanes) void features_kernel(const float4 *__restri
 }
 
 // detectKeypoints, hpp:197-256 with draws_remove == false (order-independent predicate):
-// keypoint <=> score >= thr (float promoted to double, hpp:207) and no neighbor within r_nms
-// has a strictly greater score (hpp:219).  non_maxima == 0: every scoreable point (hpp:189-196).
+// keypoint <=> score >= thr (float promoted to double, hpp:207 -- tested by the score kernel,
+// which appends the candidates to `cand`) and no neighbor within r_nms has a strictly greater
+// score (hpp:219).  16 lanes share one candidate and sweep its rows of cells 16 storage
+// positions at a time (coalesced 16-B loads of xyz, 4-B loads of the score), stopping at the
+// first greater neighbor; groups stride over the candidate list.
+constexpr int kNmsGroup = 16;
+
 template <bool STATS>
 __global__ __launch_bounds__(256) void nms_kernel(const float4 *__restrict__ pts,
                                                   const int *__restrict__ cell_start,
                                                   const DevState *__restrict__ ds, NmsDesc nd,
                                                   const float *__restrict__ score_sorted,
-                                                  int *__restrict__ flags, StatsDev *stats) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+                                                  NmsList cand, int *__restrict__ flags,
+                                                  StatsDev *stats) {
     const GridDesc g = ds->grid;
-    const int nfinite = cell_start[g.ncells];
-    if (s >= nfinite) return;
-    const float si = score_sorted[s];
-    if (!isfinite(si)) return;                                                     // hpp:206
-    const float4 p = pts[s];
-    const int orig = __float_as_int(p.w);
-    if (!nd.non_maxima) {
-        flags[orig] = 1;
-        return;
-    }
-    if ((double)si < nd.thr) return;                                               // hpp:207
-    const CellBox b = make_box(g, p.x, p.y, p.z, nd.rr);
-    bool is_max = true;
-    int kn = 0;
-    for (int cz = b.lo[2]; cz <= b.hi[2] && (is_max || STATS); ++cz) {
-        for (int cy = b.lo[1]; cy <= b.hi[1] && (is_max || STATS); ++cy) {
-            const int row = (cz * g.dims[1] + cy) * g.dims[0];
-            const int t0 = cell_start[row + b.lo[0]];
-            const int t1 = cell_start[row + b.hi[0] + 1];
-            for (int t = t0; t < t1; ++t) {
-                if (dist2(p.x, p.y, p.z, pts[t]) < nd.r2) {
-                    if (STATS) ++kn;
-                    if (si < score_sorted[t]) {                                    // hpp:219
-                        is_max = false;
-                        if (!STATS) break;
+    const int ncand = *cand.count;
+    const int lane = threadIdx.x & (kNmsGroup - 1);
+    const int group_in_wave = (threadIdx.x & 63) / kNmsGroup;
+    const int groups = gridDim.x * (blockDim.x / kNmsGroup);
+    for (int k = (blockIdx.x * blockDim.x + threadIdx.x) / kNmsGroup; k < ncand; k += groups) {
+        const int s = cand.list[k];
+        const float si = score_sorted[s];
+        const float4 p = pts[s];
+        const CellBox b = make_box(g, p.x, p.y, p.z, nd.rr);
+        bool greater = false;
+        int kn = 0;
+        for (int cz = b.lo[2]; cz <= b.hi[2] && (!greater || STATS); ++cz) {
+            for (int cy = b.lo[1]; cy <= b.hi[1] && (!greater || STATS); ++cy) {
+                const int row = (cz * g.dims[1] + cy) * g.dims[0];
+                const int t0 = cell_start[row + b.lo[0]];
+                const int t1 = cell_start[row + b.hi[0] + 1];
+                for (int tb = t0; tb < t1 && (!greater || STATS); tb += kNmsGroup) {
+                    const int t = tb + lane;
+                    bool hit = false;
+                    if (t < t1) {
+                        const bool in = dist2(p.x, p.y, p.z, pts[t]) < nd.r2;
+                        if (STATS) kn += in;
+                        hit = in && si < score_sorted[t];                          // hpp:219
                     }
+                    const unsigned long long any = __ballot(hit);
+                    if ((any >> (group_in_wave * kNmsGroup)) & 0xffffull) greater = true;
                 }
             }
         }
+        if (STATS) {
+            for (int off = kNmsGroup / 2; off > 0; off >>= 1) kn += __shfl_xor(kn, off);
+            if (lane == 0) {
+                atomicAdd(&stats->sum_kn, (unsigned long long)kn);
+                atomicAdd(&stats->n_thresholded, 1ull);
+            }
+        }
+        if (lane == 0 && !greater) flags[__float_as_int(p.w)] = 1;                // hpp:252-253
     }
-    if (STATS) {
-        atomicAdd(&stats->sum_kn, (unsigned long long)kn);
-        atomicAdd(&stats->n_thresholded, 1ull);
-    }
-    if (is_max) flags[orig] = 1;                                                   // hpp:252-253
 }
 
-__global__ __launch_bounds__(256) void compact_kernel(const DevState *__restrict__ ds,
-                                                      const int *flags, const int *prefix, int n,
-                                                      int *kp_idx, int kp_cap, int *kp_count) {
+// ordered compaction; also leaves flags[] and the candidate counter clean for the next call
+__global__ __launch_bounds__(256) void compact_kernel(const DevState *__restrict__ ds, int *flags,
+                                                      const int *prefix, int n, int *kp_idx,
+                                                      int kp_cap, int *kp_count, int *cand_count) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) *kp_count = ds->status != 0 ? -1 : prefix[n];   // -1: see kpl_sync_status
+    if (i == 0) {
+        *kp_count = ds->status != 0 ? -1 : prefix[n];   // -1: see kpl_sync_status
+        *cand_count = 0;
+    }
     if (i >= n) return;
     if (flags[i]) {
         int pos = prefix[i];
         if (pos < kp_cap) kp_idx[pos] = i;
+        flags[i] = 0;
     }
 }
 
@@ -836,16 +854,16 @@ void launch_rank_store(const char *xyz, size_t xs, const char *nrm, size_t ns, i
 int score_block_size(int F) { (void)F; return kLanes; }
 
 void launch_score(const float4 *pts, const float4 *nrm, const int *cell_start, const DevState *ds,
-                  FeatDesc f, ForestDev forest, const int *cid, int n, float *score_sorted,
-                  float *scores, int *flags, StatsDev *stats, hipStream_t st) {
+                  FeatDesc f, ForestDev forest, NmsDesc nd, const int *cid, int n, float *score_sorted,
+                  float *scores, int *flags, NmsList cand, StatsDev *stats, hipStream_t st) {
     if (n <= 0) return;
     const size_t lds = sizeof(float) * (size_t)f.F * kLanes;
     if (stats)
-        score_kernel<true><<<div_up(n, kLanes), kLanes, lds, st>>>(pts, nrm, cell_start, ds, f, forest, cid, n,
-                                                                    score_sorted, scores, flags, stats);
+        score_kernel<true><<<div_up(n, kLanes), kLanes, lds, st>>>(pts, nrm, cell_start, ds, f, forest, nd, cid, n,
+                                                                    score_sorted, scores, flags, cand, stats);
     else
-        score_kernel<false><<<div_up(n, kLanes), kLanes, lds, st>>>(pts, nrm, cell_start, ds, f, forest, cid, n,
-                                                                     score_sorted, scores, flags, stats);
+        score_kernel<false><<<div_up(n, kLanes), kLanes, lds, st>>>(pts, nrm, cell_start, ds, f, forest, nd, cid, n,
+                                                                     score_sorted, scores, flags, cand, stats);
 }
 
 void launch_features(const float4 *pts, const float4 *nrm, const int *cell_start,
@@ -858,17 +876,20 @@ void launch_features(const float4 *pts, const float4 *nrm, const int *cell_start
 }
 
 void launch_nms(const float4 *pts, const int *cell_start, const DevState *ds, NmsDesc nd,
-                const float *score_sorted, int n, int *flags, StatsDev *stats, hipStream_t st) {
-    if (n <= 0) return;
+                const float *score_sorted, NmsList cand, int n, int *flags, StatsDev *stats, hipStream_t st) {
+    if (n <= 0 || !nd.non_maxima) return;
+    int blocks = div_up(n, 256 / kNmsGroup);        // at most one group per point ...
+    if (blocks > 1024) blocks = 1024;               // ... but a few waves per SIMD are plenty
     if (stats)
-        nms_kernel<true><<<div_up(n, 256), 256, 0, st>>>(pts, cell_start, ds, nd, score_sorted, flags, stats);
+        nms_kernel<true><<<blocks, 256, 0, st>>>(pts, cell_start, ds, nd, score_sorted, cand, flags, stats);
     else
-        nms_kernel<false><<<div_up(n, 256), 256, 0, st>>>(pts, cell_start, ds, nd, score_sorted, flags, stats);
+        nms_kernel<false><<<blocks, 256, 0, st>>>(pts, cell_start, ds, nd, score_sorted, cand, flags, stats);
 }
 
-void launch_compact(const DevState *ds, const int *flags, const int *prefix, int n, int *kp_idx,
-                    int kp_cap, int *kp_count, hipStream_t st) {
-    compact_kernel<<<div_up(n > 0 ? n : 1, 256), 256, 0, st>>>(ds, flags, prefix, n, kp_idx, kp_cap, kp_count);
+void launch_compact(const DevState *ds, int *flags, const int *prefix, int n, int *kp_idx, int kp_cap,
+                    int *kp_count, int *cand_count, hipStream_t st) {
+    compact_kernel<<<div_up(n > 0 ? n : 1, 256), 256, 0, st>>>(ds, flags, prefix, n, kp_idx, kp_cap, kp_count,
+                                                               cand_count);
 }
 
 }  // namespace kpl
