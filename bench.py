@@ -152,6 +152,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         full_step()
+    t_enq = time.perf_counter()
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
@@ -234,6 +235,7 @@ def main():
                           "score": round(score_ms, 5),
                           "nms_compact": round(timing["nms_ms"] / max(timing["calls"], 1), 5),
                           "detect_only_wall": round(detect_only_ms, 5)},
+            "host_enqueue_ms_per_step": round((t_enq - t0) * 1e3 / args.steps, 5),
             "alg_bytes_per_point": round(b_alg_total / max(st["n_scored"], 1), 1),
             "pipeline_alg_GBps": round(b_alg_total / (ms * 1e-3) / 1e9, 2),
             "counters": st,
