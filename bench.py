@@ -39,7 +39,33 @@ def cloud_resolution_scipy(xyz):
     return float(d[:, 1].mean())
 
 
+def usable_cores():
+    """Host cores this process may really use: affinity mask and cgroup CPU quota, not the machine's
+    core count (a container on a 256-core host is usually limited to a few of them)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, min(n, 32))
+
+
 def main():
+    # the oracle's OpenMP workers must sleep, not spin, once the parity gate is done: spinning
+    # workers would compete with the thread that enqueues the timed steps
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -115,7 +141,7 @@ def main():
         from tools import forest_yaml
         fa = forest_yaml.load_forest(FOREST)
         of = kplo.Forest(fa.root, fa.var, fa.thr, fa.left, fa.right, fa.value, fa.var_count)
-        ncores = os.cpu_count() or 1
+        ncores = usable_cores()
         o_scores, o_kp = kplo.detect(xyz, nrm, A, B, r_feat, r_nms, thr, of, threads=ncores)
         g_scores = d_scores.cpu().numpy()
         g_kp = d_kp[:n_kp].cpu().numpy()
@@ -145,6 +171,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # untimed settle: let clocks ramp and the host thread pool of the parity gate go to sleep
+    t_settle = time.perf_counter()
+    while time.perf_counter() - t_settle < 0.5:
+        full_step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         full_step()
     barrier()

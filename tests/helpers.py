@@ -36,6 +36,22 @@ def trained_forest(A=5, B=6, nx=80, ny=60, seed=1, ntrees=10, max_depth=10, rmul
     return synth.train_extra_trees(feat[ok], lab, ntrees=ntrees, max_depth=max_depth, seed=seed + 1)
 
 
+def usable_cores():
+    """threads for the oracle: the affinity mask / cgroup quota, not the machine's core count"""
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(q) // int(per)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
+
+
 def oracle_forest(fa):
     return kplo.Forest(fa.root, fa.var, fa.thr, fa.left, fa.right, fa.value, fa.var_count)
 

@@ -67,7 +67,7 @@ def test_config2_full_size_vs_oracle_and_properties(kpl, oracle, cases):
     _, scores = det.compute()
     kp = det.getKeypointsIndices().copy()
     fa = forest_yaml.load_forest(CFG_FOREST)
-    o_scores, o_kp = oracle.detect(xyz, nrm, 5, 6, r, rn, thr, cases.oracle_forest(fa), threads=os.cpu_count())
+    o_scores, o_kp = oracle.detect(xyz, nrm, 5, 6, r, rn, thr, cases.oracle_forest(fa), threads=cases.usable_cores())
     assert cases.same_bits(scores, o_scores)
     assert np.array_equal(kp, o_kp)
     # properties that need no oracle
@@ -103,7 +103,7 @@ def test_config4_radius_sweep_dense(kpl, oracle, cases, rmul):
     det.setNormals(nrm)
     _, scores = det.compute()
     fa = forest_yaml.load_forest(CFG_FOREST)
-    o_scores, o_kp = oracle.detect(xyz, nrm, 5, 6, r, rn, 0.6, cases.oracle_forest(fa), threads=os.cpu_count())
+    o_scores, o_kp = oracle.detect(xyz, nrm, 5, 6, r, rn, 0.6, cases.oracle_forest(fa), threads=cases.usable_cores())
     assert cases.same_bits(scores, o_scores) and np.array_equal(det.getKeypointsIndices(), o_kp)
 
 
@@ -126,7 +126,7 @@ def test_config5_deep_forest_80_features(kpl, oracle, cases):
     det.setInputCloud(xyz)
     det.setNormals(nrm)
     _, scores = det.compute()
-    o_scores, o_kp = oracle.detect(xyz, nrm, A, B, r, rn, 0.3, cases.oracle_forest(fa), threads=os.cpu_count())
+    o_scores, o_kp = oracle.detect(xyz, nrm, A, B, r, rn, 0.3, cases.oracle_forest(fa), threads=cases.usable_cores())
     assert cases.same_bits(scores, o_scores) and np.array_equal(det.getKeypointsIndices(), o_kp)
     assert len(np.unique(o_scores)) > 10
 
