@@ -68,6 +68,7 @@ struct kpl_detector {
     DevBuf stage_xyz, stage_nrm, stage_idx, stage_feat;
     DevBuf dstate, cid, cnt, cell_start, cursor, tmp_idx, scan_tmp, pts, nrm, pos_of;
     DevBuf score_sorted, flags, prefix, stats, out_scores, out_kp, out_count, cand_list, cand_count;
+    DevBuf draw_list, draw_count, skip;
     int cells_cap = 0;            // capacity (cells) of cnt / cell_start / cursor
     DevState *h_state = nullptr;  // pinned copy of the device state (status read-back)
     int *h_count = nullptr;       // pinned
@@ -148,6 +149,8 @@ NmsDesc make_nms(const kpl_params &p) {
     d.rr = (float)(p.non_max_radius * (1.0 + 1.0 / 1024.0));
     d.thr = p.prediction_th;
     d.non_maxima = p.non_maxima;
+    d.draws_remove = p.non_maxima && p.non_maxima_draws_remove;
+    d.draws_thr = p.non_maxima_draws_threshold;
     return d;
 }
 
@@ -229,7 +232,7 @@ int build_index(kpl_detector *h, hipStream_t st) {
     launch_grid_setup(h->d_xyz, h->xs, n, (float)h->prm.radius_search, h->cells_cap, ds, st);
     launch_cell_count(h->d_xyz, h->xs, n, ds, h->cid.as<int>(), h->cnt.as<int>(), st);
     launch_exclusive_scan(h->cnt.as<int>(), h->cell_start.as<int>(), h->cursor.as<int>(), &ds->grid.ncells,
-                          h->cells_cap, h->scan_tmp.as<int>(), true, st);
+                          h->cells_cap, h->scan_tmp.as<int>(), true, -1, st);
     launch_scatter(h->cid.as<int>(), n, h->cursor.as<int>(), h->tmp_idx.as<int>(), st);
     launch_rank_store(h->d_xyz, h->xs, h->d_nrm, h->ns, n, ds, h->cid.as<int>(), h->cell_start.as<int>(),
                       h->tmp_idx.as<int>(), h->pts.as<float4>(), h->nrm.as<float4>(), h->pos_of.as<int>(), st);
@@ -269,8 +272,6 @@ int detect_on_device(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap
     if (!h->bound) return fail(h, KPL_ERR_NO_CLOUD, "no cloud bound");
     if (kp_cap < 0 || !d_kp_count || (kp_cap > 0 && !d_kp_idx))
         return fail(h, KPL_ERR_INVALID_ARG, "bad keypoint output buffers");
-    if (h->prm.non_maxima && h->prm.non_maxima_draws_remove)
-        return fail(h, KPL_ERR_UNSUPPORTED, "non_maxima_draws_remove = true is not available yet");
     rc = use_device(h);
     if (rc) return rc;
     rc = ensure_index(h, st);
@@ -299,8 +300,22 @@ int detect_on_device(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap
     span(h, 1, ev1, ev2);
     launch_nms(h->pts.as<float4>(), h->cell_start.as<int>(), ds, nd, h->score_sorted.as<float>(), cand, n,
                h->flags.as<int>(), d_stats, st);
-    launch_exclusive_scan(h->flags.as<int>(), h->prefix.as<int>(), nullptr, nullptr, n, h->scan_tmp.as<int>(), false, st);
-    launch_compact(ds, h->flags.as<int>(), h->prefix.as<int>(), n, d_kp_idx, kp_cap, d_kp_count, cand.count, st);
+    int *skip = nullptr;
+    if (nd.draws_remove) {
+        if (h->skip.cap < sizeof(int) * nn) {
+            KPL_HIP(h, hipDeviceSynchronize());
+            KPL_HIP(h, h->skip.ensure(sizeof(int) * nn));
+            KPL_HIP(h, hipMemset(h->skip.p, 0, h->skip.cap));             // kept zero by compact_kernel
+        }
+        KPL_HIP(h, h->draw_list.ensure(sizeof(int) * nn));
+        KPL_HIP(h, h->draw_count.ensure(sizeof(int)));
+        skip = h->skip.as<int>();
+        launch_draws(h->pts.as<float4>(), h->cell_start.as<int>(), h->pos_of.as<int>(), ds, nd,
+                     h->score_sorted.as<float>(), n, h->flags.as<int>(), h->prefix.as<int>(), h->scan_tmp.as<int>(),
+                     h->draw_list.as<int>(), h->draw_count.as<int>(), skip, st);
+    }
+    launch_exclusive_scan(h->flags.as<int>(), h->prefix.as<int>(), nullptr, nullptr, n, h->scan_tmp.as<int>(), false, -1, st);
+    launch_compact(ds, h->flags.as<int>(), h->prefix.as<int>(), n, d_kp_idx, kp_cap, d_kp_count, cand.count, skip, st);
     span(h, 2, ev2, mark(h, st));
     KPL_HIP(h, hipGetLastError());
     return KPL_OK;
@@ -399,7 +414,8 @@ void kpl_destroy(kpl_detector *h) {
     DevBuf *bufs[] = {&h->d_nodes, &h->d_roots, &h->stage_xyz, &h->stage_nrm, &h->stage_idx, &h->stage_feat,
                       &h->dstate, &h->cid, &h->cnt, &h->cell_start, &h->cursor, &h->tmp_idx, &h->scan_tmp,
                       &h->pts, &h->nrm, &h->pos_of, &h->score_sorted, &h->flags, &h->prefix, &h->stats,
-                      &h->out_scores, &h->out_kp, &h->out_count, &h->cand_list, &h->cand_count};
+                      &h->out_scores, &h->out_kp, &h->out_count, &h->cand_list, &h->cand_count,
+                      &h->draw_list, &h->draw_count, &h->skip};
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->h_state) (void)hipHostFree(h->h_state);

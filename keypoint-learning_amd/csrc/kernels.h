@@ -43,6 +43,8 @@ struct NmsDesc {
     float r2, rr;
     double thr;
     int non_maxima;
+    int draws_remove;     // non_maxima_draws_remove_
+    float draws_thr;      // non_maxima_draws_threshold_
 };
 
 // candidates of the NMS stage: storage positions of the points whose score passed the threshold,
@@ -82,8 +84,9 @@ void launch_cell_count(const char *xyz, size_t stride, int n, const DevState *ds
 // exclusive scan of in[0..L) into out[0..L], out[L] = total (also into out2 if given), with
 // L = min(*dlen, len) when dlen is given (len = launch-time upper bound); tmp holds >= len/4096+2
 // ints; zero_in clears the input behind the read
+// match < 0 scans the values, match >= 0 scans the predicate (value == match)
 void launch_exclusive_scan(int *in, int *out, int *out2, const int *dlen, int len, int *tmp,
-                           bool zero_in, hipStream_t st);
+                           bool zero_in, int match, hipStream_t st);
 void launch_scatter(const int *cid, int n, int *cursor, int *tmp_idx, hipStream_t st);
 void launch_rank_store(const char *xyz, size_t xs, const char *nrm, size_t ns, int n,
                        const DevState *ds, const int *cid, const int *cell_start, const int *tmp_idx,
@@ -105,7 +108,12 @@ void launch_features(const float4 *pts, const float4 *nrm, const int *cell_start
 // flags[] must be all zero on entry to a detect call; compact leaves it (and cand.count) zeroed
 void launch_nms(const float4 *pts, const int *cell_start, const DevState *ds, NmsDesc nd,
                 const float *score_sorted, NmsList cand, int n, int *flags, StatsDev *stats, hipStream_t st);
+// draws_remove: resolves the flags with value 2 (maxima with equal-score neighbors) to 0 / 1 in
+// ascending index order; skip[] must be zero on entry (compact re-zeroes it)
+void launch_draws(const float4 *pts, const int *cell_start, const int *pos_of, const DevState *ds,
+                  NmsDesc nd, const float *score_sorted, int n, int *flags, int *prefix, int *scan_tmp,
+                  int *list, int *list_count, int *skip, hipStream_t st);
 void launch_compact(const DevState *ds, int *flags, const int *prefix, int n, int *kp_idx, int kp_cap,
-                    int *kp_count, int *cand_count, hipStream_t st);
+                    int *kp_count, int *cand_count, int *skip, hipStream_t st);
 
 }  // namespace kpl

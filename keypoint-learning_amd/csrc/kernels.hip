@@ -199,14 +199,17 @@ __device__ __forceinline__ int scan_len(const int *dlen, int len) {
     return dlen ? min(*dlen, len) : len;
 }
 
+// match < 0: scan the values themselves; match >= 0: scan the predicate (value == match)
+__device__ __forceinline__ int scan_value(int v, int match) { return match < 0 ? v : (v == match ? 1 : 0); }
+
 __global__ __launch_bounds__(kScanBlock) void scan_sums_kernel(const int *in, const int *dlen, int len,
-                                                               int *sums) {
+                                                               int *sums, int match) {
     len = scan_len(dlen, len);
     const int base = blockIdx.x * kScanChunk + threadIdx.x * kScanPerThread;
     int s = 0;
 #pragma unroll
     for (int k = 0; k < kScanPerThread; ++k)
-        if (base + k < len) s += in[base + k];
+        if (base + k < len) s += scan_value(in[base + k], match);
     int tot;
     block_exclusive_scan(s, &tot);
     if (threadIdx.x == 0) sums[blockIdx.x] = tot;
@@ -229,14 +232,15 @@ __global__ __launch_bounds__(kScanBlock) void scan_top_kernel(int *sums, int nb)
 // zeroed behind the read when zero_in is set (self-cleaning counters: no memset per call)
 __global__ __launch_bounds__(kScanBlock) void scan_apply_kernel(int *in, int *out, int *out2,
                                                                 const int *dlen, int len,
-                                                                const int *sums, int nb, int zero_in) {
+                                                                const int *sums, int nb, int zero_in,
+                                                                int match) {
     len = scan_len(dlen, len);
     const int base = blockIdx.x * kScanChunk + threadIdx.x * kScanPerThread;
     int v[kScanPerThread];
     int s = 0;
 #pragma unroll
     for (int k = 0; k < kScanPerThread; ++k) {
-        v[k] = base + k < len ? in[base + k] : 0;
+        v[k] = base + k < len ? scan_value(in[base + k], match) : 0;
         if (zero_in && base + k < len) in[base + k] = 0;
         s += v[k];
     }
@@ -734,7 +738,7 @@ __global__ __launch_bounds__(kLanes) void features_kernel(const float4 *__restri
 // first greater neighbor; groups stride over the candidate list.
 constexpr int kNmsGroup = 16;
 
-template <bool STATS>
+template <bool STATS, bool DRAWS>
 __global__ __launch_bounds__(256) void nms_kernel(const float4 *__restrict__ pts,
                                                   const int *__restrict__ cell_start,
                                                   const DevState *__restrict__ ds, NmsDesc nd,
@@ -751,7 +755,7 @@ __global__ __launch_bounds__(256) void nms_kernel(const float4 *__restrict__ pts
         const float si = score_sorted[s];
         const float4 p = pts[s];
         const CellBox b = make_box(g, p.x, p.y, p.z, nd.rr);
-        bool greater = false;
+        bool greater = false, draw = false;
         int kn = 0;
         for (int cz = b.lo[2]; cz <= b.hi[2] && (!greater || STATS); ++cz) {
             for (int cy = b.lo[1]; cy <= b.hi[1] && (!greater || STATS); ++cy) {
@@ -760,14 +764,20 @@ __global__ __launch_bounds__(256) void nms_kernel(const float4 *__restrict__ pts
                 const int t1 = cell_start[row + b.hi[0] + 1];
                 for (int tb = t0; tb < t1 && (!greater || STATS); tb += kNmsGroup) {
                     const int t = tb + lane;
-                    bool hit = false;
+                    bool hit = false, eq = false;
                     if (t < t1) {
                         const bool in = dist2(p.x, p.y, p.z, pts[t]) < nd.r2;
                         if (STATS) kn += in;
-                        hit = in && si < score_sorted[t];                          // hpp:219
+                        const float sj = score_sorted[t];
+                        hit = in && si < sj;                                       // hpp:219
+                        if (DRAWS) eq = in && si == sj && t != s;                  // hpp:224-229
                     }
                     const unsigned long long any = __ballot(hit);
                     if ((any >> (group_in_wave * kNmsGroup)) & 0xffffull) greater = true;
+                    if (DRAWS) {
+                        const unsigned long long anyeq = __ballot(eq);
+                        if ((anyeq >> (group_in_wave * kNmsGroup)) & 0xffffull) draw = true;
+                    }
                 }
             }
         }
@@ -778,25 +788,92 @@ __global__ __launch_bounds__(256) void nms_kernel(const float4 *__restrict__ pts
                 atomicAdd(&stats->n_thresholded, 1ull);
             }
         }
-        if (lane == 0 && !greater) flags[__float_as_int(p.w)] = 1;                // hpp:252-253
+        // 1 = keypoint (hpp:252-253); 2 = maximum with draws, decided by draws_kernel (hpp:233-250)
+        if (lane == 0 && !greater) flags[__float_as_int(p.w)] = (DRAWS && draw) ? 2 : 1;
+    }
+}
+
+// non_maxima_draws_remove == true, hpp:231-250: the order-dependent greedy pass over the maxima
+// that have equal-score neighbors ("draws"), in ascending point index like the reference's loop.
+// One wave walks the (ordered) list; the 64 lanes sweep the neighborhood of the current point.
+// A point survives iff it is not in the skip list and some draw lies within draws_threshold;
+// every such draw goes on the skip list (a flag per point instead of std::find, same meaning).
+__global__ __launch_bounds__(64) void draws_kernel(const float4 *__restrict__ pts,
+                                                   const int *__restrict__ cell_start,
+                                                   const int *__restrict__ pos_of,
+                                                   const DevState *__restrict__ ds, NmsDesc nd,
+                                                   const float *__restrict__ score_sorted,
+                                                   const int *__restrict__ list, const int *list_count,
+                                                   int *skip, int *flags) {
+    const GridDesc g = ds->grid;
+    const int count = *list_count;
+    const int lane = threadIdx.x;
+    for (int k = 0; k < count; ++k) {
+        const int idx = list[k];
+        // earlier iterations of this loop may have put idx on the skip list: read it past the L1
+        const int skipped = __hip_atomic_load(&skip[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (skipped) {                                                              // hpp:234
+            if (lane == 0) flags[idx] = 0;
+            continue;
+        }
+        const int s = pos_of[idx];
+        const float4 p = pts[s];
+        const float si = score_sorted[s];
+        const CellBox b = make_box(g, p.x, p.y, p.z, nd.rr);
+        bool survive = false;
+        for (int cz = b.lo[2]; cz <= b.hi[2]; ++cz) {
+            for (int cy = b.lo[1]; cy <= b.hi[1]; ++cy) {
+                const int row = (cz * g.dims[1] + cy) * g.dims[0];
+                const int t0 = cell_start[row + b.lo[0]];
+                const int t1 = cell_start[row + b.hi[0] + 1];
+                for (int t = t0 + lane; t < t1; t += 64) {
+                    const float4 q = pts[t];
+                    if (t != s && dist2(p.x, p.y, p.z, q) < nd.r2 && si == score_sorted[t]) {
+                        // hpp:239 (a - b).norm(): x*x + (y*y + z*z), then sqrt
+                        const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
+                        const float distance = sqrtf(dx * dx + (dy * dy + dz * dz));
+                        if (distance < nd.draws_thr) {                              // hpp:240
+                            survive = true;
+                            __hip_atomic_store(&skip[__float_as_int(q.w)], 1, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);          // hpp:242
+                        }
+                    }
+                }
+            }
+        }
+        const bool any = __any(survive);
+        if (lane == 0) flags[idx] = any ? 1 : 0;                                    // hpp:245-248
+        // this iteration's skip marks (agent-scope stores, straight to L2) must have landed before
+        // the next iteration's agent-scope load of skip[] is issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 }
 
 // ordered compaction; also leaves flags[] and the candidate counter clean for the next call
 __global__ __launch_bounds__(256) void compact_kernel(const DevState *__restrict__ ds, int *flags,
                                                       const int *prefix, int n, int *kp_idx,
-                                                      int kp_cap, int *kp_count, int *cand_count) {
+                                                      int kp_cap, int *kp_count, int *cand_count,
+                                                      int *skip) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {
         *kp_count = ds->status != 0 ? -1 : prefix[n];   // -1: see kpl_sync_status
         *cand_count = 0;
     }
     if (i >= n) return;
+    if (skip) skip[i] = 0;
     if (flags[i]) {
         int pos = prefix[i];
         if (pos < kp_cap) kp_idx[pos] = i;
         flags[i] = 0;
     }
+}
+
+// list of the points whose flag equals `match`, ascending (prefix = scan of that predicate)
+__global__ __launch_bounds__(256) void list_match_kernel(const int *flags, const int *prefix, int n,
+                                                         int match, int *list, int *count) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *count = prefix[n];
+    if (i < n && flags[i] == match) list[prefix[i]] = i;
 }
 
 inline int div_up(int a, int b) { return (a + b - 1) / b; }
@@ -831,11 +908,11 @@ void launch_cell_count(const char *xyz, size_t stride, int n, const DevState *ds
 }
 
 void launch_exclusive_scan(int *in, int *out, int *out2, const int *dlen, int len, int *tmp,
-                           bool zero_in, hipStream_t st) {
+                           bool zero_in, int match, hipStream_t st) {
     const int nb = len > 0 ? div_up(len, kScanChunk) : 1;
-    scan_sums_kernel<<<nb, kScanBlock, 0, st>>>(in, dlen, len, tmp);
+    scan_sums_kernel<<<nb, kScanBlock, 0, st>>>(in, dlen, len, tmp, match);
     scan_top_kernel<<<1, kScanBlock, 0, st>>>(tmp, nb);
-    scan_apply_kernel<<<nb, kScanBlock, 0, st>>>(in, out, out2, dlen, len, tmp, nb, zero_in ? 1 : 0);
+    scan_apply_kernel<<<nb, kScanBlock, 0, st>>>(in, out, out2, dlen, len, tmp, nb, zero_in ? 1 : 0, match);
 }
 
 void launch_scatter(const int *cid, int n, int *cursor, int *tmp_idx, hipStream_t st) {
@@ -880,16 +957,28 @@ void launch_nms(const float4 *pts, const int *cell_start, const DevState *ds, Nm
     if (n <= 0 || !nd.non_maxima) return;
     int blocks = div_up(n, 256 / kNmsGroup);        // at most one group per point ...
     if (blocks > 1024) blocks = 1024;               // ... but a few waves per SIMD are plenty
-    if (stats)
-        nms_kernel<true><<<blocks, 256, 0, st>>>(pts, cell_start, ds, nd, score_sorted, cand, flags, stats);
-    else
-        nms_kernel<false><<<blocks, 256, 0, st>>>(pts, cell_start, ds, nd, score_sorted, cand, flags, stats);
+    if (nd.draws_remove) {
+        if (stats) nms_kernel<true, true><<<blocks, 256, 0, st>>>(pts, cell_start, ds, nd, score_sorted, cand, flags, stats);
+        else nms_kernel<false, true><<<blocks, 256, 0, st>>>(pts, cell_start, ds, nd, score_sorted, cand, flags, stats);
+    } else {
+        if (stats) nms_kernel<true, false><<<blocks, 256, 0, st>>>(pts, cell_start, ds, nd, score_sorted, cand, flags, stats);
+        else nms_kernel<false, false><<<blocks, 256, 0, st>>>(pts, cell_start, ds, nd, score_sorted, cand, flags, stats);
+    }
+}
+
+void launch_draws(const float4 *pts, const int *cell_start, const int *pos_of, const DevState *ds,
+                  NmsDesc nd, const float *score_sorted, int n, int *flags, int *prefix, int *scan_tmp,
+                  int *list, int *list_count, int *skip, hipStream_t st) {
+    if (n <= 0) return;
+    launch_exclusive_scan(flags, prefix, nullptr, nullptr, n, scan_tmp, false, 2, st);
+    list_match_kernel<<<div_up(n, 256), 256, 0, st>>>(flags, prefix, n, 2, list, list_count);
+    draws_kernel<<<1, 64, 0, st>>>(pts, cell_start, pos_of, ds, nd, score_sorted, list, list_count, skip, flags);
 }
 
 void launch_compact(const DevState *ds, int *flags, const int *prefix, int n, int *kp_idx, int kp_cap,
-                    int *kp_count, int *cand_count, hipStream_t st) {
+                    int *kp_count, int *cand_count, int *skip, hipStream_t st) {
     compact_kernel<<<div_up(n > 0 ? n : 1, 256), 256, 0, st>>>(ds, flags, prefix, n, kp_idx, kp_cap, kp_count,
-                                                               cand_count);
+                                                               cand_count, skip);
 }
 
 }  // namespace kpl

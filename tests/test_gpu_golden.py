@@ -40,6 +40,11 @@ def test_small_case_fixture(kpl, cases):
         _, scores = det.compute()
         assert cases.same_bits(scores, z["scores"])
         assert np.array_equal(det.getKeypointsIndices(), z["kp_thr%03d_dr0" % int(thr * 100)])
+        det.setNonMaximaDrawsRemove(True)
+        det.setNonMaximaDrawsThreshold(float(z["draws_threshold"]))
+        det.compute()
+        assert np.array_equal(det.getKeypointsIndices(), z["kp_thr%03d_dr1" % int(thr * 100)])
+        det.setNonMaximaDrawsRemove(False)
 
 
 def test_config1_cheff_view(kpl, cases):

@@ -195,3 +195,48 @@ def test_errors(kpl, cases):
         det.compute()
     assert e.value.status == kpl.ERR_GRID_TOO_LARGE
     assert not det.loadForest("/nonexistent/forest.yaml.gz")
+
+
+@pytest.mark.parametrize("thr,dthr_mul", [(0.0, 2.0), (0.5, 1.2), (0.85, 3.0), (0.5, 0.0)])
+def test_draws_remove_greedy_pass(kpl, oracle, cases, thr, dthr_mul):
+    """non_maxima_draws_remove = true (the class default): order-dependent greedy pass."""
+    A, B = 5, 6
+    xyz, nrm = cases.cloud()
+    mr = cases.resolution()
+    r, rn = float(np.float32(6 * mr)), float(np.float32(4 * mr))
+    dthr = float(np.float32(dthr_mul * mr))
+    fa = cases.trained_forest(A, B)
+    det = make_det(kpl, A, B, r, rn, float(np.float32(thr)), fa, draws_remove=True)
+    det.setNonMaximaDrawsThreshold(dthr)
+    det.setInputCloud(xyz)
+    det.setNormals(nrm)
+    _, scores = det.compute()
+    o_scores, o_kp = oracle.detect(xyz, nrm, A, B, r, rn, float(np.float32(thr)), cases.oracle_forest(fa),
+                                   draws_remove=True, draws_threshold=dthr)
+    assert cases.same_bits(scores, o_scores)
+    assert np.array_equal(det.getKeypointsIndices(), o_kp)
+    # switching the mode off again on the same handle gives the plain predicate result
+    det.setNonMaximaDrawsRemove(False)
+    det.compute()
+    _, kp_plain = oracle.detect(xyz, nrm, A, B, r, rn, float(np.float32(thr)), cases.oracle_forest(fa))
+    assert np.array_equal(det.getKeypointsIndices(), kp_plain)
+    assert len(kp_plain) >= len(o_kp)
+
+
+def test_draws_remove_plateau_line(kpl, oracle, cases):
+    """hand-built plateau: 4 collinear points with equal scores (constant forest)."""
+    import numpy as np
+    xyz = np.zeros((4, 3), dtype=np.float32)
+    xyz[:, 0] = np.arange(4)
+    nrm = np.tile(np.array([[0, 0, 1]], dtype=np.float32), (4, 1))
+    from tools.forest_yaml import ForestArrays
+    fa = ForestArrays([0], [-1], [0.0], [-1], [-1], [0.0], 30)        # one leaf: every score = 1
+    det = make_det(kpl, 5, 6, 1.5, 1.5, 0.5, fa, draws_remove=True)
+    det.setInputCloud(xyz)
+    det.setNormals(nrm)
+    for dthr, want in ((1.2, [0, 2]), (0.5, []), (5.0, [0])):
+        det.setNonMaximaDrawsThreshold(dthr)
+        det.compute()
+        _, o_kp = oracle.detect(xyz, nrm, 5, 6, 1.5, 1.5, 0.5, cases.oracle_forest(fa), draws_remove=True,
+                                draws_threshold=dthr)
+        assert det.getKeypointsIndices().tolist() == o_kp.tolist()
