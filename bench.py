@@ -32,13 +32,6 @@ A, B = 5, 6
 HBM_PEAK = 8.0e12   # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
 
 
-def cloud_resolution_scipy(xyz):
-    """mean 2nd-NN distance (input preparation only; the path itself never needs it)."""
-    from scipy.spatial import cKDTree
-    d, _ = cKDTree(xyz.astype(np.float64)).query(xyz.astype(np.float64), k=2)
-    return float(d[:, 1].mean())
-
-
 def usable_cores():
     """Host cores this process may really use: affinity mask and cgroup CPU quota, not the machine's
     core count (a container on a 256-core host is usually limited to a few of them)."""
@@ -99,9 +92,6 @@ def main():
     xyz, nrm = synth.make_cloud(args.nx, args.ny, seed=1 + rank)
     xyz, nrm = synth.shuffle_cloud(xyz, nrm, 1001 + rank)
     n = xyz.shape[0]
-    mr = cloud_resolution_scipy(xyz)
-    r_feat = float(np.float32(6.0 * mr))
-    r_nms = float(np.float32(4.0 * mr))
     thr = float(np.float32(0.85))       # TestDetector parses the threshold as float
 
     d_xyz = torch.from_numpy(xyz).to(dev)
@@ -112,6 +102,9 @@ def main():
     d_cnt = torch.zeros(1, dtype=torch.int32, device=dev)
 
     det = kpl.KeypointLearningDetector(device=local_rank)
+    mr = det.cloudResolution(xyz)       # kpl_cloud_resolution (input preparation, not timed)
+    r_feat = float(np.float32(6.0 * mr))
+    r_nms = float(np.float32(4.0 * mr))
     det.setNAnnulus(A)
     det.setNBins(B)
     det.setNonMaxima(True)

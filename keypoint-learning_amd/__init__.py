@@ -281,6 +281,13 @@ class KeypointLearningDetector:
             return out, scores
         return xyz[self.keypoints_indices, :3], None
 
+    def cloudResolution(self, cloud):
+        """kpl::computeCloudResolution of the reference: mean distance to the second nearest neighbor."""
+        xyz, xs = self._rows(cloud)
+        res = C.c_double()
+        self._check(self._lib.kpl_cloud_resolution(self._h, xyz.ctypes.data, xs, xyz.shape[0], C.byref(res)))
+        return res.value
+
     def getKeypointsIndices(self):
         return self.keypoints_indices
 

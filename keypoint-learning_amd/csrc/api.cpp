@@ -208,8 +208,8 @@ int ensure_cells(kpl_detector *h, int64_t cap) {
 // Index build ("initCompute"), fully asynchronous: bounding box -> grid descriptor (on the device)
 // -> cell ids + counts -> scan -> scatter -> rank/store.  The host does not learn the grid size;
 // a view whose grid does not fit the current cell tables sets DevState::status (kpl_sync_status).
-int build_index(kpl_detector *h, hipStream_t st) {
-    int rc = check_params_for_compute(h, false);
+int build_index(kpl_detector *h, hipStream_t st, bool auto_cell = false) {
+    int rc = auto_cell ? KPL_OK : check_params_for_compute(h, false);
     if (rc) return rc;
     if (!h->bound) return fail(h, KPL_ERR_NO_CLOUD, "no cloud bound");
     rc = use_device(h);
@@ -229,7 +229,7 @@ int build_index(kpl_detector *h, hipStream_t st) {
     KPL_HIP(h, h->pos_of.ensure(sizeof(int) * nn));
     DevState *ds = h->dstate.as<DevState>();
     const size_t ev0 = mark(h, st);
-    launch_grid_setup(h->d_xyz, h->xs, n, (float)h->prm.radius_search, h->cells_cap, ds, st);
+    launch_grid_setup(h->d_xyz, h->xs, n, auto_cell ? 0.0f : (float)h->prm.radius_search, h->cells_cap, ds, st);
     launch_cell_count(h->d_xyz, h->xs, n, ds, h->cid.as<int>(), h->cnt.as<int>(), st);
     launch_exclusive_scan(h->cnt.as<int>(), h->cell_start.as<int>(), h->cursor.as<int>(), &ds->grid.ncells,
                           h->cells_cap, h->scan_tmp.as<int>(), true, -1, st);
@@ -238,7 +238,7 @@ int build_index(kpl_detector *h, hipStream_t st) {
                       h->tmp_idx.as<int>(), h->pts.as<float4>(), h->nrm.as<float4>(), h->pos_of.as<int>(), st);
     span(h, 0, ev0, mark(h, st));
     KPL_HIP(h, hipGetLastError());
-    h->index_valid = true;
+    h->index_valid = !auto_cell;
     h->index_radius = h->prm.radius_search;
     return KPL_OK;
 }
@@ -715,8 +715,33 @@ int kpl_collect_stats(kpl_detector *h, kpl_stats *out, void *stream) {
 
 int kpl_cloud_resolution(kpl_detector *h, const void *xyz, size_t xyz_stride, int n, double *resolution) {
     if (!h || !resolution) return KPL_ERR_INVALID_ARG;
-    (void)xyz; (void)xyz_stride; (void)n;
-    return fail(h, KPL_ERR_UNSUPPORTED, "kpl_cloud_resolution is not available yet");
+    *resolution = 0.0;
+    // the view is bound without normals: the index build copies whatever sits at the normal
+    // pointer, which this entry point never looks at
+    int rc = upload_view(h, xyz, xyz_stride, xyz, xyz_stride, n);
+    if (rc) return rc;
+    h->d_nrm = h->d_xyz;
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    KPL_HIP(h, h->stage_feat.ensure(sizeof(float) * nn));
+    KPL_HIP(h, h->out_scores.ensure(2 * sizeof(double)));
+    hipStream_t st = nullptr;
+    for (int attempt = 0;; ++attempt) {
+        rc = build_index(h, st, true);
+        if (rc) return rc;
+        launch_resolution(h->pts.as<float4>(), h->cell_start.as<int>(), h->pos_of.as<int>(), h->dstate.as<DevState>(), n,
+                          h->stage_feat.as<float>(), h->out_scores.as<double>(), st);
+        KPL_HIP(h, hipGetLastError());
+        rc = sync_status(h, st);
+        if (rc == KPL_ERR_RETRY && attempt == 0) continue;
+        if (rc) return rc;
+        break;
+    }
+    double out[2];
+    KPL_HIP(h, hipMemcpy(out, h->out_scores.p, sizeof(out), hipMemcpyDeviceToHost));
+    h->bound = false;              // the staged view has no normals: not usable for detection
+    h->index_valid = false;
+    if (out[1] > 0.0) *resolution = out[0] / out[1];                          // hpp:145-148
+    return KPL_OK;
 }
 
 }  // extern "C"

@@ -77,6 +77,7 @@ struct DevState {
 void init_dev_state(DevState *host_copy);
 
 // ---- index build ("initCompute") ----------------------------------------------------------
+// h <= 0: the cell size is derived from the bounding box and n (cloud resolution)
 void launch_grid_setup(const char *xyz, size_t stride, int n, float h, int cells_cap, DevState *ds,
                        hipStream_t st);
 void launch_cell_count(const char *xyz, size_t stride, int n, const DevState *ds, int *cid, int *cnt,
@@ -105,6 +106,10 @@ void launch_features(const float4 *pts, const float4 *nrm, const int *cell_start
                      float *out, hipStream_t st);
 
 // ---- NMS + compaction ("detectKeypoints") -------------------------------------------------
+// cloud resolution: val[n] scratch, out[0] = ordered double sum of the 2nd-NN distances, out[1] = count
+void launch_resolution(const float4 *pts, const int *cell_start, const int *pos_of, const DevState *ds,
+                       int n, float *val, double *out, hipStream_t st);
+
 // flags[] must be all zero on entry to a detect call; compact leaves it (and cand.count) zeroed
 void launch_nms(const float4 *pts, const int *cell_start, const DevState *ds, NmsDesc nd,
                 const float *score_sorted, NmsList cand, int n, int *flags, StatsDev *stats, hipStream_t st);

@@ -101,8 +101,18 @@ __device__ __forceinline__ float dec_f32_dev(uint32_t u) {
 __global__ void grid_setup_kernel(DevState *ds, float h, int n, int cells_cap) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     GridDesc g;
-    g.h = h;
     const bool any = n > 0 && ds->bbox[0] != 0xffffffffu;
+    if (!(h > 0.0f)) {
+        // no radius given (cloud resolution): about two points per cell on a surface-like cloud
+        float e[3];
+        for (int k = 0; k < 3; ++k) e[k] = any ? dec_f32_dev(ds->bbox[3 + k]) - dec_f32_dev(ds->bbox[k]) : 0.0f;
+        if (e[0] < e[1]) { float t = e[0]; e[0] = e[1]; e[1] = t; }
+        if (e[1] < e[2]) { float t = e[1]; e[1] = e[2]; e[2] = t; }
+        if (e[0] < e[1]) { float t = e[0]; e[0] = e[1]; e[1] = t; }
+        h = sqrtf(e[0] * (e[1] > 0.0f ? e[1] : e[0]) / (float)(n > 0 ? n : 1) * 2.0f);
+        if (!(h > 0.0f)) h = 1.0f;
+    }
+    g.h = h;
     long long nc = any ? 1 : 0;
     int status = 0;
     for (int k = 0; k < 3; ++k) {
@@ -849,6 +859,77 @@ __global__ __launch_bounds__(64) void draws_kernel(const float4 *__restrict__ pt
     }
 }
 
+// computeCloudResolution, /root/reference/include/impl/point_cloud_utilities.hpp:120-151: for
+// every point the square root of its second smallest squared distance (the smallest is the point
+// itself), found by growing the searched block of cells until the answer is safe.  Values in
+// ORIGINAL point order (NaN where the point is not finite or has no second neighbor).
+__global__ __launch_bounds__(256) void second_nn_kernel(const float4 *__restrict__ pts,
+                                                        const int *__restrict__ cell_start,
+                                                        const int *__restrict__ pos_of,
+                                                        const DevState *__restrict__ ds, int n,
+                                                        float *__restrict__ val) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const GridDesc g = ds->grid;
+    const int s = g.ncells > 0 ? pos_of[i] : -1;
+    if (s < 0) {
+        val[i] = NAN;
+        return;
+    }
+    const float4 p = pts[s];
+    const int cx = cell_coord(p.x, g.mn[0], g.h, g.dims[0]);
+    const int cy = cell_coord(p.y, g.mn[1], g.h, g.dims[1]);
+    const int cz = cell_coord(p.z, g.mn[2], g.h, g.dims[2]);
+    const int maxring = max(g.dims[0], max(g.dims[1], g.dims[2]));
+    float best0 = INFINITY, best1 = INFINITY;
+    for (int ring = 1; ring <= maxring; ++ring) {
+        const int x0 = max(cx - ring, 0), x1 = min(cx + ring, g.dims[0] - 1);
+        const int y0 = max(cy - ring, 0), y1 = min(cy + ring, g.dims[1] - 1);
+        const int z0 = max(cz - ring, 0), z1 = min(cz + ring, g.dims[2] - 1);
+        best0 = best1 = INFINITY;
+        for (int z = z0; z <= z1; ++z)
+            for (int y = y0; y <= y1; ++y) {
+                const int row = (z * g.dims[1] + y) * g.dims[0];
+                const int t0 = cell_start[row + x0], t1 = cell_start[row + x1 + 1];
+                for (int t = t0; t < t1; ++t) {
+                    const float d2 = dist2(p.x, p.y, p.z, pts[t]);
+                    if (d2 < best0) {
+                        best1 = best0;
+                        best0 = d2;
+                    } else if (d2 < best1) {
+                        best1 = d2;
+                    }
+                }
+            }
+        // every point outside the block is at least ring*h away (0.999: slack for the float cell edges)
+        if (isfinite(best1) && (double)sqrtf(best1) <= (double)ring * (double)g.h * 0.999) break;
+        if (x0 == 0 && y0 == 0 && z0 == 0 && x1 == g.dims[0] - 1 && y1 == g.dims[1] - 1 && z1 == g.dims[2] - 1) break;
+    }
+    val[i] = isfinite(best1) ? sqrtf(best1) : NAN;                                 // hpp:141
+}
+
+// res += sqrt(...) over the points in index order, double accumulator (hpp:141-148): one wave,
+// 64 values fetched at a time, added one after the other so that the sum is the sequential one
+__global__ __launch_bounds__(64) void ordered_sum_kernel(const float *__restrict__ val, int n, double *out) {
+    double sum = 0.0;
+    long long cnt = 0;
+    for (int b = 0; b < n; b += 64) {
+        const int i = b + threadIdx.x;
+        const float v = i < n ? val[i] : NAN;
+        for (int k = 0; k < 64; ++k) {
+            const float vk = __shfl(v, k);
+            if (!isnan(vk)) {
+                sum += (double)vk;
+                ++cnt;
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        out[0] = sum;
+        out[1] = (double)cnt;
+    }
+}
+
 // ordered compaction; also leaves flags[] and the candidate counter clean for the next call
 __global__ __launch_bounds__(256) void compact_kernel(const DevState *__restrict__ ds, int *flags,
                                                       const int *prefix, int n, int *kp_idx,
@@ -973,6 +1054,12 @@ void launch_draws(const float4 *pts, const int *cell_start, const int *pos_of, c
     launch_exclusive_scan(flags, prefix, nullptr, nullptr, n, scan_tmp, false, 2, st);
     list_match_kernel<<<div_up(n, 256), 256, 0, st>>>(flags, prefix, n, 2, list, list_count);
     draws_kernel<<<1, 64, 0, st>>>(pts, cell_start, pos_of, ds, nd, score_sorted, list, list_count, skip, flags);
+}
+
+void launch_resolution(const float4 *pts, const int *cell_start, const int *pos_of, const DevState *ds,
+                       int n, float *val, double *out, hipStream_t st) {
+    if (n > 0) second_nn_kernel<<<div_up(n, 256), 256, 0, st>>>(pts, cell_start, pos_of, ds, n, val);
+    ordered_sum_kernel<<<1, 64, 0, st>>>(val, n, out);
 }
 
 void launch_compact(const DevState *ds, int *flags, const int *prefix, int n, int *kp_idx, int kp_cap,

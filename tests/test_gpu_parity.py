@@ -240,3 +240,17 @@ def test_draws_remove_plateau_line(kpl, oracle, cases):
         _, o_kp = oracle.detect(xyz, nrm, 5, 6, 1.5, 1.5, 0.5, cases.oracle_forest(fa), draws_remove=True,
                                 draws_threshold=dthr)
         assert det.getKeypointsIndices().tolist() == o_kp.tolist()
+
+
+def test_cloud_resolution_bit_exact(kpl, oracle, cases):
+    """kpl_cloud_resolution = computeCloudResolution (point_cloud_utilities.hpp:120-151)."""
+    det = kpl.KeypointLearningDetector()
+    for nan in (0, 30):
+        xyz, _ = cases.cloud(nan_points=nan)
+        assert det.cloudResolution(xyz) == oracle.cloud_resolution(xyz)
+    p16 = np.zeros((len(xyz), 4), dtype=np.float32)
+    p16[:, :3] = xyz
+    assert det.cloudResolution(p16) == oracle.cloud_resolution(xyz)
+    assert det.cloudResolution(xyz[:1]) == 0.0 and det.cloudResolution(xyz[:0].reshape(0, 3)) == 0.0
+    two = np.array([[0, 0, 0], [3, 4, 0]], dtype=np.float32)
+    assert det.cloudResolution(two) == 5.0
