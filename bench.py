@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--nx", type=int, default=500)
     ap.add_argument("--ny", type=int, default=400)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     ap.add_argument("--no-parity", action="store_true", help="timing experiments with ablated kernels only")
     ap.add_argument("--detect-only", action="store_true",
                     help="time detectKeypoints only (index prebuilt); reported as extra field anyway")
@@ -79,9 +80,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    local_rank %= torch.cuda.device_count()      # (only matters for the 1-GPU gloo smoke run)
+    if world > 1:
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -97,9 +103,11 @@ def main():
     d_xyz = torch.from_numpy(xyz).to(dev)
     d_nrm = torch.from_numpy(nrm).to(dev)
     d_scores = torch.empty(n, dtype=torch.float32, device=dev)
+    # keypoint output = one packed buffer [count, idx_0, idx_1, ...]: the engine writes the count and
+    # the indices straight into it, and with N > 1 the same buffer is the RCCL all-gather payload
     kp_cap = n
-    d_kp = torch.empty(kp_cap, dtype=torch.int32, device=dev)
-    d_cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    d_packed = torch.zeros(kp_cap + 1, dtype=torch.int32, device=dev)
+    d_cnt, d_kp = d_packed[0:1], d_packed[1:]
 
     det = kpl.KeypointLearningDetector(device=local_rank)
     mr = det.cloudResolution(xyz)       # kpl_cloud_resolution (input preparation, not timed)
@@ -146,16 +154,16 @@ def main():
             raise SystemExit("PARITY FAILURE vs oracle: %s" % parity)
 
     # ---- multi-GPU: the one exchange step = gather the keypoint lists ------------------------------
-    gather_cap = 32768
+    gather_cap = 32768                     # keypoints per view that travel (the view has ~22 k)
+    gathered = [None]
     if world > 1:
-        send = torch.empty(gather_cap + 1, dtype=torch.int32, device=dev)
-        recv = torch.empty(world * (gather_cap + 1), dtype=torch.int32, device=dev)
+        kd = importlib.import_module("keypoint-learning_amd.dist")
+        payload = d_packed[:gather_cap + 1]
 
         def full_step():
             step()
-            send[0:1].copy_(d_cnt)
-            send[1:].copy_(d_kp[:gather_cap])
-            dist.all_gather_into_tensor(recv, send)
+            # the one exchange step of the path: all-gather of the packed keypoint lists (RCCL)
+            gathered[0] = kd.gather_keypoints(payload if args.backend == "nccl" else payload.cpu())
     else:
         full_step = step
 
@@ -167,7 +175,7 @@ def main():
     # untimed settle: let clocks ramp and the host thread pool of the parity gate go to sleep
     t_settle = time.perf_counter()
     while time.perf_counter() - t_settle < 0.5:
-        full_step()
+        step()                      # no collective in here: ranks run different iteration counts
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         full_step()
@@ -183,11 +191,12 @@ def main():
     timing = det.getTiming()
     det.enableTiming(False)
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        counts = recv.view(world, gather_cap + 1)[:, 0].cpu().numpy()
-        assert (counts > 0).all()
+        lists = kd.unpack_keypoints(gathered[0])
+        assert len(lists) == world and all(len(x) > 0 for x in lists)
+        assert np.array_equal(lists[rank].numpy(), d_kp[:len(lists[rank])].cpu().numpy())
 
     # detect-only timing (index prebuilt: mirrors detectKeypoints without initCompute)
     det.buildIndexDevice(stream)

@@ -40,6 +40,8 @@ def gather_keypoints(packed, group=None):
 
 
 def unpack_keypoints(gathered):
-    """[world, cap + 1] -> list of 1-D index tensors, one per rank."""
+    """[world, cap + 1] -> list of 1-D index tensors, one per rank (a count above cap means the
+    list was truncated to cap entries; a negative count means that rank's call failed)."""
     g = gathered.cpu()
-    return [g[r, 1:1 + int(g[r, 0])].clone() for r in range(g.shape[0])]
+    cap = g.shape[1] - 1
+    return [g[r, 1:1 + max(0, min(int(g[r, 0]), cap))].clone() for r in range(g.shape[0])]
