@@ -68,7 +68,7 @@ struct kpl_detector {
     DevBuf stage_xyz, stage_nrm, stage_idx, stage_feat;
     DevBuf dstate, cid, cnt, cell_start, cursor, tmp_idx, scan_tmp, pts, nrm, pos_of;
     DevBuf score_sorted, flags, prefix, stats, out_scores, out_kp, out_count, cand_list, cand_count;
-    DevBuf draw_list, draw_count, skip;
+    DevBuf draw_list, draw_count, skip, rowtab;
     int cells_cap = 0;            // capacity (cells) of cnt / cell_start / cursor
     DevState *h_state = nullptr;  // pinned copy of the device state (status read-back)
     int *h_count = nullptr;       // pinned
@@ -212,6 +212,7 @@ int build_index(kpl_detector *h, hipStream_t st, bool auto_cell = false) {
     int rc = auto_cell ? KPL_OK : check_params_for_compute(h, false);
     if (rc) return rc;
     if (!h->bound) return fail(h, KPL_ERR_NO_CLOUD, "no cloud bound");
+    if (h->n >= (1 << 28)) return fail(h, KPL_ERR_UNSUPPORTED, "more than 2^28 - 1 points per view");
     rc = use_device(h);
     if (rc) return rc;
     const int n = h->n;
@@ -287,6 +288,7 @@ int detect_on_device(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap
         KPL_HIP(h, hipMemset(h->cand_count.p, 0, sizeof(int)));
     }
     KPL_HIP(h, h->cand_list.ensure(sizeof(int) * nn));
+    KPL_HIP(h, h->rowtab.ensure(rowtab_bytes(n)));
     KPL_HIP(h, h->prefix.ensure(sizeof(int) * (nn + 2)));
     NmsList cand{h->cand_list.as<int>(), h->cand_count.as<int>()};
     const FeatDesc f = make_feat(h->prm);
@@ -295,7 +297,7 @@ int detect_on_device(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap
     const DevState *ds = h->dstate.as<DevState>();
     const size_t ev1 = mark(h, st);
     launch_score(h->pts.as<float4>(), h->nrm.as<float4>(), h->cell_start.as<int>(), ds, f, fd, nd, h->cid.as<int>(), n,
-                 h->score_sorted.as<float>(), d_scores, h->flags.as<int>(), cand, d_stats, st);
+                 h->score_sorted.as<float>(), d_scores, h->flags.as<int>(), cand, h->rowtab.as<uint2>(), d_stats, st);
     const size_t ev2 = mark(h, st);
     span(h, 1, ev1, ev2);
     launch_nms(h->pts.as<float4>(), h->cell_start.as<int>(), ds, nd, h->score_sorted.as<float>(), cand, n,
@@ -415,7 +417,7 @@ void kpl_destroy(kpl_detector *h) {
                       &h->dstate, &h->cid, &h->cnt, &h->cell_start, &h->cursor, &h->tmp_idx, &h->scan_tmp,
                       &h->pts, &h->nrm, &h->pos_of, &h->score_sorted, &h->flags, &h->prefix, &h->stats,
                       &h->out_scores, &h->out_kp, &h->out_count, &h->cand_list, &h->cand_count,
-                      &h->draw_list, &h->draw_count, &h->skip};
+                      &h->draw_list, &h->draw_count, &h->skip, &h->rowtab};
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->h_state) (void)hipHostFree(h->h_state);
@@ -585,8 +587,9 @@ int kpl_compute_features_device(kpl_detector *h, const int *d_indices, int m, fl
     hipStream_t st = (hipStream_t)stream;
     rc = ensure_index(h, st);
     if (rc) return rc;
+    KPL_HIP(h, h->rowtab.ensure(rowtab_bytes(m > h->n ? m : h->n)));
     launch_features(h->pts.as<float4>(), h->nrm.as<float4>(), h->cell_start.as<int>(), h->pos_of.as<int>(),
-                    h->dstate.as<DevState>(), make_feat(h->prm), d_indices, m, h->n, d_features, st);
+                    h->dstate.as<DevState>(), make_feat(h->prm), d_indices, m, h->n, h->rowtab.as<uint2>(), d_features, st);
     KPL_HIP(h, hipGetLastError());
     return KPL_OK;
 }

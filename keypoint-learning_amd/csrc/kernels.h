@@ -7,6 +7,8 @@
 //   cell_start[c]    first storage position of grid cell c, c = (cz*ny + cy)*nx + cx; a run of
 //                    cells along x is therefore ONE contiguous range of pts/nrm
 //   pos_of[i]        storage position of original point i, -1 if its xyz is not finite
+//   rowtab           per query lane: its (<= 16) non-empty rows of cells [first, end) -- scratch the
+//                    feature code writes once per point and re-reads one row ahead
 //   score_sorted[s]  forest response in storage order (what the NMS kernel gathers)
 //   flags[i]         1 if original point i is a keypoint (compacted in ascending i)
 // Canonical storage order = ascending (cell id, original index); it is what makes the float
@@ -98,12 +100,14 @@ void launch_rank_store(const char *xyz, size_t xs, const char *nrm, size_t ns, i
 // the points that pass the threshold to `cand` (or, without NMS, flags every scoreable point)
 void launch_score(const float4 *pts, const float4 *nrm, const int *cell_start, const DevState *ds,
                   FeatDesc f, ForestDev forest, NmsDesc nd, const int *cid, int n, float *score_sorted,
-                  float *scores, int *flags, NmsList cand, StatsDev *stats, hipStream_t st);
+                  float *scores, int *flags, NmsList cand, uint2 *rowtab, StatsDev *stats, hipStream_t st);
+// bytes of row-table scratch the feature code needs for `nqueries` query slots
+size_t rowtab_bytes(int nqueries);
 int score_block_size(int F);
 // features of listed points -> out[m*F]
 void launch_features(const float4 *pts, const float4 *nrm, const int *cell_start,
                      const int *pos_of, const DevState *ds, FeatDesc f, const int *query, int m, int n,
-                     float *out, hipStream_t st);
+                     uint2 *rowtab, float *out, hipStream_t st);
 
 // ---- NMS + compaction ("detectKeypoints") -------------------------------------------------
 // cloud resolution: val[n] scratch, out[0] = ordered double sum of the 2nd-NN distances, out[1] = count

@@ -380,6 +380,7 @@ __device__ __forceinline__ float dist2(float px, float py, float pz, const float
 // reference's order (hpp:350-355) and written back in order, so the float result is exactly the
 // one the sequential "+=" chain gives while only one LDS round trip sits on the critical path.
 constexpr int kLanes = 64;   // one wave per workgroup: waves never synchronise with each other
+constexpr int kMaxRows = 16; // a search box spans at most 4 x 4 rows of cells (cell edge = radius)
 
 __device__ __forceinline__ void accumulate_neighbor(const FeatDesc &f, float *H, float d2,
                                                     const float4 &np, const float4 &nq) {
@@ -412,6 +413,15 @@ __device__ __forceinline__ void accumulate_neighbor(const FeatDesc &f, float *H,
     h[c3 * kLanes] = x3;
 }
 
+// 16-byte / 4-byte loads addressed by a 32-bit byte offset from a wave-uniform base (one shift
+// instead of 64-bit address arithmetic per load; views are limited to 2^28 points)
+__device__ __forceinline__ float4 ld16(const float4 *__restrict__ base, int idx) {
+    return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + ((unsigned)idx << 4));
+}
+__device__ __forceinline__ int ld4(const int *__restrict__ base, int idx) {
+    return *reinterpret_cast<const int *>(reinterpret_cast<const char *>(base) + ((unsigned)idx << 2));
+}
+
 struct Cand4 {
     float4 q0, q1, q2, q3;
 };
@@ -419,32 +429,12 @@ struct Cand4 {
 __device__ __forceinline__ Cand4 load_cand4(const float4 *__restrict__ pts, int t, int t1) {
     const int last = t1 - 1;
     Cand4 c;
-    c.q0 = pts[t];
-    c.q1 = pts[min(t + 1, last)];
-    c.q2 = pts[min(t + 2, last)];
-    c.q3 = pts[min(t + 3, last)];
+    c.q0 = ld16(pts, t);
+    c.q1 = ld16(pts, min(t + 1, last));
+    c.q2 = ld16(pts, min(t + 2, last));
+    c.q3 = ld16(pts, min(t + 3, last));
     return c;
 }
-
-// the rows of cells of a lane's search box, visited in ascending (cz, cy).  peek() gives the
-// storage positions [x, y) of the cursor's row, or an empty range past the last row; the two
-// cell_start loads are always issued (clamped row) so that no load sits behind a branch.
-struct RowCursor {
-    int cy, cz;
-    __device__ __forceinline__ int2 peek(const int *__restrict__ cell_start, const GridDesc &g,
-                                         const CellBox &b) const {
-        const bool valid = cz <= b.hi[2];
-        const int row = ((valid ? cz : b.lo[2]) * g.dims[1] + cy) * g.dims[0];
-        const int x = cell_start[row + b.lo[0]];
-        const int y = cell_start[row + b.hi[0] + 1];
-        return valid ? make_int2(x, y) : make_int2(0, 0);
-    }
-    __device__ __forceinline__ void advance(const CellBox &b) {
-        const bool wrap = cy >= b.hi[1];
-        cy = wrap ? b.lo[1] : cy + 1;
-        cz += wrap ? 1 : 0;
-    }
-};
 
 // Returns K_f.
 //
@@ -453,44 +443,55 @@ struct RowCursor {
 //      slot when it runs dry) and request its normal -- it is accumulated NEXT iteration;
 //   A  accumulate the neighbor taken one iteration ago (its normal has had a whole iteration
 //      to arrive);
-//   B  if the lane's look-ahead slot is free: one search step (4 distance tests on the
-//      candidates requested one step ago, next 4 requested) into that slot, or a move to its
-//      next non-empty row of cells.
-// The look-ahead slot decouples the two rates: a search step that accepts nothing, or a row
-// change, does not idle stage A.  A lane needs about max(accepted neighbors, search steps + row
-// changes) iterations and the wave as many as its busiest lane; neighbors never go through
-// memory.
+//   B  if the lane has no accepted candidate left: one search step (4 distance tests on the
+//      candidates requested one iteration ago, next 4 requested), or a move to its next
+//      non-empty row of cells (row table built once per point, next entry requested ahead).
+// A lane needs about (accepted neighbors + search steps that accept nothing + non-empty rows)
+// iterations and the wave as many as its busiest lane; neighbors never go through memory.
 __device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
                                               const float4 *__restrict__ nrm,
                                               const int *__restrict__ cell_start,
                                               const GridDesc &g, const FeatDesc &f, float4 p,
-                                              float4 np, float *H, bool active) {
+                                              float4 np, float *H, uint2 *rows, bool active) {
     const int tid = threadIdx.x;
     for (int c = 0; c < f.F; ++c) H[c * kLanes + tid] = 0.0f;                    // hpp:325
-    CellBox b = make_box(g, p.x, p.y, p.z, f.rr);
-    int rows_left = active ? (b.hi[1] - b.lo[1] + 1) * (b.hi[2] - b.lo[2] + 1) : 0;
-    if (!active) {               // no rows: every range the cursor produces is empty
-        b.lo[0] = b.hi[0] = b.lo[1] = b.hi[1] = b.lo[2] = 0;
-        b.hi[2] = -1;
+    // ---- row table: the ranges of all (<= 16) rows of cells of the search box are requested at
+    // once; the non-empty ones go, in canonical (cz, cy) order, to the lane's table in scratch
+    uint2 *rw = rows + tid;
+    int nrows = 0;
+    {
+        CellBox b = make_box(g, p.x, p.y, p.z, f.rr);
+        b.hi[1] = min(b.hi[1], b.lo[1] + 3);               // cell edge = radius: never more than 4 x 4 rows
+        b.hi[2] = min(b.hi[2], b.lo[2] + 3);
+        int2 rg[kMaxRows];
+#pragma unroll
+        for (int k = 0; k < kMaxRows; ++k) {
+            const int cz = b.lo[2] + (k >> 2), cy = b.lo[1] + (k & 3);
+            const bool valid = active & (cz <= b.hi[2]) & (cy <= b.hi[1]);
+            const int row = valid ? (cz * g.dims[1] + cy) * g.dims[0] : 0;
+            const int x = ld4(cell_start, row + (valid ? b.lo[0] : 0));
+            const int y = ld4(cell_start, row + (valid ? b.hi[0] + 1 : 0));
+            rg[k] = valid ? make_int2(x, y) : make_int2(0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < kMaxRows; ++k) {
+            if (rg[k].y > rg[k].x) {
+                rw[nrows * kLanes] = make_uint2((unsigned)rg[k].x, (unsigned)rg[k].y);
+                ++nrows;
+            }
+        }
     }
     const int t_max = max(cell_start[g.ncells] - 1, 0);   // last valid storage position
-    RowCursor cur{b.lo[1], b.lo[2]};
-    // current row and two rows ahead (their cell_start loads are in flight long before use)
-    int2 r0 = cur.peek(cell_start, g, b);
-    cur.advance(b);
-    int2 r1 = cur.peek(cell_start, g, b);
-    cur.advance(b);
-    int2 r2 = cur.peek(cell_start, g, b);
-    cur.advance(b);
-    int2 rn = cur.peek(cell_start, g, b);   // the row after r2, requested one iteration before use
-    int t = r0.x, t1 = r0.y;
-    Cand4 pre = load_cand4(pts, min(t, t_max), max(t1, 1));
+    int ri = 0;                       // rows taken from the table so far
+    int t = 0, t1 = 0;                // current row: next candidate, end
+    uint2 nr = rw[0];                 // next row of the table, requested ahead of its use
+    Cand4 pre = load_cand4(pts, 0, 1);
     int kf = 0;
     bool first_pending = true;   // the first accepted neighbor has not been dropped yet (hpp:336)
-    // current slot (m0) and look-ahead slot (m1): accept bits, first position, 4 squared distances
-    unsigned m0 = 0u, m1 = 0u;
-    int tc0 = 0, tc1 = 0;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;
+    // the last search step: accept bits not taken yet, first position, the 4 squared distances
+    unsigned m0 = 0u;
+    int tc0 = 0;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     // two neighbor registers used alternately: while one is accumulated, the other one's normal
     // is on its way (no register copy between iterations, so no wait on a load in flight)
     struct Taken {
@@ -525,16 +526,11 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
     {                                                                                              \
         KPL_STAMP(3)                                                                               \
         { /* ---- C ---- */                                                                        \
-            const bool dry = m0 == 0u; /* current slot dry: take over the look-ahead slot */      \
-            m0 = dry ? m1 : m0;                                                                    \
-            tc0 = dry ? tc1 : tc0;                                                                 \
-            a0 = dry ? e0 : a0; a1 = dry ? e1 : a1; a2 = dry ? e2 : a2; a3 = dry ? e3 : a3;        \
-            m1 = dry ? 0u : m1;                                                                    \
             nxt.valid = m0 != 0u;                                                                  \
             const int k = nxt.valid ? __ffs((int)m0) - 1 : 0;                                      \
             m0 &= m0 - (nxt.valid ? 1u : 0u);                                                      \
             nxt.d2 = k == 0 ? a0 : k == 1 ? a1 : k == 2 ? a2 : a3;                                 \
-            nxt.n = nrm[nxt.valid ? tc0 + k : 0];                                                  \
+            nxt.n = ld16(nrm, nxt.valid ? tc0 + k : 0);                                            \
         }                                                                                          \
         KPL_STAMP(0)                                                                               \
         if (now.valid & (now.n.w != 0.0f)) /* ---- A ---- hpp:338 */                               \
@@ -542,9 +538,8 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
         now.valid = false;                                                                         \
         KPL_STAMP(1)                                                                               \
         { /* ---- B ---- */                                                                        \
-            const bool free_slot = (m1 == 0u) & (rows_left > 0);                                   \
-            const bool adv = free_slot & (t >= t1);   /* move to the next row of cells */           \
-            const bool stp = free_slot & (t < t1);    /* one search step */                         \
+            const bool adv = (m0 == 0u) & (t >= t1) & (ri < nrows);   /* move to the next row */      \
+            const bool stp = (m0 == 0u) & (t < t1);                   /* one search step */           \
             /* search step on the candidates requested last iteration; strict d2 < r2 */           \
             const float s0 = dist2(p.x, p.y, p.z, pre.q0);                                         \
             const float s1 = dist2(p.x, p.y, p.z, pre.q1);                                         \
@@ -559,24 +554,19 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
             const bool drop = first_pending & (m != 0u); /* hpp:336 */                             \
             m &= m - (drop ? 1u : 0u);                                                             \
             first_pending = first_pending & !drop;                                                 \
-            m1 = stp ? m : m1;                                                                     \
-            tc1 = stp ? t : tc1;                                                                   \
-            e0 = stp ? s0 : e0; e1 = stp ? s1 : e1; e2 = stp ? s2 : e2; e3 = stp ? s3 : e3;        \
-            /* row change: rn was requested during the previous iteration */                       \
-            rows_left -= adv ? 1 : 0;                                                              \
-            r0 = adv ? r1 : r0;                                                                    \
-            r1 = adv ? r2 : r1;                                                                    \
-            r2 = adv ? rn : r2;                                                                    \
-            if (adv) cur.advance(b);                                                               \
-            rn = cur.peek(cell_start, g, b);                                                       \
-            t = adv ? r0.x : (stp ? t + 4 : t);                                                    \
-            t1 = adv ? r0.y : t1;                                                                  \
-            t1 = rows_left > 0 ? t1 : t; /* past the last row: nothing left */                     \
+            m0 = stp ? m : m0;                                                                     \
+            tc0 = stp ? t : tc0;                                                                   \
+            a0 = stp ? s0 : a0; a1 = stp ? s1 : a1; a2 = stp ? s2 : a2; a3 = stp ? s3 : a3;        \
+            /* row change: nr was requested at least one iteration ago */                          \
+            t = adv ? (int)nr.x : (stp ? t + 4 : t);                                               \
+            t1 = adv ? (int)nr.y : t1;                                                             \
+            ri += adv ? 1 : 0;                                                                     \
+            nr = rw[min(ri, kMaxRows - 1) * kLanes];                                               \
             pre = load_cand4(pts, min(t, t_max), max(min(t1, t_max + 1), 1));                      \
         }                                                                                          \
         KPL_STAMP(2)                                                                               \
     }
-    while (__any((rows_left > 0) | ((m0 | m1) != 0u) | pa.valid | pb.valid)) {
+    while (__any((ri < nrows) | (t < t1) | (m0 != 0u) | pa.valid | pb.valid)) {
 #if defined(KPL_ABLATE) && (KPL_ABLATE & 64)
         dbg_iters += 2;
 #endif
@@ -665,8 +655,9 @@ __global__ __launch_bounds__(kLanes) void score_kernel(const float4 *__restrict_
                                                        float *__restrict__ score_sorted,
                                                        float *__restrict__ scores,
                                                        int *__restrict__ flags, NmsList cand,
-                                                       StatsDev *stats) {
+                                                       uint2 *__restrict__ rowtab, StatsDev *stats) {
     extern __shared__ float H[];
+    uint2 *rows = rowtab + (size_t)blockIdx.x * kMaxRows * kLanes;
     const GridDesc g = ds->grid;
     {   // per ORIGINAL point: NaN for points that are not in the grid
         const int i = blockIdx.x * kLanes + threadIdx.x;
@@ -683,7 +674,7 @@ __global__ __launch_bounds__(kLanes) void score_kernel(const float4 *__restrict_
     const bool scoreable = in_range && np.w != 0.0f;                               // hpp:277
     // every lane of the wave runs the feature code (wave-level votes inside); lanes without a
     // scoreable point simply have no rows
-    const int kf = point_features(pts, nrm, cell_start, g, f, p, np, H, scoreable);
+    const int kf = point_features(pts, nrm, cell_start, g, f, p, np, H, rows, scoreable);
     if (!in_range) return;
     float score = NAN;
     if (scoreable) {
@@ -723,8 +714,10 @@ __global__ __launch_bounds__(kLanes) void features_kernel(const float4 *__restri
                                                           const int *__restrict__ pos_of,
                                                           const DevState *__restrict__ ds, FeatDesc f,
                                                           const int *__restrict__ query, int m,
-                                                          int n, float *__restrict__ out) {
+                                                          int n, uint2 *__restrict__ rowtab,
+                                                          float *__restrict__ out) {
     extern __shared__ float H[];
+    uint2 *rows = rowtab + (size_t)blockIdx.x * kMaxRows * kLanes;
     const GridDesc g = ds->grid;
     const int qi = blockIdx.x * kLanes + threadIdx.x;
     int s = -1;
@@ -734,7 +727,7 @@ __global__ __launch_bounds__(kLanes) void features_kernel(const float4 *__restri
     }
     const float4 p = s >= 0 ? pts[s] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 np = s >= 0 ? nrm[s] : make_float4(0.f, 0.f, 0.f, 0.f);
-    point_features(pts, nrm, cell_start, g, f, p, np, H, s >= 0);
+    point_features(pts, nrm, cell_start, g, f, p, np, H, rows, s >= 0);
     if (qi >= m) return;
     float *o = out + (size_t)qi * f.F;
     for (int c = 0; c < f.F; ++c) o[c] = s >= 0 ? H[c * kLanes + threadIdx.x] : NAN;
@@ -1011,26 +1004,30 @@ void launch_rank_store(const char *xyz, size_t xs, const char *nrm, size_t ns, i
 
 int score_block_size(int F) { (void)F; return kLanes; }
 
+size_t rowtab_bytes(int nqueries) {
+    return sizeof(uint2) * (size_t)div_up(nqueries > 0 ? nqueries : 1, kLanes) * kMaxRows * kLanes;
+}
+
 void launch_score(const float4 *pts, const float4 *nrm, const int *cell_start, const DevState *ds,
                   FeatDesc f, ForestDev forest, NmsDesc nd, const int *cid, int n, float *score_sorted,
-                  float *scores, int *flags, NmsList cand, StatsDev *stats, hipStream_t st) {
+                  float *scores, int *flags, NmsList cand, uint2 *rowtab, StatsDev *stats, hipStream_t st) {
     if (n <= 0) return;
     const size_t lds = sizeof(float) * (size_t)f.F * kLanes;
     if (stats)
         score_kernel<true><<<div_up(n, kLanes), kLanes, lds, st>>>(pts, nrm, cell_start, ds, f, forest, nd, cid, n,
-                                                                    score_sorted, scores, flags, cand, stats);
+                                                                    score_sorted, scores, flags, cand, rowtab, stats);
     else
         score_kernel<false><<<div_up(n, kLanes), kLanes, lds, st>>>(pts, nrm, cell_start, ds, f, forest, nd, cid, n,
-                                                                     score_sorted, scores, flags, cand, stats);
+                                                                     score_sorted, scores, flags, cand, rowtab, stats);
 }
 
 void launch_features(const float4 *pts, const float4 *nrm, const int *cell_start,
                      const int *pos_of, const DevState *ds, FeatDesc f, const int *query, int m, int n,
-                     float *out, hipStream_t st) {
+                     uint2 *rowtab, float *out, hipStream_t st) {
     if (m <= 0) return;
     const size_t lds = sizeof(float) * (size_t)f.F * kLanes;
     features_kernel<<<div_up(m, kLanes), kLanes, lds, st>>>(pts, nrm, cell_start, pos_of, ds, f,
-                                                            query, m, n, out);
+                                                            query, m, n, rowtab, out);
 }
 
 void launch_nms(const float4 *pts, const int *cell_start, const DevState *ds, NmsDesc nd,
