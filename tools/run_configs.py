@@ -1,0 +1,224 @@
+"""Measures the BASELINE.json configs on one MI355X and prints one JSON object per config
+(the rows of BASELINE.md section 4).  GPU numbers come from the engine (libkpl, device-resident
+inputs, median of timed batches); the CPU columns are the oracle timed in the same process; parity
+(scores bit-exact + keypoint lists identical) is checked before any number is reported.
+
+    python tools/run_configs.py [cfg1 cfg2 cfg3 cfg4 cfg5]
+"""
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
+import torch  # noqa: E402
+
+from oracle import kplo  # noqa: E402
+from tests import helpers  # noqa: E402
+from tools import forest_yaml, synth  # noqa: E402
+
+kpl = importlib.import_module("keypoint-learning_amd")
+CFG_FOREST = os.path.join(ROOT, "data", "forests", "synth200k_a5b6_t10.yaml.gz")
+DEV = torch.device("cuda", 0)
+
+
+def make_detector(A, B, r, rn, thr, forest):
+    det = kpl.KeypointLearningDetector()
+    det.setNAnnulus(A); det.setNBins(B); det.setNonMaxima(True); det.setNonMaxRadius(rn)
+    det.setNonMaximaDrawsRemove(False); det.setPredictionThreshold(thr); det.setRadiusSearch(r)
+    if isinstance(forest, str):
+        assert det.loadForest(forest), det.lastError()
+    else:
+        helpers.load_arrays(det, forest)
+    return det
+
+
+def time_gpu(det, xyz, nrm, reps=30, batch=10):
+    n = len(xyz)
+    dx, dn = torch.from_numpy(np.array(xyz)).to(DEV), torch.from_numpy(np.array(nrm)).to(DEV)
+    ds = torch.empty(n, dtype=torch.float32, device=DEV)
+    dk = torch.zeros(n + 1, dtype=torch.int32, device=DEV)
+    det.bindCloudDevice(dx.data_ptr(), 12, dn.data_ptr(), 12, n)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        det.computeDevice(ds.data_ptr(), dk[1:].data_ptr(), n, dk[0:1].data_ptr(), st)
+    step()
+    if det.syncStatus(st) == kpl.ERR_RETRY:
+        step()
+        det.syncStatus(st)
+    t_end = time.perf_counter() + 0.3
+    while time.perf_counter() < t_end:
+        step()
+        torch.cuda.synchronize()
+    times = []
+    det.enableTiming(True)
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        for _ in range(batch):
+            step()
+        torch.cuda.synchronize()
+        times.append((time.perf_counter() - t0) / batch)
+    tm = det.getTiming()
+    det.enableTiming(False)
+    cnt = int(dk[0].item())
+    return (float(np.median(times)), ds.cpu().numpy(), dk[1:1 + cnt].cpu().numpy(),
+            {k: tm[k] / max(tm["calls"], 1) for k in ("index_ms", "score_ms", "nms_ms")}, det.collectStats(st))
+
+
+def time_cpu(xyz, nrm, A, B, r, rn, thr, of, budget=12.0):
+    cores = helpers.usable_cores()
+    t0 = time.perf_counter()
+    sc, kp = kplo.detect(xyz, nrm, A, B, r, rn, thr, of, threads=cores)
+    t_all = time.perf_counter() - t0
+    n = len(xyz)
+    # 1 thread on a bounded sample: the first m points' worth of work is not separable, so time the
+    # whole view only when it fits the budget, else a spatially compact prefix of the storage order
+    est = t_all * cores * 0.8
+    if est <= budget:
+        t0 = time.perf_counter()
+        kplo.detect(xyz, nrm, A, B, r, rn, thr, of, threads=1)
+        t1 = time.perf_counter() - t0
+        sample = "whole view"
+        rate1 = n / t1 / 1e6
+    else:
+        g = kplo.Grid(xyz, r)
+        m = max(1000, int(n * budget / est))
+        q = g.sorted_indices()[:m].astype(np.int32)
+        t0 = time.perf_counter()
+        feat = g.features(nrm, A, B, r, q)
+        for row in feat[: min(m, 20000)]:
+            of.predict_sum(row)
+        t1 = time.perf_counter() - t0
+        sample = "features of %d points + forest of %d (spatially compact prefix)" % (m, min(m, 20000))
+        rate1 = m / t1 / 1e6
+    return sc, kp, {"cpu_1thr_Mpts": round(rate1, 4), "cpu_all_Mpts": round(n / t_all / 1e6, 3), "cores": cores,
+                    "cpu_sample": sample}
+
+
+def report(name, xyz, nrm, A, B, rmul_f, rmul_n, thr, forest, fa, extra=None):
+    det = make_detector(A, B, 1.0, 1.0, thr, forest)
+    mr = det.cloudResolution(xyz)
+    r, rn = float(np.float32(rmul_f * mr)), float(np.float32(rmul_n * mr))
+    det.setRadiusSearch(r)
+    det.setNonMaxRadius(rn)
+    of = helpers.oracle_forest(fa)
+    o_sc, o_kp, cpu = time_cpu(xyz, nrm, A, B, r, rn, thr, of)
+    t, sc, kp, phases, st = time_gpu(det, xyz, nrm)
+    ok = bool(np.array_equal(np.asarray(sc).view(np.uint32), o_sc.view(np.uint32)) and np.array_equal(kp, o_kp))
+    n = len(xyz)
+    b_alg = 24 * (st["n_scored"] + st["sum_kf"]) + 16 * st["sum_kn"] + 8 * st["sum_depth"] + 8 * st["n_scored"]
+    b_score = 24 * (st["n_scored"] + st["sum_kf"]) + 8 * st["sum_depth"] + 4 * st["n_scored"]
+    row = {"config": name, "N": n, "AxB": "%dx%d" % (A, B), "T": fa.ntrees, "nodes": int(fa.nnodes), "r_feat": "%g*mr" % rmul_f,
+           "mr": round(mr, 5), "gpu_Mpts": round(n / t / 1e6, 2), "gpu_ms": round(t * 1e3, 4),
+           "phases_ms": {k: round(v, 4) for k, v in phases.items()},
+           "K_f": round(st["sum_kf"] / max(st["n_scored"], 1), 1), "depth_per_pt": round(st["sum_depth"] / max(st["n_scored"], 1), 1),
+           "B_alg_per_pt": round(b_alg / max(st["n_scored"], 1), 1),
+           "score_kernel_alg_GBps": round(b_score / (phases["score_ms"] * 1e-3) / 1e9, 1),
+           "score_kernel_frac_of_8TBps": round(b_score / (phases["score_ms"] * 1e-3) / 8e12, 4),
+           "keypoints": int(len(kp)), "parity": ok}
+    row.update(cpu)
+    if extra:
+        row.update(extra)
+    print(json.dumps(row), flush=True)
+    assert ok, "PARITY FAILURE in " + name
+    return row
+
+
+def cfg1():
+    z = np.load(os.path.join(ROOT, "tests", "golden", "cheff000.npz"))
+    fa = forest_yaml.load_forest(CFG_FOREST)
+    report("cfg1 cheff000 + cfg forest", z["xyz"], z["nrm"], 5, 6, 6.0, 4.0, float(np.float32(0.85)), CFG_FOREST, fa)
+
+
+def cfg2():
+    xyz, nrm = synth.make_cloud(500, 400, seed=1)
+    xyz, nrm = synth.shuffle_cloud(xyz, nrm, 1001)
+    fa = forest_yaml.load_forest(CFG_FOREST)
+    report("cfg2 synthetic 200k", xyz, nrm, 5, 6, 6.0, 4.0, float(np.float32(0.85)), CFG_FOREST, fa)
+
+
+def cfg3():
+    """64 views, one handle + stream per view in flight; on ONE GPU here (8 views resident at a time),
+    so this is the per-GPU share of the 8-GPU config."""
+    fa = forest_yaml.load_forest(CFG_FOREST)
+    views = []
+    for k in range(8):
+        xyz, nrm = synth.make_cloud(252, 250, seed=100 + k)
+        views.append(synth.shuffle_cloud(xyz, nrm, 1100 + k))
+    dets, bufs, streams = [], [], []
+    for xyz, nrm in views:
+        det = make_detector(5, 6, 1.0, 1.0, float(np.float32(0.85)), CFG_FOREST)
+        mr = det.cloudResolution(xyz)
+        det.setRadiusSearch(float(np.float32(6 * mr)))
+        det.setNonMaxRadius(float(np.float32(4 * mr)))
+        n = len(xyz)
+        dx, dn = torch.from_numpy(np.array(xyz)).to(DEV), torch.from_numpy(np.array(nrm)).to(DEV)
+        ds = torch.empty(n, dtype=torch.float32, device=DEV)
+        dk = torch.zeros(n + 1, dtype=torch.int32, device=DEV)
+        det.bindCloudDevice(dx.data_ptr(), 12, dn.data_ptr(), 12, n)
+        dets.append(det); bufs.append((dx, dn, ds, dk)); streams.append(torch.cuda.Stream())
+    def sweep():
+        for det, (dx, dn, ds, dk), st in zip(dets, bufs, streams):
+            det.computeDevice(ds.data_ptr(), dk[1:].data_ptr(), len(ds), dk[0:1].data_ptr(), st.cuda_stream)
+    sweep()
+    for det, st in zip(dets, streams):
+        if det.syncStatus(st.cuda_stream) == kpl.ERR_RETRY:
+            pass
+    sweep(); torch.cuda.synchronize()
+    # parity of every view
+    ok = True
+    for (xyz, nrm), det, (dx, dn, ds, dk) in zip(views, dets, bufs):
+        p = det._p
+        o_sc, o_kp = kplo.detect(xyz, nrm, 5, 6, p.radius_search, p.non_max_radius, p.prediction_th,
+                                 helpers.oracle_forest(fa), threads=helpers.usable_cores())
+        cnt = int(dk[0].item())
+        ok &= bool(np.array_equal(ds.cpu().numpy().view(np.uint32), o_sc.view(np.uint32)) and
+                   np.array_equal(dk[1:1 + cnt].cpu().numpy(), o_kp))
+    times = []
+    for _ in range(20):
+        t0 = time.perf_counter()
+        for _ in range(8):          # 8 sweeps x 8 views = the 64 views of the config
+            sweep()
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    t = float(np.median(times))
+    npts = 8 * sum(len(v[0]) for v in views)
+    print(json.dumps({"config": "cfg3 64 views x 63k, 8 streams on ONE GPU", "points": npts, "makespan_ms": round(t * 1e3, 3),
+                      "gpu_Mpts": round(npts / t / 1e6, 2), "parity": ok}), flush=True)
+    assert ok
+
+
+def cfg4():
+    xyz, nrm = synth.make_cloud(707, 707, seed=4)
+    xyz, nrm = synth.shuffle_cloud(xyz, nrm, 1004)
+    fa = forest_yaml.load_forest(CFG_FOREST)
+    for rmul in (4.0, 6.0, 8.0, 10.0):
+        report("cfg4 dense 500k r=%g*mr" % rmul, xyz, nrm, 5, 6, rmul, 4.0, float(np.float32(0.85)), CFG_FOREST, fa)
+
+
+def cfg5():
+    xyz, nrm = synth.make_cloud(500, 500, seed=5, overlap_layers=4)
+    xyz, nrm = synth.shuffle_cloud(xyz, nrm, 1005)
+    A, B = 8, 10
+    det = kpl.KeypointLearningDetector()
+    mr = det.cloudResolution(xyz)
+    r = float(np.float32(6 * mr))
+    g = kplo.Grid(xyz, r)
+    feat = g.features(nrm, A, B, r, g.sorted_indices()[::97].astype(np.int32))
+    t0 = time.perf_counter()
+    fa = synth.random_forest(A * B, ntrees=100, max_depth=28, seed=3, target_nodes_per_tree=20000, feat=feat)
+    report("cfg5 fused 1M, 100 deep trees", xyz, nrm, A, B, 6.0, 4.0, float(np.float32(0.3)), fa, fa,
+           {"forest_build_s": round(time.perf_counter() - t0, 1)})
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"]
+    for name in which:
+        globals()[name]()
