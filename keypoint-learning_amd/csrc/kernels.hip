@@ -372,9 +372,9 @@ __device__ __forceinline__ float dist2(float px, float py, float pz, const float
 //   H[c * 64 + lane]          LDS: the lane's A x B histogram       (bank = lane mod 32: no conflicts)
 // Neighbors are visited in canonical order (rows of cells ascending, storage positions
 // ascending); the first accepted one is dropped (hpp:336 starts at neigh_indx = 1).  Every lane
-// walks its own rows of cells back to back (the next two rows' ranges are requested ahead) with
-// the next 4 candidates' 16-B loads always in flight; the expensive part (sqrt, two soft
-// assignments, 4 histogram adds) only ever runs on accepted neighbors -- see point_features.
+// walks its own non-empty rows of cells back to back with the next search step's 16-B loads
+// always in flight; the expensive part (sqrt, two soft assignments, 4 histogram adds) only ever
+// runs on accepted neighbors -- see point_features.
 // The 4 adds of one neighbor may hit the same cell (pair == index at the range ends -- the common
 // case for bin 0); the cells are read once, the adds are forwarded through registers in the
 // reference's order (hpp:350-355) and written back in order, so the float result is exactly the
@@ -382,8 +382,14 @@ __device__ __forceinline__ float dist2(float px, float py, float pz, const float
 constexpr int kLanes = 64;   // one wave per workgroup: waves never synchronise with each other
 constexpr int kMaxRows = 16; // a search box spans at most 4 x 4 rows of cells (cell edge = radius)
 
-__device__ __forceinline__ void accumulate_neighbor(const FeatDesc &f, float *H, float d2,
-                                                    const float4 &np, const float4 &nq) {
+// what one accepted neighbor adds to the histogram: 4 cells and 4 weights (hpp:342-355)
+struct Contribution {
+    int c0, c1, c2, c3;
+    float w00, w01, w10, w11;
+};
+
+__device__ __forceinline__ Contribution neighbor_contribution(const FeatDesc &f, float d2,
+                                                              const float4 &np, const float4 &nq) {
     const float dot = np.x * nq.x + (np.y * nq.y + np.z * nq.z);                   // hpp:342
     float cosine = 1 - dot;
     int a, ap, bi, bp;
@@ -392,25 +398,33 @@ __device__ __forceinline__ void accumulate_neighbor(const FeatDesc &f, float *H,
     if (cosine < 0) cosine = 0;                                                    // cpp:70-73
     if (cosine > 2) cosine = 2;
     soft_pair(f.B, cosine, f.bin_dim, f.bin_half, f.bin_rdim, bi, bp, bw);         // hpp:348
-    const float w00 = (1 - bw) * (1 - aw);
-    const float w01 = bw * (1 - aw);
-    const float w10 = (1 - bw) * aw;
-    const float w11 = bw * aw;
-    const int c0 = a * f.B + bi, c1 = a * f.B + bp, c2 = ap * f.B + bi, c3 = ap * f.B + bp;
+    Contribution c;
+    c.w00 = (1 - bw) * (1 - aw);
+    c.w01 = bw * (1 - aw);
+    c.w10 = (1 - bw) * aw;
+    c.w11 = bw * aw;
+    c.c0 = a * f.B + bi;
+    c.c1 = a * f.B + bp;
+    c.c2 = ap * f.B + bi;
+    c.c3 = ap * f.B + bp;
+    return c;
+}
+
+__device__ __forceinline__ void apply_contribution(float *H, const Contribution &c) {
     float *h = H + threadIdx.x;
 #if defined(KPL_ABLATE) && (KPL_ABLATE & 8)
-    h[0] += (w00 + w01 + w10 + w11) * (float)(c0 + c1 + c2 + c3);   // timing experiment: math only
+    h[0] += (c.w00 + c.w01 + c.w10 + c.w11) * (float)(c.c0 + c.c1 + c.c2 + c.c3);   // timing experiment
     return;
 #endif
-    const float v0 = h[c0 * kLanes], v1 = h[c1 * kLanes], v2 = h[c2 * kLanes], v3 = h[c3 * kLanes];
-    const float x0 = v0 + w00;                                                     // hpp:350
-    const float x1 = ((c1 == c0) ? x0 : v1) + w01;                                 // hpp:351
-    const float x2 = ((c2 == c1) ? x1 : (c2 == c0) ? x0 : v2) + w10;               // hpp:354
-    const float x3 = ((c3 == c2) ? x2 : (c3 == c1) ? x1 : (c3 == c0) ? x0 : v3) + w11;  // hpp:355
-    h[c0 * kLanes] = x0;
-    h[c1 * kLanes] = x1;
-    h[c2 * kLanes] = x2;
-    h[c3 * kLanes] = x3;
+    const float v0 = h[c.c0 * kLanes], v1 = h[c.c1 * kLanes], v2 = h[c.c2 * kLanes], v3 = h[c.c3 * kLanes];
+    const float x0 = v0 + c.w00;                                                                   // hpp:350
+    const float x1 = ((c.c1 == c.c0) ? x0 : v1) + c.w01;                                           // hpp:351
+    const float x2 = ((c.c2 == c.c1) ? x1 : (c.c2 == c.c0) ? x0 : v2) + c.w10;                     // hpp:354
+    const float x3 = ((c.c3 == c.c2) ? x2 : (c.c3 == c.c1) ? x1 : (c.c3 == c.c0) ? x0 : v3) + c.w11;  // hpp:355
+    h[c.c0 * kLanes] = x0;
+    h[c.c1 * kLanes] = x1;
+    h[c.c2 * kLanes] = x2;
+    h[c.c3 * kLanes] = x3;
 }
 
 // 16-byte / 4-byte loads addressed by a 32-bit byte offset from a wave-uniform base (one shift
@@ -422,31 +436,34 @@ __device__ __forceinline__ int ld4(const int *__restrict__ base, int idx) {
     return *reinterpret_cast<const int *>(reinterpret_cast<const char *>(base) + ((unsigned)idx << 2));
 }
 
-struct Cand4 {
-    float4 q0, q1, q2, q3;
+constexpr int kStepW = 4;   // candidates tested per search step (4 and 8 measure the same; 4 keeps fewer loads in flight)
+constexpr int kTake = 1;    // accepted neighbors accumulated per iteration (2 and 3 measure slightly slower)
+
+struct Cand {
+    float4 q[kStepW];
 };
 
-__device__ __forceinline__ Cand4 load_cand4(const float4 *__restrict__ pts, int t, int t1) {
+// the kStepW candidates starting at storage position t of a row ending at t1 (indices clamped into
+// the row, so every load is issued unconditionally)
+__device__ __forceinline__ Cand load_cand(const float4 *__restrict__ pts, int t, int t1) {
     const int last = t1 - 1;
-    Cand4 c;
-    c.q0 = ld16(pts, t);
-    c.q1 = ld16(pts, min(t + 1, last));
-    c.q2 = ld16(pts, min(t + 2, last));
-    c.q3 = ld16(pts, min(t + 3, last));
+    Cand c;
+#pragma unroll
+    for (int j = 0; j < kStepW; ++j) c.q[j] = ld16(pts, min(t + j, last));
     return c;
 }
 
 // Returns K_f.
 //
 // One loop, three stages per iteration, each lane taking part in the stages it has work for:
-//   C  take the lowest accepted candidate of the current slot (refilled from the look-ahead
-//      slot when it runs dry) and request its normal -- it is accumulated NEXT iteration;
-//   A  accumulate the neighbor taken one iteration ago (its normal has had a whole iteration
-//      to arrive);
-//   B  if the lane has no accepted candidate left: one search step (4 distance tests on the
-//      candidates requested one iteration ago, next 4 requested), or a move to its next
+//   C  take the (up to kTake) lowest accepted candidates of the last search step and request
+//      their points and normals -- they are accumulated NEXT iteration;
+//   A  accumulate the neighbors taken one iteration ago, in order (their data has had a whole
+//      iteration to arrive);
+//   B  if the lane has no accepted candidate left: one search step (kStepW distance tests on the
+//      candidates requested one iteration ago, the next kStepW requested), or a move to its next
 //      non-empty row of cells (row table built once per point, next entry requested ahead).
-// A lane needs about (accepted neighbors + search steps that accept nothing + non-empty rows)
+// A lane needs about (sum over search steps of max(1, ceil(accepted / kTake)) + non-empty rows)
 // iterations and the wave as many as its busiest lane; neighbors never go through memory.
 __device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
                                               const float4 *__restrict__ nrm,
@@ -485,21 +502,25 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
     int ri = 0;                       // rows taken from the table so far
     int t = 0, t1 = 0;                // current row: next candidate, end
     uint2 nr = rw[0];                 // next row of the table, requested ahead of its use
-    Cand4 pre = load_cand4(pts, 0, 1);
+    Cand pre = load_cand(pts, 0, 1);
     int kf = 0;
     bool first_pending = true;   // the first accepted neighbor has not been dropped yet (hpp:336)
-    // the last search step: accept bits not taken yet, first position, the 4 squared distances
+    // the last search step: accept bits not taken yet and the position of its first candidate
     unsigned m0 = 0u;
     int tc0 = 0;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    // two neighbor registers used alternately: while one is accumulated, the other one's normal
-    // is on its way (no register copy between iterations, so no wait on a load in flight)
+    // two sets of neighbor registers used alternately: while one set is accumulated, the other
+    // set's points and normals are on their way (no register copy between iterations, so nothing
+    // waits on a load in flight)
     struct Taken {
         bool valid;
-        float d2;
-        float4 n;
+        float4 q, n;
     };
-    Taken pa{false, 0.f, make_float4(0.f, 0.f, 0.f, 0.f)}, pb = pa;
+    Taken pa[kTake], pb[kTake];
+#pragma unroll
+    for (int k = 0; k < kTake; ++k) {
+        pa[k].valid = pb[k].valid = false;
+        pa[k].q = pa[k].n = pb[k].q = pb[k].n = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 #if defined(KPL_ABLATE) && (KPL_ABLATE & 64)
     int dbg_iters = 0;
 #endif
@@ -525,30 +546,41 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
 #define KPL_FEATURE_ITERATION(now, nxt)                                                            \
     {                                                                                              \
         KPL_STAMP(3)                                                                               \
-        { /* ---- C ---- */                                                                        \
-            nxt.valid = m0 != 0u;                                                                  \
-            const int k = nxt.valid ? __ffs((int)m0) - 1 : 0;                                      \
-            m0 &= m0 - (nxt.valid ? 1u : 0u);                                                      \
-            nxt.d2 = k == 0 ? a0 : k == 1 ? a1 : k == 2 ? a2 : a3;                                 \
-            nxt.n = ld16(nrm, nxt.valid ? tc0 + k : 0);                                            \
+        /* ---- C: take the lowest accepted candidates, request their points and normals ---- */   \
+        _Pragma("unroll") for (int k_ = 0; k_ < kTake; ++k_) {                                     \
+            nxt[k_].valid = m0 != 0u;                                                              \
+            const int j_ = nxt[k_].valid ? __ffs((int)m0) - 1 : 0;                                 \
+            m0 &= m0 - (nxt[k_].valid ? 1u : 0u);                                                  \
+            const int t_ = nxt[k_].valid ? tc0 + j_ : 0;                                           \
+            nxt[k_].q = ld16(pts, t_);                                                             \
+            nxt[k_].n = ld16(nrm, t_);                                                             \
         }                                                                                          \
         KPL_STAMP(0)                                                                               \
-        if (now.valid & (now.n.w != 0.0f)) /* ---- A ---- hpp:338 */                               \
-            accumulate_neighbor(f, H, now.d2, np, now.n);                                          \
-        now.valid = false;                                                                         \
+        /* ---- A: accumulate the neighbors taken last iteration, in order (hpp:338: a neighbor   \
+         * with a non-finite normal is skipped) ---- */                                            \
+        {                                                                                          \
+            bool do_[kTake], any_ = false;                                                         \
+            _Pragma("unroll") for (int k_ = 0; k_ < kTake; ++k_) {                                 \
+                do_[k_] = now[k_].valid & (now[k_].n.w != 0.0f);                                   \
+                any_ |= do_[k_];                                                                   \
+                now[k_].valid = false;                                                             \
+            }                                                                                      \
+            if (any_) { /* contributions first (independent chains), then applied in order */      \
+                Contribution c_[kTake];                                                            \
+                _Pragma("unroll") for (int k_ = 0; k_ < kTake; ++k_)                               \
+                    c_[k_] = neighbor_contribution(f, dist2(p.x, p.y, p.z, now[k_].q), np, now[k_].n); \
+                _Pragma("unroll") for (int k_ = 0; k_ < kTake; ++k_)                               \
+                    if (do_[k_]) apply_contribution(H, c_[k_]);                                    \
+            }                                                                                      \
+        }                                                                                          \
         KPL_STAMP(1)                                                                               \
         { /* ---- B ---- */                                                                        \
             const bool adv = (m0 == 0u) & (t >= t1) & (ri < nrows);   /* move to the next row */      \
             const bool stp = (m0 == 0u) & (t < t1);                   /* one search step */           \
             /* search step on the candidates requested last iteration; strict d2 < r2 */           \
-            const float s0 = dist2(p.x, p.y, p.z, pre.q0);                                         \
-            const float s1 = dist2(p.x, p.y, p.z, pre.q1);                                         \
-            const float s2 = dist2(p.x, p.y, p.z, pre.q2);                                         \
-            const float s3 = dist2(p.x, p.y, p.z, pre.q3);                                         \
-            unsigned m = (unsigned)(s0 < f.r2);                                                    \
-            m |= (unsigned)((s1 < f.r2) & (t + 1 < t1)) << 1;                                      \
-            m |= (unsigned)((s2 < f.r2) & (t + 2 < t1)) << 2;                                      \
-            m |= (unsigned)((s3 < f.r2) & (t + 3 < t1)) << 3;                                      \
+            unsigned m = 0u;                                                                       \
+            _Pragma("unroll") for (int j_ = 0; j_ < kStepW; ++j_)                                  \
+                m |= (unsigned)((dist2(p.x, p.y, p.z, pre.q[j_]) < f.r2) & (t + j_ < t1)) << j_;   \
             m = stp ? m : 0u;                                                                      \
             kf += __popc(m);                                                                       \
             const bool drop = first_pending & (m != 0u); /* hpp:336 */                             \
@@ -556,23 +588,26 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
             first_pending = first_pending & !drop;                                                 \
             m0 = stp ? m : m0;                                                                     \
             tc0 = stp ? t : tc0;                                                                   \
-            a0 = stp ? s0 : a0; a1 = stp ? s1 : a1; a2 = stp ? s2 : a2; a3 = stp ? s3 : a3;        \
             /* row change: nr was requested at least one iteration ago */                          \
-            t = adv ? (int)nr.x : (stp ? t + 4 : t);                                               \
+            t = adv ? (int)nr.x : (stp ? t + kStepW : t);                                          \
             t1 = adv ? (int)nr.y : t1;                                                             \
             ri += adv ? 1 : 0;                                                                     \
             nr = rw[min(ri, kMaxRows - 1) * kLanes];                                               \
-            pre = load_cand4(pts, min(t, t_max), max(min(t1, t_max + 1), 1));                      \
+            pre = load_cand(pts, min(t, t_max), max(min(t1, t_max + 1), 1));                       \
         }                                                                                          \
         KPL_STAMP(2)                                                                               \
     }
-    while (__any((ri < nrows) | (t < t1) | (m0 != 0u) | pa.valid | pb.valid)) {
+    bool busy = false;
+    do {
 #if defined(KPL_ABLATE) && (KPL_ABLATE & 64)
         dbg_iters += 2;
 #endif
         KPL_FEATURE_ITERATION(pa, pb)
         KPL_FEATURE_ITERATION(pb, pa)
-    }
+        busy = (ri < nrows) | (t < t1) | (m0 != 0u);
+#pragma unroll
+        for (int k = 0; k < kTake; ++k) busy |= pa[k].valid | pb[k].valid;
+    } while (__any(busy));
 #undef KPL_FEATURE_ITERATION
 #undef KPL_STAMP
     for (int a = 0; a < f.A; ++a) {                                                // hpp:360-370
