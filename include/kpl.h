@@ -148,6 +148,16 @@ int kpl_compute_device(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_c
                        int *d_kp_count, void *stream);
 int kpl_compute_features_device(kpl_detector *h, const int *d_indices, int m,
                                 float *d_features, void *stream);
+/* compute() for a batch of up to 8 independent views (one handle per view, each with its cloud
+ * bound, forest loaded and parameters set; all on one device).  A single 200 k-point view is only
+ * ~3 waves per SIMD on an MI355X; the batch puts the scoring stage of all its views into ONE
+ * launch so that the chip is full, while index build and NMS of the views run concurrently on
+ * per-view streams.  Everything is ordered after prior work on `stream`, and work enqueued on
+ * `stream` afterwards sees all results.  Arrays are indexed by view; d_scores may be NULL (or hold
+ * NULLs).  Results per view are exactly those of kpl_compute_device. */
+int kpl_compute_batch_device(kpl_detector *const *handles, int count, float *const *d_scores,
+                             int *const *d_kp_idx, const int *kp_caps, int *const *d_kp_counts,
+                             void *stream);
 /* The device entry points never wait for the GPU: the grid descriptor is computed on the device.
  * Two conditions can therefore only be seen afterwards -- a view that needs more than 2^28 grid
  * cells, or more cells than the handle's tables currently hold (they start at 8*n + 65536 cells).

@@ -77,6 +77,7 @@ SYMBOLS = {
     "kpl_detect_device": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
     "kpl_compute_device": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
     "kpl_compute_features_device": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),
+    "kpl_compute_batch_device": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "kpl_sync_status": (C.c_int, [_vp, _vp]),
     "kpl_enable_timing": (C.c_int, [_vp, C.c_int]),
     "kpl_get_timing": (C.c_int, [_vp, C.POINTER(Timing)]),
@@ -106,6 +107,24 @@ def load_library():
 
 def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def compute_batch_device(detectors, d_scores, d_kp_idx, kp_caps, d_kp_counts, stream=None):
+    """kpl_compute_batch_device: one scoring launch for up to 8 independent views.  The lists hold one
+    entry per detector: raw device addresses (ints; d_scores entries may be None) and capacities."""
+    lib = load_library()
+    k = len(detectors)
+    for d in detectors:
+        d._push()
+    H = (_vp * k)(*[d._h for d in detectors])
+    S = (_vp * k)(*[(_vp(p) if p else _vp()) for p in d_scores]) if d_scores else None
+    K = (_vp * k)(*[_vp(p) for p in d_kp_idx])
+    N = (_vp * k)(*[_vp(p) for p in d_kp_counts])
+    Cp = (C.c_int * k)(*kp_caps)
+    rc = lib.kpl_compute_batch_device(C.cast(H, _vp), k, C.cast(S, _vp) if S else None, C.cast(K, _vp),
+                                      C.cast(Cp, _vp), C.cast(N, _vp), stream)
+    if rc != OK:
+        raise KplError(rc, lib.kpl_last_error(detectors[0]._h).decode())
 
 
 def forest_inspect(data):

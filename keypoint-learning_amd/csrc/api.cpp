@@ -73,6 +73,10 @@ struct kpl_detector {
     DevState *h_state = nullptr;  // pinned copy of the device state (status read-back)
     int *h_count = nullptr;       // pinned
 
+    // batched calls: this view's private stream (index build, NMS) and its fork/join events
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_index = nullptr, ev_done = nullptr, ev_fork = nullptr, ev_score = nullptr;
+
     // optional per-phase event timing (kpl_enable_timing)
     bool timing = false;
     std::vector<hipEvent_t> ev_pool;   // created lazily, reused
@@ -266,16 +270,16 @@ int sync_status(kpl_detector *h, hipStream_t st) {
     return KPL_OK;
 }
 
-int detect_on_device(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, int *d_kp_count,
-                     hipStream_t st, StatsDev *d_stats) {
+// detectKeypoints in three pieces so that the scoring stage of several views can go into one
+// launch: prepare (checks, scratch, arguments) -> scoring -> finish (NMS, draws, compaction)
+int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, int *d_kp_count,
+                   StatsDev *d_stats, ScoreArgs &a) {
     int rc = check_params_for_compute(h, true);
     if (rc) return rc;
     if (!h->bound) return fail(h, KPL_ERR_NO_CLOUD, "no cloud bound");
     if (kp_cap < 0 || !d_kp_count || (kp_cap > 0 && !d_kp_idx))
         return fail(h, KPL_ERR_INVALID_ARG, "bad keypoint output buffers");
     rc = use_device(h);
-    if (rc) return rc;
-    rc = ensure_index(h, st);
     if (rc) return rc;
     const int n = h->n;
     const size_t nn = (size_t)(n > 0 ? n : 1);
@@ -290,19 +294,7 @@ int detect_on_device(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap
     KPL_HIP(h, h->cand_list.ensure(sizeof(int) * nn));
     KPL_HIP(h, h->rowtab.ensure(rowtab_bytes(n)));
     KPL_HIP(h, h->prefix.ensure(sizeof(int) * (nn + 2)));
-    NmsList cand{h->cand_list.as<int>(), h->cand_count.as<int>()};
-    const FeatDesc f = make_feat(h->prm);
     const NmsDesc nd = make_nms(h->prm);
-    ForestDev fd{h->d_nodes.as<uint2>(), h->d_roots.as<uint32_t>(), h->flat.ntrees};
-    const DevState *ds = h->dstate.as<DevState>();
-    const size_t ev1 = mark(h, st);
-    launch_score(h->pts.as<float4>(), h->nrm.as<float4>(), h->cell_start.as<int>(), ds, f, fd, nd, h->cid.as<int>(), n,
-                 h->score_sorted.as<float>(), d_scores, h->flags.as<int>(), cand, h->rowtab.as<uint2>(), d_stats, st);
-    const size_t ev2 = mark(h, st);
-    span(h, 1, ev1, ev2);
-    launch_nms(h->pts.as<float4>(), h->cell_start.as<int>(), ds, nd, h->score_sorted.as<float>(), cand, n,
-               h->flags.as<int>(), d_stats, st);
-    int *skip = nullptr;
     if (nd.draws_remove) {
         if (h->skip.cap < sizeof(int) * nn) {
             KPL_HIP(h, hipDeviceSynchronize());
@@ -311,16 +303,56 @@ int detect_on_device(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap
         }
         KPL_HIP(h, h->draw_list.ensure(sizeof(int) * nn));
         KPL_HIP(h, h->draw_count.ensure(sizeof(int)));
-        skip = h->skip.as<int>();
-        launch_draws(h->pts.as<float4>(), h->cell_start.as<int>(), h->pos_of.as<int>(), ds, nd,
-                     h->score_sorted.as<float>(), n, h->flags.as<int>(), h->prefix.as<int>(), h->scan_tmp.as<int>(),
-                     h->draw_list.as<int>(), h->draw_count.as<int>(), skip, st);
     }
-    launch_exclusive_scan(h->flags.as<int>(), h->prefix.as<int>(), nullptr, nullptr, n, h->scan_tmp.as<int>(), false, -1, st);
-    launch_compact(ds, h->flags.as<int>(), h->prefix.as<int>(), n, d_kp_idx, kp_cap, d_kp_count, cand.count, skip, st);
-    span(h, 2, ev2, mark(h, st));
+    a.pts = h->pts.as<float4>();
+    a.nrm = h->nrm.as<float4>();
+    a.cell_start = h->cell_start.as<int>();
+    a.ds = h->dstate.as<DevState>();
+    a.f = make_feat(h->prm);
+    a.forest = ForestDev{h->d_nodes.as<uint2>(), h->d_roots.as<uint32_t>(), h->flat.ntrees};
+    a.nd = nd;
+    a.cid = h->cid.as<int>();
+    a.n = n;
+    a.score_sorted = h->score_sorted.as<float>();
+    a.scores = d_scores;
+    a.flags = h->flags.as<int>();
+    a.cand = NmsList{h->cand_list.as<int>(), h->cand_count.as<int>()};
+    a.rowtab = h->rowtab.as<uint2>();
+    a.stats = d_stats;
+    return KPL_OK;
+}
+
+int finish_detect(kpl_detector *h, const ScoreArgs &a, int *d_kp_idx, int kp_cap, int *d_kp_count, hipStream_t st) {
+    const int n = a.n;
+    launch_nms(a.pts, a.cell_start, a.ds, a.nd, a.score_sorted, a.cand, n, a.flags, a.stats, st);
+    int *skip = nullptr;
+    if (a.nd.draws_remove) {
+        skip = h->skip.as<int>();
+        launch_draws(a.pts, a.cell_start, h->pos_of.as<int>(), a.ds, a.nd, a.score_sorted, n, a.flags,
+                     h->prefix.as<int>(), h->scan_tmp.as<int>(), h->draw_list.as<int>(), h->draw_count.as<int>(), skip, st);
+    }
+    launch_exclusive_scan(a.flags, h->prefix.as<int>(), nullptr, nullptr, n, h->scan_tmp.as<int>(), false, -1, st);
+    launch_compact(a.ds, a.flags, h->prefix.as<int>(), n, d_kp_idx, kp_cap, d_kp_count, a.cand.count, skip, st);
     KPL_HIP(h, hipGetLastError());
     return KPL_OK;
+}
+
+int detect_on_device(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, int *d_kp_count,
+                     hipStream_t st, StatsDev *d_stats) {
+    ScoreArgs a;
+    int rc = check_params_for_compute(h, true);
+    if (rc) return rc;
+    rc = ensure_index(h, st);               // before prepare_detect: it may (re)allocate what `a` points at
+    if (rc) return rc;
+    rc = prepare_detect(h, d_scores, d_kp_idx, kp_cap, d_kp_count, d_stats, a);
+    if (rc) return rc;
+    const size_t ev1 = mark(h, st);
+    launch_score(a, st);
+    const size_t ev2 = mark(h, st);
+    span(h, 1, ev1, ev2);
+    rc = finish_detect(h, a, d_kp_idx, kp_cap, d_kp_count, st);
+    span(h, 2, ev2, mark(h, st));
+    return rc;
 }
 
 int upload_view(kpl_detector *h, const void *xyz, size_t xs, const void *nrm, size_t ns, int n) {
@@ -420,6 +452,11 @@ void kpl_destroy(kpl_detector *h) {
                       &h->draw_list, &h->draw_count, &h->skip, &h->rowtab};
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+    if (h->ev_index) (void)hipEventDestroy(h->ev_index);
+    if (h->ev_done) (void)hipEventDestroy(h->ev_done);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_score) (void)hipEventDestroy(h->ev_score);
+    if (h->aux) (void)hipStreamDestroy(h->aux);
     if (h->h_state) (void)hipHostFree(h->h_state);
     if (h->h_count) (void)hipHostFree(h->h_count);
     delete h;
@@ -574,6 +611,67 @@ int kpl_compute_device(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_c
     rc = build_index(h, (hipStream_t)stream);
     if (rc) return rc;
     return detect_on_device(h, d_scores, d_kp_idx, kp_cap, d_kp_count, (hipStream_t)stream, nullptr);
+}
+
+int kpl_compute_batch_device(kpl_detector *const *handles, int count, float *const *d_scores, int *const *d_kp_idx,
+                             const int *kp_caps, int *const *d_kp_counts, void *stream) {
+    if (!handles || count <= 0 || !d_kp_idx || !kp_caps || !d_kp_counts) return KPL_ERR_INVALID_ARG;
+    for (int k = 0; k < count; ++k)
+        if (!handles[k]) return KPL_ERR_INVALID_ARG;
+    kpl_detector *h0 = handles[0];
+    if (count > kMaxBatch) return fail(h0, KPL_ERR_INVALID_ARG, "at most %d views per batch", kMaxBatch);
+    hipStream_t st = (hipStream_t)stream;
+    ScoreArgs args[kMaxBatch];
+    int rc = use_device(h0);
+    if (rc) return rc;
+    // fork: every view builds its index on its own stream, after whatever `stream` holds already
+    for (int k = 0; k < count; ++k) {
+        kpl_detector *h = handles[k];
+        if (h->device != h0->device) return fail(h0, KPL_ERR_INVALID_ARG, "all views of a batch must live on one device");
+        for (int j = 0; j < k; ++j)
+            if (handles[j] == h) return fail(h0, KPL_ERR_INVALID_ARG, "a handle appears twice in the batch");
+        if (!h->aux) {
+            KPL_HIP(h, hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
+            KPL_HIP(h, hipEventCreateWithFlags(&h->ev_index, hipEventDisableTiming));
+            KPL_HIP(h, hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
+            KPL_HIP(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+            KPL_HIP(h, hipEventCreateWithFlags(&h->ev_score, hipEventDisableTiming));
+        }
+        rc = check_params_for_compute(h, true);
+        if (rc) {
+            if (h != h0) fail(h0, rc, "view %d: %s", k, kpl_last_error(h));
+            return rc;
+        }
+    }
+    KPL_HIP(h0, hipEventRecord(h0->ev_fork, st));
+    for (int k = 0; k < count; ++k) {
+        kpl_detector *h = handles[k];
+        KPL_HIP(h, hipStreamWaitEvent(h->aux, h0->ev_fork, 0));
+        rc = build_index(h, h->aux);        // allocates the view's tables: before prepare_detect
+        if (!rc) rc = prepare_detect(h, d_scores ? d_scores[k] : nullptr, d_kp_idx[k], kp_caps[k], d_kp_counts[k], nullptr, args[k]);
+        if (rc) {
+            if (h != h0) fail(h0, rc, "view %d: %s", k, kpl_last_error(h));
+            return rc;
+        }
+        KPL_HIP(h, hipEventRecord(h->ev_index, h->aux));
+        KPL_HIP(h, hipStreamWaitEvent(st, h->ev_index, 0));
+    }
+    // one launch scores every view of the batch
+    const size_t ev1 = mark(h0, st);
+    launch_score_batch(args, count, st);
+    const size_t ev2 = mark(h0, st);
+    span(h0, 1, ev1, ev2);
+    KPL_HIP(h0, hipEventRecord(h0->ev_score, st));
+    // fork again for NMS + compaction, then join on `stream`
+    for (int k = 0; k < count; ++k) {
+        kpl_detector *h = handles[k];
+        KPL_HIP(h, hipStreamWaitEvent(h->aux, h0->ev_score, 0));
+        rc = finish_detect(h, args[k], d_kp_idx[k], kp_caps[k], d_kp_counts[k], h->aux);
+        if (rc) return rc;
+        KPL_HIP(h, hipEventRecord(h->ev_done, h->aux));
+        KPL_HIP(h, hipStreamWaitEvent(st, h->ev_done, 0));
+    }
+    return KPL_OK;
 }
 
 int kpl_compute_features_device(kpl_detector *h, const int *d_indices, int m, float *d_features, void *stream) {

@@ -66,6 +66,33 @@ struct StatsDev {
     unsigned long long sum_kf, sum_kn, sum_depth, n_scored, n_thresholded;
 };
 
+struct DevState;
+
+// everything the scoring stage needs to know about one view
+struct ScoreArgs {
+    const float4 *pts, *nrm;     // canonical storage order
+    const int *cell_start;
+    const DevState *ds;
+    FeatDesc f;
+    ForestDev forest;
+    NmsDesc nd;
+    const int *cid;              // [n] cell of original point i, -1 if not finite
+    int n;
+    float *score_sorted;         // [n] out, storage order
+    float *scores;               // [n] out, original order (may be null)
+    int *flags;                  // [n] keypoint flags (only written when NMS is off)
+    NmsList cand;                // out: points that passed the threshold
+    uint2 *rowtab;               // scratch, rowtab_bytes(n)
+    StatsDev *stats;             // null unless counters are collected
+};
+
+constexpr int kMaxBatch = 8;     // views per batched launch (bounded by the kernel argument size)
+struct ScoreBatch {
+    int nviews;
+    int first_chunk[kMaxBatch + 1];
+    ScoreArgs view[kMaxBatch];
+};
+
 // Device-resident state of one handle: the grid descriptor is computed ON the device from the
 // bounding box, so the host never waits between the kernels of a call.
 constexpr int kStatusOk = 0, kStatusGridTooLarge = 1, kStatusCellCapacity = 2;
@@ -98,9 +125,9 @@ void launch_rank_store(const char *xyz, size_t xs, const char *nrm, size_t ns, i
 // ---- scoring ("runForest") ----------------------------------------------------------------
 // scores[i] (original order, may be null) and score_sorted[s]; NaN where not scoreable; appends
 // the points that pass the threshold to `cand` (or, without NMS, flags every scoreable point)
-void launch_score(const float4 *pts, const float4 *nrm, const int *cell_start, const DevState *ds,
-                  FeatDesc f, ForestDev forest, NmsDesc nd, const int *cid, int n, float *score_sorted,
-                  float *scores, int *flags, NmsList cand, uint2 *rowtab, StatsDev *stats, hipStream_t st);
+void launch_score(const ScoreArgs &a, hipStream_t st);
+// the same for up to kMaxBatch independent views in one launch (no counters)
+void launch_score_batch(const ScoreArgs *views, int nviews, hipStream_t st);
 // bytes of row-table scratch the feature code needs for `nqueries` query slots
 size_t rowtab_bytes(int nqueries);
 int score_block_size(int F);

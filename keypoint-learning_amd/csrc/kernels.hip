@@ -680,28 +680,22 @@ __device__ __forceinline__ float forest_sum(const ForestDev &forest, const float
     return (float)sum;
 }
 
+// One wave of the scoring stage: 64 consecutive storage positions of the view described by `a`.
 template <bool STATS>
-__global__ __launch_bounds__(kLanes) void score_kernel(const float4 *__restrict__ pts,
-                                                       const float4 *__restrict__ nrm,
-                                                       const int *__restrict__ cell_start,
-                                                       const DevState *__restrict__ ds, FeatDesc f,
-                                                       ForestDev forest, NmsDesc nd,
-                                                       const int *__restrict__ cid, int n,
-                                                       float *__restrict__ score_sorted,
-                                                       float *__restrict__ scores,
-                                                       int *__restrict__ flags, NmsList cand,
-                                                       uint2 *__restrict__ rowtab, StatsDev *stats) {
-    extern __shared__ float H[];
-    uint2 *rows = rowtab + (size_t)blockIdx.x * kMaxRows * kLanes;
-    const GridDesc g = ds->grid;
+__device__ __forceinline__ void score_wave(const ScoreArgs &a, int chunk, float *H) {
+    const float4 *__restrict__ pts = a.pts;
+    const float4 *__restrict__ nrm = a.nrm;
+    const int *__restrict__ cell_start = a.cell_start;
+    uint2 *rows = a.rowtab + (size_t)chunk * kMaxRows * kLanes;
+    const GridDesc g = a.ds->grid;
     {   // per ORIGINAL point: NaN for points that are not in the grid
-        const int i = blockIdx.x * kLanes + threadIdx.x;
-        if (i < n && scores && cid[i] < 0) scores[i] = NAN;
+        const int i = chunk * kLanes + threadIdx.x;
+        if (i < a.n && a.scores && a.cid[i] < 0) a.scores[i] = NAN;
     }
 #if defined(KPL_ABLATE) && (KPL_ABLATE & 16)
     const unsigned long long stamp0 = __builtin_amdgcn_s_memtime();   // diagnostic build only
 #endif
-    const int s = blockIdx.x * kLanes + threadIdx.x;
+    const int s = chunk * kLanes + threadIdx.x;
     const int nfinite = cell_start[g.ncells];
     const bool in_range = s < nfinite;
     const float4 p = in_range ? pts[s] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -709,7 +703,7 @@ __global__ __launch_bounds__(kLanes) void score_kernel(const float4 *__restrict_
     const bool scoreable = in_range && np.w != 0.0f;                               // hpp:277
     // every lane of the wave runs the feature code (wave-level votes inside); lanes without a
     // scoreable point simply have no rows
-    const int kf = point_features(pts, nrm, cell_start, g, f, p, np, H, rows, scoreable);
+    const int kf = point_features(pts, nrm, cell_start, g, a.f, p, np, H, rows, scoreable);
     if (!in_range) return;
     float score = NAN;
     if (scoreable) {
@@ -717,13 +711,13 @@ __global__ __launch_bounds__(kLanes) void score_kernel(const float4 *__restrict_
 #if defined(KPL_ABLATE) && (KPL_ABLATE & 1)
         const float fsum = 0.0f;   // timing experiment only: no forest walk
 #else
-        const float fsum = forest_sum<STATS>(forest, H, depth);
+        const float fsum = forest_sum<STATS>(a.forest, H, depth);
 #endif
-        score = 1 - (fsum / (forest.ntrees * 1.0f));                               // hpp:287
+        score = 1 - (fsum / (a.forest.ntrees * 1.0f));                             // hpp:287
         if (STATS) {
-            atomicAdd(&stats->sum_kf, (unsigned long long)kf);
-            atomicAdd(&stats->sum_depth, (unsigned long long)depth);
-            atomicAdd(&stats->n_scored, 1ull);
+            atomicAdd(&a.stats->sum_kf, (unsigned long long)kf);
+            atomicAdd(&a.stats->sum_depth, (unsigned long long)depth);
+            atomicAdd(&a.stats->n_scored, 1ull);
         }
     }
 #if defined(KPL_ABLATE) && (KPL_ABLATE & 16)
@@ -732,14 +726,30 @@ __global__ __launch_bounds__(kLanes) void score_kernel(const float4 *__restrict_
 #if defined(KPL_ABLATE) && (KPL_ABLATE & (64 | 0x380))
     score = (float)kf;   // diagnostic build only: loop iterations / stage cycles of the wave
 #endif
-    score_sorted[s] = score;
-    if (scores) scores[__float_as_int(p.w)] = score;
+    a.score_sorted[s] = score;
+    if (a.scores) a.scores[__float_as_int(p.w)] = score;
     // hand the point to the NMS stage (detectKeypoints, hpp:203-208): only scoreable points whose
     // score, promoted to double, is not below the threshold are ever searched
     if (scoreable) {
-        if (!nd.non_maxima) flags[__float_as_int(p.w)] = 1;                         // hpp:189-196
-        else if (!((double)score < nd.thr)) cand.list[atomicAdd(cand.count, 1)] = s;
+        if (!a.nd.non_maxima) a.flags[__float_as_int(p.w)] = 1;                     // hpp:189-196
+        else if (!((double)score < a.nd.thr)) a.cand.list[atomicAdd(a.cand.count, 1)] = s;
     }
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(kLanes) void score_kernel(ScoreArgs a) {
+    extern __shared__ float H[];
+    score_wave<STATS>(a, blockIdx.x, H);
+}
+
+// Several independent views in ONE launch: 200 k points are only ~3 waves per SIMD, too few to
+// hide the latencies of this kernel; a batch of views fills the chip.  Workgroup b belongs to
+// the view v with first_chunk[v] <= b < first_chunk[v + 1].
+__global__ __launch_bounds__(kLanes) void score_batch_kernel(ScoreBatch batch) {
+    extern __shared__ float H[];
+    int v = 0;
+    while (v + 1 < batch.nviews && (int)blockIdx.x >= batch.first_chunk[v + 1]) ++v;
+    score_wave<false>(batch.view[v], blockIdx.x - batch.first_chunk[v], H);
 }
 
 // computePointsForTrainingFeatures, hpp:299-318: same feature code, sparse query list.
@@ -1043,17 +1053,28 @@ size_t rowtab_bytes(int nqueries) {
     return sizeof(uint2) * (size_t)div_up(nqueries > 0 ? nqueries : 1, kLanes) * kMaxRows * kLanes;
 }
 
-void launch_score(const float4 *pts, const float4 *nrm, const int *cell_start, const DevState *ds,
-                  FeatDesc f, ForestDev forest, NmsDesc nd, const int *cid, int n, float *score_sorted,
-                  float *scores, int *flags, NmsList cand, uint2 *rowtab, StatsDev *stats, hipStream_t st) {
-    if (n <= 0) return;
-    const size_t lds = sizeof(float) * (size_t)f.F * kLanes;
-    if (stats)
-        score_kernel<true><<<div_up(n, kLanes), kLanes, lds, st>>>(pts, nrm, cell_start, ds, f, forest, nd, cid, n,
-                                                                    score_sorted, scores, flags, cand, rowtab, stats);
-    else
-        score_kernel<false><<<div_up(n, kLanes), kLanes, lds, st>>>(pts, nrm, cell_start, ds, f, forest, nd, cid, n,
-                                                                     score_sorted, scores, flags, cand, rowtab, stats);
+void launch_score(const ScoreArgs &a, hipStream_t st) {
+    if (a.n <= 0) return;
+    const size_t lds = sizeof(float) * (size_t)a.f.F * kLanes;
+    if (a.stats) score_kernel<true><<<div_up(a.n, kLanes), kLanes, lds, st>>>(a);
+    else score_kernel<false><<<div_up(a.n, kLanes), kLanes, lds, st>>>(a);
+}
+
+void launch_score_batch(const ScoreArgs *views, int nviews, hipStream_t st) {
+    ScoreBatch b;
+    b.nviews = 0;
+    int chunks = 0, maxF = 1;
+    for (int v = 0; v < nviews && b.nviews < kMaxBatch; ++v) {
+        if (views[v].n <= 0) continue;
+        b.view[b.nviews] = views[v];
+        b.first_chunk[b.nviews] = chunks;
+        chunks += div_up(views[v].n, kLanes);
+        if (views[v].f.F > maxF) maxF = views[v].f.F;
+        ++b.nviews;
+    }
+    b.first_chunk[b.nviews] = chunks;
+    if (chunks == 0) return;
+    score_batch_kernel<<<chunks, kLanes, sizeof(float) * (size_t)maxF * kLanes, st>>>(b);
 }
 
 void launch_features(const float4 *pts, const float4 *nrm, const int *cell_start,

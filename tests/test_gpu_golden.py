@@ -168,3 +168,42 @@ def test_device_resident_entry_points(kpl, oracle, cases):
     det.detectDevice(None, dk2.data_ptr(), 4, dc.data_ptr(), None)
     torch.cuda.synchronize()
     assert int(dc.item()) == len(o_kp) and np.array_equal(dk2.cpu().numpy(), o_kp[:4])
+
+
+def test_batched_compute_equals_single_views(kpl, oracle, cases):
+    """kpl_compute_batch_device: one scoring launch for several independent views (different
+    sizes, radii and thresholds) gives exactly the per-view results."""
+    import torch
+    from tools import forest_yaml, synth
+    fa = forest_yaml.load_forest(CFG_FOREST)
+    of = cases.oracle_forest(fa)
+    dev = torch.device("cuda", 0)
+    views, dets, bufs = [], [], []
+    for k, (nx, ny, thr) in enumerate([(70, 60, 0.85), (90, 50, 0.5), (33, 31, 0.0), (64, 64, 0.85)]):
+        xyz, nrm = synth.make_cloud(nx, ny, seed=20 + k, nan_points=3 * k, nan_normals=2 * k)
+        xyz, nrm = synth.shuffle_cloud(xyz, nrm, 1020 + k)
+        mr = oracle.cloud_resolution(xyz)
+        r, rn = float(np.float32((5 + k) * mr)), float(np.float32(4 * mr))
+        det = detector(kpl, 5, 6, r, rn, float(np.float32(thr)), CFG_FOREST)
+        n = len(xyz)
+        dx, dn = torch.from_numpy(xyz.copy()).to(dev), torch.from_numpy(nrm.copy()).to(dev)
+        ds = torch.empty(n, dtype=torch.float32, device=dev)
+        dk = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+        det.bindCloudDevice(dx.data_ptr(), 12, dn.data_ptr(), 12, n)
+        views.append((xyz, nrm, r, rn, float(np.float32(thr))))
+        dets.append(det)
+        bufs.append((dx, dn, ds, dk))
+    st = torch.cuda.Stream()
+    for rep in range(3):                      # repeated batches reuse the self-cleaning scratch
+        kpl.compute_batch_device(dets, [b[2].data_ptr() for b in bufs], [b[3][1:].data_ptr() for b in bufs],
+                                 [len(b[2]) for b in bufs], [b[3][0:1].data_ptr() for b in bufs], st.cuda_stream)
+        st.synchronize()
+        for (xyz, nrm, r, rn, thr), det, (dx, dn, ds, dk) in zip(views, dets, bufs):
+            assert det.syncStatus(st.cuda_stream) == kpl.OK
+            o_sc, o_kp = oracle.detect(xyz, nrm, 5, 6, r, rn, thr, of)
+            assert cases.same_bits(ds.cpu().numpy(), o_sc)
+            assert np.array_equal(dk[1:1 + int(dk[0].item())].cpu().numpy(), o_kp)
+    # a handle twice in one batch is refused
+    with pytest.raises(kpl.KplError):
+        kpl.compute_batch_device([dets[0], dets[0]], None, [bufs[0][3][1:].data_ptr()] * 2, [4, 4],
+                                 [bufs[0][3][0:1].data_ptr()] * 2, None)
