@@ -296,7 +296,7 @@ def main():
 
     if rank == 0:
         ms = elapsed * 1e3 / args.steps
-        kernel = "score_batch_kernel" if nb > 1 else "score_kernel"
+        kernel = "score_kernel"
         out = {
             "metric": "Mpoints/sec scored (feature+forest+NMS), 200k-pt cloud",
             "value": round(n * nb * world * args.steps / elapsed / 1e6, 3),
@@ -314,7 +314,8 @@ def main():
                                    "r_feat=6*mr r_nms=4*mr thr=0.85; one step = a batch of %d independent views "
                                    "per GPU (scored in one launch); %d batches in flight on %d HIP streams"
                                    % (n, nb, ng, ng),
-                       "points_per_view": n, "views_per_step_per_gpu": nb, "batches_in_flight": ng,
+                       "points_per_view": n, "views_per_step_per_gpu": nb, "views_per_launch": nb,
+                       "batches_in_flight": ng,
                        "mr": [round(v[2], 6) for v in views[:nb]],
                        "forest": os.path.basename(FOREST), "timed": "index build + detect (compute()) of every view",
                        "parallelism": "views sharded, %d rank(s)" % world},
@@ -323,6 +324,7 @@ def main():
                          "kernel": "%s (feature + forest, %d view(s) per launch)" % (kernel, nb),
                          "kernel_ms": round(score_ms, 5), "alg_bytes_per_launch": int(b_alg_score)},
             "cpu_baseline": cpu,
+            "phases_ms": {k: round(timing[k] / max(timing["calls"], 1), 5) for k in ("index_ms", "score_ms", "nms_ms")},
             "single_view": {"compute_ms": round(single_ms, 5), "Mpoints_per_s": round(n / single_ms / 1e3, 2),
                             "detect_only_ms": round(detect_only_ms, 5),
                             "score_kernel_ms": round(t_single["score_ms"] / max(t_single["calls"], 1), 5),

@@ -73,10 +73,6 @@ struct kpl_detector {
     DevState *h_state = nullptr;  // pinned copy of the device state (status read-back)
     int *h_count = nullptr;       // pinned
 
-    // batched calls: this view's private stream (index build, NMS) and its fork/join events
-    hipStream_t aux = nullptr;
-    hipEvent_t ev_index = nullptr, ev_done = nullptr, ev_fork = nullptr, ev_score = nullptr;
-
     // optional per-phase event timing (kpl_enable_timing)
     bool timing = false;
     std::vector<hipEvent_t> ev_pool;   // created lazily, reused
@@ -209,10 +205,11 @@ int ensure_cells(kpl_detector *h, int64_t cap) {
     return KPL_OK;
 }
 
-// Index build ("initCompute"), fully asynchronous: bounding box -> grid descriptor (on the device)
+// Index stage ("initCompute"), fully asynchronous: bounding box -> grid descriptor (on the device)
 // -> cell ids + counts -> scan -> scatter -> rank/store.  The host does not learn the grid size;
 // a view whose grid does not fit the current cell tables sets DevState::status (kpl_sync_status).
-int build_index(kpl_detector *h, hipStream_t st, bool auto_cell = false) {
+// prepare_index checks, allocates and fills the index half of the view descriptor.
+int prepare_index(kpl_detector *h, bool auto_cell, ViewDev &v) {
     int rc = auto_cell ? KPL_OK : check_params_for_compute(h, false);
     if (rc) return rc;
     if (!h->bound) return fail(h, KPL_ERR_NO_CLOUD, "no cloud bound");
@@ -232,24 +229,48 @@ int build_index(kpl_detector *h, hipStream_t st, bool auto_cell = false) {
     KPL_HIP(h, h->pts.ensure(sizeof(float4) * nn));
     KPL_HIP(h, h->nrm.ensure(sizeof(float4) * nn));
     KPL_HIP(h, h->pos_of.ensure(sizeof(int) * nn));
-    DevState *ds = h->dstate.as<DevState>();
-    const size_t ev0 = mark(h, st);
-    launch_grid_setup(h->d_xyz, h->xs, n, auto_cell ? 0.0f : (float)h->prm.radius_search, h->cells_cap, ds, st);
-    launch_cell_count(h->d_xyz, h->xs, n, ds, h->cid.as<int>(), h->cnt.as<int>(), st);
-    launch_exclusive_scan(h->cnt.as<int>(), h->cell_start.as<int>(), h->cursor.as<int>(), &ds->grid.ncells,
-                          h->cells_cap, h->scan_tmp.as<int>(), true, -1, st);
-    launch_scatter(h->cid.as<int>(), n, h->cursor.as<int>(), h->tmp_idx.as<int>(), st);
-    launch_rank_store(h->d_xyz, h->xs, h->d_nrm, h->ns, n, ds, h->cid.as<int>(), h->cell_start.as<int>(),
-                      h->tmp_idx.as<int>(), h->pts.as<float4>(), h->nrm.as<float4>(), h->pos_of.as<int>(), st);
-    span(h, 0, ev0, mark(h, st));
-    KPL_HIP(h, hipGetLastError());
+    v.xyz = h->d_xyz;
+    v.nrmsrc = h->d_nrm;
+    v.xs = (unsigned)h->xs;
+    v.ns = (unsigned)h->ns;
+    v.n = n;
+    v.ds = h->dstate.as<DevState>();
+    v.cells_cap = h->cells_cap;
+    v.cell = auto_cell ? 0.0f : (float)h->prm.radius_search;
+    v.cid = h->cid.as<int>();
+    v.cnt = h->cnt.as<int>();
+    v.cell_start = h->cell_start.as<int>();
+    v.cursor = h->cursor.as<int>();
+    v.tmp_idx = h->tmp_idx.as<int>();
+    v.scan_tmp = h->scan_tmp.as<int>();
+    v.pts = h->pts.as<float4>();
+    v.nrm = h->nrm.as<float4>();
+    v.pos_of = h->pos_of.as<int>();
+    return KPL_OK;
+}
+
+bool index_is_current(const kpl_detector *h) { return h->index_valid && h->index_radius == h->prm.radius_search; }
+
+void index_was_built(kpl_detector *h, bool auto_cell) {
     h->index_valid = !auto_cell;
     h->index_radius = h->prm.radius_search;
+}
+
+int build_index(kpl_detector *h, hipStream_t st, bool auto_cell = false) {
+    Batch b{};
+    b.nviews = 1;
+    int rc = prepare_index(h, auto_cell, b.view[0]);
+    if (rc) return rc;
+    const size_t ev0 = mark(h, st);
+    launch_index(b, st);
+    span(h, 0, ev0, mark(h, st));
+    KPL_HIP(h, hipGetLastError());
+    index_was_built(h, auto_cell);
     return KPL_OK;
 }
 
 int ensure_index(kpl_detector *h, hipStream_t st) {
-    if (h->index_valid && h->index_radius == h->prm.radius_search) return KPL_OK;
+    if (index_is_current(h)) return KPL_OK;
     return build_index(h, st);
 }
 
@@ -270,10 +291,9 @@ int sync_status(kpl_detector *h, hipStream_t st) {
     return KPL_OK;
 }
 
-// detectKeypoints in three pieces so that the scoring stage of several views can go into one
-// launch: prepare (checks, scratch, arguments) -> scoring -> finish (NMS, draws, compaction)
+// checks, scratch and the scoring / NMS half of the view descriptor (detectKeypoints)
 int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, int *d_kp_count,
-                   StatsDev *d_stats, ScoreArgs &a) {
+                   StatsDev *d_stats, ViewDev &v) {
     int rc = check_params_for_compute(h, true);
     if (rc) return rc;
     if (!h->bound) return fail(h, KPL_ERR_NO_CLOUD, "no cloud bound");
@@ -304,55 +324,62 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
         KPL_HIP(h, h->draw_list.ensure(sizeof(int) * nn));
         KPL_HIP(h, h->draw_count.ensure(sizeof(int)));
     }
-    a.pts = h->pts.as<float4>();
-    a.nrm = h->nrm.as<float4>();
-    a.cell_start = h->cell_start.as<int>();
-    a.ds = h->dstate.as<DevState>();
-    a.f = make_feat(h->prm);
-    a.forest = ForestDev{h->d_nodes.as<uint2>(), h->d_roots.as<uint32_t>(), h->flat.ntrees};
-    a.nd = nd;
-    a.cid = h->cid.as<int>();
-    a.n = n;
-    a.score_sorted = h->score_sorted.as<float>();
-    a.scores = d_scores;
-    a.flags = h->flags.as<int>();
-    a.cand = NmsList{h->cand_list.as<int>(), h->cand_count.as<int>()};
-    a.rowtab = h->rowtab.as<uint2>();
-    a.stats = d_stats;
+    v.f = make_feat(h->prm);
+    v.forest = ForestDev{h->d_nodes.as<uint2>(), h->d_roots.as<uint32_t>(), h->flat.ntrees};
+    v.nd = nd;
+    v.score_sorted = h->score_sorted.as<float>();
+    v.scores = d_scores;
+    v.flags = h->flags.as<int>();
+    v.prefix = h->prefix.as<int>();
+    v.cand = NmsList{h->cand_list.as<int>(), h->cand_count.as<int>()};
+    v.rowtab = h->rowtab.as<uint2>();
+    v.draw_list = h->draw_list.as<int>();
+    v.draw_count = h->draw_count.as<int>();
+    v.skip = h->skip.as<int>();
+    v.kp_idx = d_kp_idx;
+    v.kp_cap = kp_cap;
+    v.kp_count = d_kp_count;
+    v.stats = d_stats;
     return KPL_OK;
 }
 
-int finish_detect(kpl_detector *h, const ScoreArgs &a, int *d_kp_idx, int kp_cap, int *d_kp_count, hipStream_t st) {
-    const int n = a.n;
-    launch_nms(a.pts, a.cell_start, a.ds, a.nd, a.score_sorted, a.cand, n, a.flags, a.stats, st);
-    int *skip = nullptr;
-    if (a.nd.draws_remove) {
-        skip = h->skip.as<int>();
-        launch_draws(a.pts, a.cell_start, h->pos_of.as<int>(), a.ds, a.nd, a.score_sorted, n, a.flags,
-                     h->prefix.as<int>(), h->scan_tmp.as<int>(), h->draw_list.as<int>(), h->draw_count.as<int>(), skip, st);
+// compute() / detectKeypoints of `count` views: one stream, three stages, every kernel launched
+// once for the whole batch.  rebuild = always rebuild the index (compute), else only if stale.
+int run_batch(kpl_detector *const *handles, int count, float *const *d_scores, int *const *d_kp_idx,
+              const int *kp_caps, int *const *d_kp_counts, StatsDev *d_stats, bool rebuild, hipStream_t st) {
+    kpl_detector *h0 = handles[0];
+    Batch all{}, idx{};
+    for (int k = 0; k < count; ++k) {
+        kpl_detector *h = handles[k];
+        int rc = check_params_for_compute(h, true);
+        if (!rc) rc = prepare_index(h, false, all.view[k]);      // allocates the view's tables ...
+        if (!rc) rc = prepare_detect(h, d_scores ? d_scores[k] : nullptr, d_kp_idx[k], kp_caps[k], d_kp_counts[k],
+                                     d_stats, all.view[k]);      // ... and its scratch
+        if (rc) {
+            if (h != h0) fail(h0, rc, "view %d: %s", k, kpl_last_error(h));
+            return rc;
+        }
+        if (rebuild || !index_is_current(h)) idx.view[idx.nviews++] = all.view[k];
     }
-    launch_exclusive_scan(a.flags, h->prefix.as<int>(), nullptr, nullptr, n, h->scan_tmp.as<int>(), false, -1, st);
-    launch_compact(a.ds, a.flags, h->prefix.as<int>(), n, d_kp_idx, kp_cap, d_kp_count, a.cand.count, skip, st);
-    KPL_HIP(h, hipGetLastError());
+    all.nviews = count;
+    const size_t ev0 = mark(h0, st);
+    if (idx.nviews) launch_index(idx, st);
+    const size_t ev1 = mark(h0, st);
+    launch_score(all, st);
+    const size_t ev2 = mark(h0, st);
+    launch_post(all, st);
+    const size_t ev3 = mark(h0, st);
+    if (idx.nviews) span(h0, 0, ev0, ev1);
+    span(h0, 1, ev1, ev2);
+    span(h0, 2, ev2, ev3);
+    KPL_HIP(h0, hipGetLastError());
+    for (int k = 0; k < count; ++k) index_was_built(handles[k], false);
     return KPL_OK;
 }
 
 int detect_on_device(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, int *d_kp_count,
-                     hipStream_t st, StatsDev *d_stats) {
-    ScoreArgs a;
-    int rc = check_params_for_compute(h, true);
-    if (rc) return rc;
-    rc = ensure_index(h, st);               // before prepare_detect: it may (re)allocate what `a` points at
-    if (rc) return rc;
-    rc = prepare_detect(h, d_scores, d_kp_idx, kp_cap, d_kp_count, d_stats, a);
-    if (rc) return rc;
-    const size_t ev1 = mark(h, st);
-    launch_score(a, st);
-    const size_t ev2 = mark(h, st);
-    span(h, 1, ev1, ev2);
-    rc = finish_detect(h, a, d_kp_idx, kp_cap, d_kp_count, st);
-    span(h, 2, ev2, mark(h, st));
-    return rc;
+                     hipStream_t st, StatsDev *d_stats, bool rebuild = false) {
+    return run_batch(&h, 1, &d_scores, &d_kp_idx, &kp_cap, &d_kp_count, d_stats, rebuild, st);
 }
 
 int upload_view(kpl_detector *h, const void *xyz, size_t xs, const void *nrm, size_t ns, int n) {
@@ -452,11 +479,6 @@ void kpl_destroy(kpl_detector *h) {
                       &h->draw_list, &h->draw_count, &h->skip, &h->rowtab};
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
-    if (h->ev_index) (void)hipEventDestroy(h->ev_index);
-    if (h->ev_done) (void)hipEventDestroy(h->ev_done);
-    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-    if (h->ev_score) (void)hipEventDestroy(h->ev_score);
-    if (h->aux) (void)hipStreamDestroy(h->aux);
     if (h->h_state) (void)hipHostFree(h->h_state);
     if (h->h_count) (void)hipHostFree(h->h_count);
     delete h;
@@ -606,11 +628,7 @@ int kpl_detect_device(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_ca
 
 int kpl_compute_device(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, int *d_kp_count, void *stream) {
     if (!h) return KPL_ERR_INVALID_ARG;
-    int rc = check_params_for_compute(h, true);
-    if (rc) return rc;
-    rc = build_index(h, (hipStream_t)stream);
-    if (rc) return rc;
-    return detect_on_device(h, d_scores, d_kp_idx, kp_cap, d_kp_count, (hipStream_t)stream, nullptr);
+    return detect_on_device(h, d_scores, d_kp_idx, kp_cap, d_kp_count, (hipStream_t)stream, nullptr, true);
 }
 
 int kpl_compute_batch_device(kpl_detector *const *handles, int count, float *const *d_scores, int *const *d_kp_idx,
@@ -620,58 +638,15 @@ int kpl_compute_batch_device(kpl_detector *const *handles, int count, float *con
         if (!handles[k]) return KPL_ERR_INVALID_ARG;
     kpl_detector *h0 = handles[0];
     if (count > kMaxBatch) return fail(h0, KPL_ERR_INVALID_ARG, "at most %d views per batch", kMaxBatch);
-    hipStream_t st = (hipStream_t)stream;
-    ScoreArgs args[kMaxBatch];
     int rc = use_device(h0);
     if (rc) return rc;
-    // fork: every view builds its index on its own stream, after whatever `stream` holds already
     for (int k = 0; k < count; ++k) {
         kpl_detector *h = handles[k];
         if (h->device != h0->device) return fail(h0, KPL_ERR_INVALID_ARG, "all views of a batch must live on one device");
         for (int j = 0; j < k; ++j)
             if (handles[j] == h) return fail(h0, KPL_ERR_INVALID_ARG, "a handle appears twice in the batch");
-        if (!h->aux) {
-            KPL_HIP(h, hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
-            KPL_HIP(h, hipEventCreateWithFlags(&h->ev_index, hipEventDisableTiming));
-            KPL_HIP(h, hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
-            KPL_HIP(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-            KPL_HIP(h, hipEventCreateWithFlags(&h->ev_score, hipEventDisableTiming));
-        }
-        rc = check_params_for_compute(h, true);
-        if (rc) {
-            if (h != h0) fail(h0, rc, "view %d: %s", k, kpl_last_error(h));
-            return rc;
-        }
     }
-    KPL_HIP(h0, hipEventRecord(h0->ev_fork, st));
-    for (int k = 0; k < count; ++k) {
-        kpl_detector *h = handles[k];
-        KPL_HIP(h, hipStreamWaitEvent(h->aux, h0->ev_fork, 0));
-        rc = build_index(h, h->aux);        // allocates the view's tables: before prepare_detect
-        if (!rc) rc = prepare_detect(h, d_scores ? d_scores[k] : nullptr, d_kp_idx[k], kp_caps[k], d_kp_counts[k], nullptr, args[k]);
-        if (rc) {
-            if (h != h0) fail(h0, rc, "view %d: %s", k, kpl_last_error(h));
-            return rc;
-        }
-        KPL_HIP(h, hipEventRecord(h->ev_index, h->aux));
-        KPL_HIP(h, hipStreamWaitEvent(st, h->ev_index, 0));
-    }
-    // one launch scores every view of the batch
-    const size_t ev1 = mark(h0, st);
-    launch_score_batch(args, count, st);
-    const size_t ev2 = mark(h0, st);
-    span(h0, 1, ev1, ev2);
-    KPL_HIP(h0, hipEventRecord(h0->ev_score, st));
-    // fork again for NMS + compaction, then join on `stream`
-    for (int k = 0; k < count; ++k) {
-        kpl_detector *h = handles[k];
-        KPL_HIP(h, hipStreamWaitEvent(h->aux, h0->ev_score, 0));
-        rc = finish_detect(h, args[k], d_kp_idx[k], kp_caps[k], d_kp_counts[k], h->aux);
-        if (rc) return rc;
-        KPL_HIP(h, hipEventRecord(h->ev_done, h->aux));
-        KPL_HIP(h, hipStreamWaitEvent(st, h->ev_done, 0));
-    }
-    return KPL_OK;
+    return run_batch(handles, count, d_scores, d_kp_idx, kp_caps, d_kp_counts, nullptr, true, (hipStream_t)stream);
 }
 
 int kpl_compute_features_device(kpl_detector *h, const int *d_indices, int m, float *d_features, void *stream) {

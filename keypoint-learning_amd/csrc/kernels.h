@@ -68,29 +68,43 @@ struct StatsDev {
 
 struct DevState;
 
-// everything the scoring stage needs to know about one view
-struct ScoreArgs {
-    const float4 *pts, *nrm;     // canonical storage order
-    const int *cell_start;
-    const DevState *ds;
+// Everything the kernels need to know about one view.  Every kernel of the pipeline takes a Batch
+// of these and picks its view with blockIdx.y, so a call over k views costs the same ~15 launches
+// as a call over one (the single-view entry points are batches of one).
+struct ViewDev {
+    // input as bound by the caller (byte strides)
+    const char *xyz, *nrmsrc;
+    unsigned xs, ns;
+    int n;
+    // index ("initCompute")
+    DevState *ds;
+    int cells_cap;               // capacity of cnt / cell_start / cursor
+    float cell;                  // cell edge; <= 0: derived from the bounding box (cloud resolution)
+    int *cid;                    // [n] cell of original point i, -1 if not finite
+    int *cnt, *cell_start, *cursor, *tmp_idx, *scan_tmp;
+    float4 *pts, *nrm;           // canonical storage order
+    int *pos_of;
+    // scoring ("runForest")
     FeatDesc f;
     ForestDev forest;
     NmsDesc nd;
-    const int *cid;              // [n] cell of original point i, -1 if not finite
-    int n;
     float *score_sorted;         // [n] out, storage order
     float *scores;               // [n] out, original order (may be null)
-    int *flags;                  // [n] keypoint flags (only written when NMS is off)
-    NmsList cand;                // out: points that passed the threshold
+    int *flags, *prefix;         // [n+1] keypoint flags in original order and their scan
+    NmsList cand;                // points that passed the threshold
     uint2 *rowtab;               // scratch, rowtab_bytes(n)
+    // draws pass + compaction ("detectKeypoints")
+    int *draw_list, *draw_count, *skip;
+    int *kp_idx;
+    int kp_cap;
+    int *kp_count;
     StatsDev *stats;             // null unless counters are collected
 };
 
-constexpr int kMaxBatch = 8;     // views per batched launch (bounded by the kernel argument size)
-struct ScoreBatch {
+constexpr int kMaxBatch = 8;     // views per batched launch (bounded by the 4 KB kernel argument block)
+struct Batch {
     int nviews;
-    int first_chunk[kMaxBatch + 1];
-    ScoreArgs view[kMaxBatch];
+    ViewDev view[kMaxBatch];
 };
 
 // Device-resident state of one handle: the grid descriptor is computed ON the device from the
@@ -105,29 +119,17 @@ struct DevState {
 };
 void init_dev_state(DevState *host_copy);
 
-// ---- index build ("initCompute") ----------------------------------------------------------
-// h <= 0: the cell size is derived from the bounding box and n (cloud resolution)
-void launch_grid_setup(const char *xyz, size_t stride, int n, float h, int cells_cap, DevState *ds,
-                       hipStream_t st);
-void launch_cell_count(const char *xyz, size_t stride, int n, const DevState *ds, int *cid, int *cnt,
-                       hipStream_t st);
-// exclusive scan of in[0..L) into out[0..L], out[L] = total (also into out2 if given), with
-// L = min(*dlen, len) when dlen is given (len = launch-time upper bound); tmp holds >= len/4096+2
-// ints; zero_in clears the input behind the read
-// match < 0 scans the values, match >= 0 scans the predicate (value == match)
-void launch_exclusive_scan(int *in, int *out, int *out2, const int *dlen, int len, int *tmp,
-                           bool zero_in, int match, hipStream_t st);
-void launch_scatter(const int *cid, int n, int *cursor, int *tmp_idx, hipStream_t st);
-void launch_rank_store(const char *xyz, size_t xs, const char *nrm, size_t ns, int n,
-                       const DevState *ds, const int *cid, const int *cell_start, const int *tmp_idx,
-                       float4 *pts, float4 *nrmo, int *pos_of, hipStream_t st);
+// ---- the three stages of compute(), each over every view of the batch ------------------------
+// index build ("initCompute"): needs the input + index fields of ViewDev
+void launch_index(const Batch &b, hipStream_t st);
+// scoring ("runForest"): scores[i] (original order, may be null) and score_sorted[s]; NaN where not
+// scoreable; appends the points that pass the threshold to `cand` (or, without NMS, flags every
+// scoreable point)
+void launch_score(const Batch &b, hipStream_t st);
+// NMS, draws pass, ordered compaction ("detectKeypoints").  flags[] / cand.count / skip[] must be
+// all zero on entry to a detect call; the compaction leaves them zeroed again
+void launch_post(const Batch &b, hipStream_t st);
 
-// ---- scoring ("runForest") ----------------------------------------------------------------
-// scores[i] (original order, may be null) and score_sorted[s]; NaN where not scoreable; appends
-// the points that pass the threshold to `cand` (or, without NMS, flags every scoreable point)
-void launch_score(const ScoreArgs &a, hipStream_t st);
-// the same for up to kMaxBatch independent views in one launch (no counters)
-void launch_score_batch(const ScoreArgs *views, int nviews, hipStream_t st);
 // bytes of row-table scratch the feature code needs for `nqueries` query slots
 size_t rowtab_bytes(int nqueries);
 int score_block_size(int F);
@@ -136,20 +138,8 @@ void launch_features(const float4 *pts, const float4 *nrm, const int *cell_start
                      const int *pos_of, const DevState *ds, FeatDesc f, const int *query, int m, int n,
                      uint2 *rowtab, float *out, hipStream_t st);
 
-// ---- NMS + compaction ("detectKeypoints") -------------------------------------------------
 // cloud resolution: val[n] scratch, out[0] = ordered double sum of the 2nd-NN distances, out[1] = count
 void launch_resolution(const float4 *pts, const int *cell_start, const int *pos_of, const DevState *ds,
                        int n, float *val, double *out, hipStream_t st);
-
-// flags[] must be all zero on entry to a detect call; compact leaves it (and cand.count) zeroed
-void launch_nms(const float4 *pts, const int *cell_start, const DevState *ds, NmsDesc nd,
-                const float *score_sorted, NmsList cand, int n, int *flags, StatsDev *stats, hipStream_t st);
-// draws_remove: resolves the flags with value 2 (maxima with equal-score neighbors) to 0 / 1 in
-// ascending index order; skip[] must be zero on entry (compact re-zeroes it)
-void launch_draws(const float4 *pts, const int *cell_start, const int *pos_of, const DevState *ds,
-                  NmsDesc nd, const float *score_sorted, int n, int *flags, int *prefix, int *scan_tmp,
-                  int *list, int *list_count, int *skip, hipStream_t st);
-void launch_compact(const DevState *ds, int *flags, const int *prefix, int n, int *kp_idx, int kp_cap,
-                    int *kp_count, int *cand_count, int *skip, hipStream_t st);
 
 }  // namespace kpl

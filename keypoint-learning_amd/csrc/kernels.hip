@@ -43,9 +43,12 @@ __device__ __forceinline__ const float *point_at(const char *base, size_t stride
 // ---------------------------------------------------------------------------------------------
 // bounding box of the finite points
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bbox_kernel(const char *xyz, size_t stride, int n,
-                                                   DevState *ds) {
-    uint32_t *bbox = ds->bbox;
+__global__ __launch_bounds__(256) void bbox_kernel(Batch b) {
+    const ViewDev &v = b.view[blockIdx.y];
+    const char *xyz = v.xyz;
+    const size_t stride = v.xs;
+    const int n = v.n;
+    uint32_t *bbox = v.ds->bbox;
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float *p = point_at(xyz, stride, i);
@@ -98,8 +101,12 @@ __device__ __forceinline__ float dec_f32_dev(uint32_t u) {
     return __uint_as_float(u);
 }
 
-__global__ void grid_setup_kernel(DevState *ds, float h, int n, int cells_cap) {
+__global__ void grid_setup_kernel(Batch b) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const ViewDev &v = b.view[blockIdx.y];
+    DevState *ds = v.ds;
+    float h = v.cell;
+    const int n = v.n, cells_cap = v.cells_cap;
     GridDesc g;
     const bool any = n > 0 && ds->bbox[0] != 0xffffffffu;
     if (!(h > 0.0f)) {
@@ -153,9 +160,13 @@ __global__ void grid_setup_kernel(DevState *ds, float h, int n, int cells_cap) {
 // ---------------------------------------------------------------------------------------------
 // cell id per point + population count per cell
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void cell_count_kernel(const char *xyz, size_t stride, int n,
-                                                         const DevState *__restrict__ ds, int *cid,
-                                                         int *cnt) {
+__global__ __launch_bounds__(256) void cell_count_kernel(Batch b) {
+    const ViewDev &v = b.view[blockIdx.y];
+    const char *xyz = v.xyz;
+    const size_t stride = v.xs;
+    const int n = v.n;
+    const DevState *ds = v.ds;
+    int *cid = v.cid, *cnt = v.cnt;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const GridDesc g = ds->grid;
@@ -209,12 +220,31 @@ __device__ __forceinline__ int scan_len(const int *dlen, int len) {
     return dlen ? min(*dlen, len) : len;
 }
 
+// one exclusive scan per view of a batch: in[0..L) -> out[0..L], out[L] = total (also into out2 if
+// given), L = min(*dlen, len) when dlen is given (len = launch-time upper bound); tmp holds
+// >= len/4096 + 2 ints
+struct ScanJob {
+    int *in, *out, *out2;
+    const int *dlen;
+    int len;
+    int *tmp;
+};
+struct ScanJobs {
+    ScanJob job[kMaxBatch];
+    int zero_in;   // clear the input behind the read
+    int match;     // < 0: scan the values, >= 0: scan the predicate (value == match)
+};
+
 // match < 0: scan the values themselves; match >= 0: scan the predicate (value == match)
 __device__ __forceinline__ int scan_value(int v, int match) { return match < 0 ? v : (v == match ? 1 : 0); }
 
-__global__ __launch_bounds__(kScanBlock) void scan_sums_kernel(const int *in, const int *dlen, int len,
-                                                               int *sums, int match) {
-    len = scan_len(dlen, len);
+__global__ __launch_bounds__(kScanBlock) void scan_sums_kernel(ScanJobs jobs) {
+    const ScanJob &job = jobs.job[blockIdx.y];
+    const int *in = job.in;
+    int *sums = job.tmp;
+    const int match = jobs.match;
+    const int len = scan_len(job.dlen, job.len);
+    if ((int)blockIdx.x * kScanChunk >= job.len && blockIdx.x > 0) return;   // beyond this view's launch bound
     const int base = blockIdx.x * kScanChunk + threadIdx.x * kScanPerThread;
     int s = 0;
 #pragma unroll
@@ -225,7 +255,10 @@ __global__ __launch_bounds__(kScanBlock) void scan_sums_kernel(const int *in, co
     if (threadIdx.x == 0) sums[blockIdx.x] = tot;
 }
 
-__global__ __launch_bounds__(kScanBlock) void scan_top_kernel(int *sums, int nb) {
+__global__ __launch_bounds__(kScanBlock) void scan_top_kernel(ScanJobs jobs) {
+    const ScanJob &job = jobs.job[blockIdx.y];
+    int *sums = job.tmp;
+    const int nb = job.len > 0 ? (job.len + kScanChunk - 1) / kScanChunk : 1;
     int carry = 0;
     for (int b0 = 0; b0 < nb; b0 += kScanBlock) {
         int i = b0 + threadIdx.x;
@@ -240,11 +273,14 @@ __global__ __launch_bounds__(kScanBlock) void scan_top_kernel(int *sums, int nb)
 
 // out[i] = exclusive prefix, out[len] = total; the same goes to out2 when given; the input is
 // zeroed behind the read when zero_in is set (self-cleaning counters: no memset per call)
-__global__ __launch_bounds__(kScanBlock) void scan_apply_kernel(int *in, int *out, int *out2,
-                                                                const int *dlen, int len,
-                                                                const int *sums, int nb, int zero_in,
-                                                                int match) {
-    len = scan_len(dlen, len);
+__global__ __launch_bounds__(kScanBlock) void scan_apply_kernel(ScanJobs jobs) {
+    const ScanJob &job = jobs.job[blockIdx.y];
+    int *in = job.in, *out = job.out, *out2 = job.out2;
+    const int *sums = job.tmp;
+    const int nb = job.len > 0 ? (job.len + kScanChunk - 1) / kScanChunk : 1;
+    const int zero_in = jobs.zero_in, match = jobs.match;
+    if ((int)blockIdx.x >= nb) return;
+    const int len = scan_len(job.dlen, job.len);
     const int base = blockIdx.x * kScanChunk + threadIdx.x * kScanPerThread;
     int v[kScanPerThread];
     int s = 0;
@@ -274,8 +310,11 @@ __global__ __launch_bounds__(kScanBlock) void scan_apply_kernel(int *in, int *ou
 // counting sort, made deterministic: scatter in arrival order, then rank inside the cell by
 // original index (ascending), and store the point + normal at its canonical position
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void scatter_kernel(const int *cid, int n, int *cursor,
-                                                      int *tmp_idx) {
+__global__ __launch_bounds__(256) void scatter_kernel(Batch b) {
+    const ViewDev &v = b.view[blockIdx.y];
+    const int *cid = v.cid;
+    const int n = v.n;
+    int *cursor = v.cursor, *tmp_idx = v.tmp_idx;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int c = cid[i];
@@ -284,14 +323,16 @@ __global__ __launch_bounds__(256) void scatter_kernel(const int *cid, int n, int
     tmp_idx[slot] = i;
 }
 
-__global__ __launch_bounds__(256) void rank_store_kernel(const char *xyz, size_t xs,
-                                                         const char *nrm, size_t ns, int n,
-                                                         const DevState *__restrict__ ds,
-                                                         const int *cid, const int *cell_start,
-                                                         const int *tmp_idx, float4 *pts, float4 *nrmo,
-                                                         int *pos_of) {
+__global__ __launch_bounds__(256) void rank_store_kernel(Batch b) {
+    const ViewDev &v = b.view[blockIdx.y];
+    const char *xyz = v.xyz, *nrm = v.nrmsrc;
+    const size_t xs = v.xs, ns = v.ns;
+    const int n = v.n;
+    const int *cid = v.cid, *cell_start = v.cell_start, *tmp_idx = v.tmp_idx;
+    float4 *pts = v.pts, *nrmo = v.nrm;
+    int *pos_of = v.pos_of;
     int s = blockIdx.x * blockDim.x + threadIdx.x;
-    const GridDesc g = ds->grid;
+    const GridDesc g = v.ds->grid;
     if (s < n && cid[s] < 0) pos_of[s] = -1;   // non-finite original point s
     const int nfinite = cell_start[g.ncells];
     if (s >= nfinite) return;
@@ -682,7 +723,7 @@ __device__ __forceinline__ float forest_sum(const ForestDev &forest, const float
 
 // One wave of the scoring stage: 64 consecutive storage positions of the view described by `a`.
 template <bool STATS>
-__device__ __forceinline__ void score_wave(const ScoreArgs &a, int chunk, float *H) {
+__device__ __forceinline__ void score_wave(const ViewDev &a, int chunk, float *H) {
     const float4 *__restrict__ pts = a.pts;
     const float4 *__restrict__ nrm = a.nrm;
     const int *__restrict__ cell_start = a.cell_start;
@@ -736,20 +777,14 @@ __device__ __forceinline__ void score_wave(const ScoreArgs &a, int chunk, float 
     }
 }
 
+// Several independent views per launch (blockIdx.y = view): 200 k points are only ~3 waves per
+// SIMD, too few to hide the latencies of this kernel; a batch of views fills the chip.
 template <bool STATS>
-__global__ __launch_bounds__(kLanes) void score_kernel(ScoreArgs a) {
+__global__ __launch_bounds__(kLanes) void score_kernel(Batch b) {
     extern __shared__ float H[];
-    score_wave<STATS>(a, blockIdx.x, H);
-}
-
-// Several independent views in ONE launch: 200 k points are only ~3 waves per SIMD, too few to
-// hide the latencies of this kernel; a batch of views fills the chip.  Workgroup b belongs to
-// the view v with first_chunk[v] <= b < first_chunk[v + 1].
-__global__ __launch_bounds__(kLanes) void score_batch_kernel(ScoreBatch batch) {
-    extern __shared__ float H[];
-    int v = 0;
-    while (v + 1 < batch.nviews && (int)blockIdx.x >= batch.first_chunk[v + 1]) ++v;
-    score_wave<false>(batch.view[v], blockIdx.x - batch.first_chunk[v], H);
+    const ViewDev &v = b.view[blockIdx.y];
+    if ((int)blockIdx.x * kLanes >= v.n) return;
+    score_wave<STATS>(v, blockIdx.x, H);
 }
 
 // computePointsForTrainingFeatures, hpp:299-318: same feature code, sparse query list.
@@ -786,14 +821,19 @@ __global__ __launch_bounds__(kLanes) void features_kernel(const float4 *__restri
 // first greater neighbor; groups stride over the candidate list.
 constexpr int kNmsGroup = 16;
 
-template <bool STATS, bool DRAWS>
-__global__ __launch_bounds__(256) void nms_kernel(const float4 *__restrict__ pts,
-                                                  const int *__restrict__ cell_start,
-                                                  const DevState *__restrict__ ds, NmsDesc nd,
-                                                  const float *__restrict__ score_sorted,
-                                                  NmsList cand, int *__restrict__ flags,
-                                                  StatsDev *stats) {
-    const GridDesc g = ds->grid;
+template <bool STATS>
+__global__ __launch_bounds__(256) void nms_kernel(Batch b) {
+    const ViewDev &v = b.view[blockIdx.y];
+    const float4 *__restrict__ pts = v.pts;
+    const int *__restrict__ cell_start = v.cell_start;
+    const NmsDesc nd = v.nd;
+    if (!nd.non_maxima) return;
+    const float *__restrict__ score_sorted = v.score_sorted;
+    const NmsList cand = v.cand;
+    int *__restrict__ flags = v.flags;
+    StatsDev *stats = v.stats;
+    const bool DRAWS = nd.draws_remove != 0;
+    const GridDesc g = v.ds->grid;
     const int ncand = *cand.count;
     const int lane = threadIdx.x & (kNmsGroup - 1);
     const int group_in_wave = (threadIdx.x & 63) / kNmsGroup;
@@ -846,14 +886,18 @@ __global__ __launch_bounds__(256) void nms_kernel(const float4 *__restrict__ pts
 // One wave walks the (ordered) list; the 64 lanes sweep the neighborhood of the current point.
 // A point survives iff it is not in the skip list and some draw lies within draws_threshold;
 // every such draw goes on the skip list (a flag per point instead of std::find, same meaning).
-__global__ __launch_bounds__(64) void draws_kernel(const float4 *__restrict__ pts,
-                                                   const int *__restrict__ cell_start,
-                                                   const int *__restrict__ pos_of,
-                                                   const DevState *__restrict__ ds, NmsDesc nd,
-                                                   const float *__restrict__ score_sorted,
-                                                   const int *__restrict__ list, const int *list_count,
-                                                   int *skip, int *flags) {
-    const GridDesc g = ds->grid;
+__global__ __launch_bounds__(64) void draws_kernel(Batch b) {
+    const ViewDev &v = b.view[blockIdx.y];
+    const NmsDesc nd = v.nd;
+    if (!nd.draws_remove) return;
+    const float4 *__restrict__ pts = v.pts;
+    const int *__restrict__ cell_start = v.cell_start;
+    const int *__restrict__ pos_of = v.pos_of;
+    const float *__restrict__ score_sorted = v.score_sorted;
+    const int *__restrict__ list = v.draw_list;
+    const int *list_count = v.draw_count;
+    int *skip = v.skip, *flags = v.flags;
+    const GridDesc g = v.ds->grid;
     const int count = *list_count;
     const int lane = threadIdx.x;
     for (int k = 0; k < count; ++k) {
@@ -969,10 +1013,14 @@ __global__ __launch_bounds__(64) void ordered_sum_kernel(const float *__restrict
 }
 
 // ordered compaction; also leaves flags[] and the candidate counter clean for the next call
-__global__ __launch_bounds__(256) void compact_kernel(const DevState *__restrict__ ds, int *flags,
-                                                      const int *prefix, int n, int *kp_idx,
-                                                      int kp_cap, int *kp_count, int *cand_count,
-                                                      int *skip) {
+__global__ __launch_bounds__(256) void compact_kernel(Batch b) {
+    const ViewDev &v = b.view[blockIdx.y];
+    const DevState *ds = v.ds;
+    int *flags = v.flags;
+    const int *prefix = v.prefix;
+    const int n = v.n, kp_cap = v.kp_cap;
+    int *kp_idx = v.kp_idx, *kp_count = v.kp_count, *cand_count = v.cand.count;
+    int *skip = v.nd.draws_remove ? v.skip : nullptr;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {
         *kp_count = ds->status != 0 ? -1 : prefix[n];   // -1: see kpl_sync_status
@@ -988,8 +1036,12 @@ __global__ __launch_bounds__(256) void compact_kernel(const DevState *__restrict
 }
 
 // list of the points whose flag equals `match`, ascending (prefix = scan of that predicate)
-__global__ __launch_bounds__(256) void list_match_kernel(const int *flags, const int *prefix, int n,
-                                                         int match, int *list, int *count) {
+__global__ __launch_bounds__(256) void list_match_kernel(Batch b, int match) {
+    const ViewDev &v = b.view[blockIdx.y];
+    if (!v.nd.draws_remove) return;
+    const int *flags = v.flags, *prefix = v.prefix;
+    const int n = v.n;
+    int *list = v.draw_list, *count = v.draw_count;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) *count = prefix[n];
     if (i < n && flags[i] == match) list[prefix[i]] = i;
@@ -1010,41 +1062,45 @@ void init_dev_state(DevState *host_copy) {
     }
 }
 
-void launch_grid_setup(const char *xyz, size_t stride, int n, float h, int cells_cap, DevState *ds,
-                       hipStream_t st) {
+static int max_n(const Batch &b) {
+    int m = 0;
+    for (int v = 0; v < b.nviews; ++v) m = b.view[v].n > m ? b.view[v].n : m;
+    return m;
+}
+
+static void run_scan(const ScanJobs &jobs, int nviews, hipStream_t st) {
+    int len = 0;
+    for (int v = 0; v < nviews; ++v) len = jobs.job[v].len > len ? jobs.job[v].len : len;
+    const int nb = len > 0 ? div_up(len, kScanChunk) : 1;
+    scan_sums_kernel<<<dim3(nb, nviews), kScanBlock, 0, st>>>(jobs);
+    scan_top_kernel<<<dim3(1, nviews), kScanBlock, 0, st>>>(jobs);
+    scan_apply_kernel<<<dim3(nb, nviews), kScanBlock, 0, st>>>(jobs);
+}
+
+// Index build ("initCompute") of every view of the batch: bounding box -> grid descriptor (on the
+// device) -> cell ids + counts -> scan -> scatter -> rank/store.  7 launches whatever the batch size.
+void launch_index(const Batch &b, hipStream_t st) {
+    const int nv = b.nviews, n = max_n(b);
+    if (nv <= 0) return;
     if (n > 0) {
         int blocks = div_up(n, 256);
         if (blocks > 512) blocks = 512;
-        bbox_kernel<<<blocks, 256, 0, st>>>(xyz, stride, n, ds);
+        bbox_kernel<<<dim3(blocks, nv), 256, 0, st>>>(b);
     }
-    grid_setup_kernel<<<1, 64, 0, st>>>(ds, h, n, cells_cap);
-}
-
-void launch_cell_count(const char *xyz, size_t stride, int n, const DevState *ds, int *cid, int *cnt,
-                       hipStream_t st) {
-    if (n <= 0) return;
-    cell_count_kernel<<<div_up(n, 256), 256, 0, st>>>(xyz, stride, n, ds, cid, cnt);
-}
-
-void launch_exclusive_scan(int *in, int *out, int *out2, const int *dlen, int len, int *tmp,
-                           bool zero_in, int match, hipStream_t st) {
-    const int nb = len > 0 ? div_up(len, kScanChunk) : 1;
-    scan_sums_kernel<<<nb, kScanBlock, 0, st>>>(in, dlen, len, tmp, match);
-    scan_top_kernel<<<1, kScanBlock, 0, st>>>(tmp, nb);
-    scan_apply_kernel<<<nb, kScanBlock, 0, st>>>(in, out, out2, dlen, len, tmp, nb, zero_in ? 1 : 0, match);
-}
-
-void launch_scatter(const int *cid, int n, int *cursor, int *tmp_idx, hipStream_t st) {
-    if (n <= 0) return;
-    scatter_kernel<<<div_up(n, 256), 256, 0, st>>>(cid, n, cursor, tmp_idx);
-}
-
-void launch_rank_store(const char *xyz, size_t xs, const char *nrm, size_t ns, int n,
-                       const DevState *ds, const int *cid, const int *cell_start, const int *tmp_idx,
-                       float4 *pts, float4 *nrmo, int *pos_of, hipStream_t st) {
-    if (n <= 0) return;
-    rank_store_kernel<<<div_up(n, 256), 256, 0, st>>>(xyz, xs, nrm, ns, n, ds, cid, cell_start,
-                                                      tmp_idx, pts, nrmo, pos_of);
+    grid_setup_kernel<<<dim3(1, nv), 64, 0, st>>>(b);
+    if (n > 0) cell_count_kernel<<<dim3(div_up(n, 256), nv), 256, 0, st>>>(b);
+    ScanJobs jobs;
+    jobs.zero_in = 1;
+    jobs.match = -1;
+    for (int v = 0; v < nv; ++v) {
+        const ViewDev &w = b.view[v];
+        jobs.job[v] = ScanJob{w.cnt, w.cell_start, w.cursor, &w.ds->grid.ncells, w.cells_cap, w.scan_tmp};
+    }
+    run_scan(jobs, nv, st);
+    if (n > 0) {
+        scatter_kernel<<<dim3(div_up(n, 256), nv), 256, 0, st>>>(b);
+        rank_store_kernel<<<dim3(div_up(n, 256), nv), 256, 0, st>>>(b);
+    }
 }
 
 int score_block_size(int F) { (void)F; return kLanes; }
@@ -1053,28 +1109,19 @@ size_t rowtab_bytes(int nqueries) {
     return sizeof(uint2) * (size_t)div_up(nqueries > 0 ? nqueries : 1, kLanes) * kMaxRows * kLanes;
 }
 
-void launch_score(const ScoreArgs &a, hipStream_t st) {
-    if (a.n <= 0) return;
-    const size_t lds = sizeof(float) * (size_t)a.f.F * kLanes;
-    if (a.stats) score_kernel<true><<<div_up(a.n, kLanes), kLanes, lds, st>>>(a);
-    else score_kernel<false><<<div_up(a.n, kLanes), kLanes, lds, st>>>(a);
-}
-
-void launch_score_batch(const ScoreArgs *views, int nviews, hipStream_t st) {
-    ScoreBatch b;
-    b.nviews = 0;
-    int chunks = 0, maxF = 1;
-    for (int v = 0; v < nviews && b.nviews < kMaxBatch; ++v) {
-        if (views[v].n <= 0) continue;
-        b.view[b.nviews] = views[v];
-        b.first_chunk[b.nviews] = chunks;
-        chunks += div_up(views[v].n, kLanes);
-        if (views[v].f.F > maxF) maxF = views[v].f.F;
-        ++b.nviews;
+// scoring ("runForest") of every view of the batch in one launch
+void launch_score(const Batch &b, hipStream_t st) {
+    const int n = max_n(b);
+    if (b.nviews <= 0 || n <= 0) return;
+    int maxF = 1;
+    bool stats = false;
+    for (int v = 0; v < b.nviews; ++v) {
+        maxF = b.view[v].f.F > maxF ? b.view[v].f.F : maxF;
+        stats |= b.view[v].stats != nullptr;
     }
-    b.first_chunk[b.nviews] = chunks;
-    if (chunks == 0) return;
-    score_batch_kernel<<<chunks, kLanes, sizeof(float) * (size_t)maxF * kLanes, st>>>(b);
+    const size_t lds = sizeof(float) * (size_t)maxF * kLanes;
+    if (stats) score_kernel<true><<<dim3(div_up(n, kLanes), b.nviews), kLanes, lds, st>>>(b);
+    else score_kernel<false><<<dim3(div_up(n, kLanes), b.nviews), kLanes, lds, st>>>(b);
 }
 
 void launch_features(const float4 *pts, const float4 *nrm, const int *cell_start,
@@ -1086,39 +1133,47 @@ void launch_features(const float4 *pts, const float4 *nrm, const int *cell_start
                                                             query, m, n, rowtab, out);
 }
 
-void launch_nms(const float4 *pts, const int *cell_start, const DevState *ds, NmsDesc nd,
-                const float *score_sorted, NmsList cand, int n, int *flags, StatsDev *stats, hipStream_t st) {
-    if (n <= 0 || !nd.non_maxima) return;
-    int blocks = div_up(n, 256 / kNmsGroup);        // at most one group per point ...
-    if (blocks > 1024) blocks = 1024;               // ... but a few waves per SIMD are plenty
-    if (nd.draws_remove) {
-        if (stats) nms_kernel<true, true><<<blocks, 256, 0, st>>>(pts, cell_start, ds, nd, score_sorted, cand, flags, stats);
-        else nms_kernel<false, true><<<blocks, 256, 0, st>>>(pts, cell_start, ds, nd, score_sorted, cand, flags, stats);
-    } else {
-        if (stats) nms_kernel<true, false><<<blocks, 256, 0, st>>>(pts, cell_start, ds, nd, score_sorted, cand, flags, stats);
-        else nms_kernel<false, false><<<blocks, 256, 0, st>>>(pts, cell_start, ds, nd, score_sorted, cand, flags, stats);
+// NMS, draws pass (if any view asks for it), flag scan and ordered compaction of every view
+void launch_post(const Batch &b, hipStream_t st) {
+    const int nv = b.nviews, n = max_n(b);
+    if (nv <= 0) return;
+    bool stats = false, draws = false, nms = false;
+    for (int v = 0; v < nv; ++v) {
+        stats |= b.view[v].stats != nullptr;
+        draws |= b.view[v].nd.draws_remove != 0;
+        nms |= b.view[v].nd.non_maxima != 0;
     }
-}
-
-void launch_draws(const float4 *pts, const int *cell_start, const int *pos_of, const DevState *ds,
-                  NmsDesc nd, const float *score_sorted, int n, int *flags, int *prefix, int *scan_tmp,
-                  int *list, int *list_count, int *skip, hipStream_t st) {
-    if (n <= 0) return;
-    launch_exclusive_scan(flags, prefix, nullptr, nullptr, n, scan_tmp, false, 2, st);
-    list_match_kernel<<<div_up(n, 256), 256, 0, st>>>(flags, prefix, n, 2, list, list_count);
-    draws_kernel<<<1, 64, 0, st>>>(pts, cell_start, pos_of, ds, nd, score_sorted, list, list_count, skip, flags);
+    ScanJobs jobs;
+    jobs.zero_in = 0;
+    if (n > 0 && nms) {
+        int blocks = div_up(n, 256 / kNmsGroup);        // at most one group per point ...
+        if (blocks > 1024) blocks = 1024;               // ... but a few waves per SIMD are plenty
+        if (stats) nms_kernel<true><<<dim3(blocks, nv), 256, 0, st>>>(b);
+        else nms_kernel<false><<<dim3(blocks, nv), 256, 0, st>>>(b);
+        if (draws) {
+            jobs.match = 2;
+            for (int v = 0; v < nv; ++v) {
+                const ViewDev &w = b.view[v];
+                jobs.job[v] = ScanJob{w.flags, w.prefix, nullptr, nullptr, w.nd.draws_remove ? w.n : 0, w.scan_tmp};
+            }
+            run_scan(jobs, nv, st);
+            list_match_kernel<<<dim3(div_up(n, 256), nv), 256, 0, st>>>(b, 2);
+            draws_kernel<<<dim3(1, nv), 64, 0, st>>>(b);
+        }
+    }
+    jobs.match = -1;
+    for (int v = 0; v < nv; ++v) {
+        const ViewDev &w = b.view[v];
+        jobs.job[v] = ScanJob{w.flags, w.prefix, nullptr, nullptr, w.n, w.scan_tmp};
+    }
+    run_scan(jobs, nv, st);
+    compact_kernel<<<dim3(div_up(n > 0 ? n : 1, 256), nv), 256, 0, st>>>(b);
 }
 
 void launch_resolution(const float4 *pts, const int *cell_start, const int *pos_of, const DevState *ds,
                        int n, float *val, double *out, hipStream_t st) {
     if (n > 0) second_nn_kernel<<<div_up(n, 256), 256, 0, st>>>(pts, cell_start, pos_of, ds, n, val);
     ordered_sum_kernel<<<1, 64, 0, st>>>(val, n, out);
-}
-
-void launch_compact(const DevState *ds, int *flags, const int *prefix, int n, int *kp_idx, int kp_cap,
-                    int *kp_count, int *cand_count, int *skip, hipStream_t st) {
-    compact_kernel<<<div_up(n > 0 ? n : 1, 256), 256, 0, st>>>(ds, flags, prefix, n, kp_idx, kp_cap, kp_count,
-                                                               cand_count, skip);
 }
 
 }  // namespace kpl

@@ -34,9 +34,15 @@ def main():
                 out[k]["vgpr/agpr/sgpr/lds/scratch/wg/grid"] = meta[k]
     json.dump(out, open(os.path.join(prof, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
     sk = out.get("score_kernel<false>", {})
+    views = 1
+    if len(sys.argv) > 5 and os.path.exists(sys.argv[5]):
+        try:
+            views = int(json.load(open(sys.argv[5]))["config"].get("views_per_launch", 1))
+        except Exception:
+            pass
     if "FETCH_SIZE_KiB_mean" in sk and "WRITE_SIZE_KiB_mean" in sk:
         traffic = (2.0 * sk["FETCH_SIZE_KiB_mean"] + sk["WRITE_SIZE_KiB_mean"]) * 1024.0
-        json.dump({"score_kernel_hbm_bytes_per_launch": int(traffic), "source": tag + "_pmc.json",
+        json.dump({"score_kernel_hbm_bytes_per_launch": int(traffic), "views_per_launch": views, "source": tag + "_pmc.json",
                    "formula": "(2*FETCH_SIZE + WRITE_SIZE) KiB, separate rocprofv3 --pmc passes"},
                   open(os.path.join(prof, "traffic.json"), "w"), indent=1)
     if len(sys.argv) > 5 and os.path.exists(sys.argv[5]):
