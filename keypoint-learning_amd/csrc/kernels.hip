@@ -546,9 +546,10 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
     Cand pre = load_cand(pts, 0, 1);
     int kf = 0;
     bool first_pending = true;   // the first accepted neighbor has not been dropped yet (hpp:336)
-    // the last search step: accept bits not taken yet and the position of its first candidate
-    unsigned m0 = 0u;
-    int tc0 = 0;
+    // search steps with accepted candidates not taken yet, oldest first: (position of the step's
+    // first candidate << 4 | accept bits); 0 = empty.  The search runs up to three steps ahead of
+    // the accumulation, so a step without a hit or a row change does not cost the lane an iteration
+    unsigned f0 = 0u, f1 = 0u, f2 = 0u;
     // two sets of neighbor registers used alternately: while one set is accumulated, the other
     // set's points and normals are on their way (no register copy between iterations, so nothing
     // waits on a load in flight)
@@ -589,10 +590,13 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
         KPL_STAMP(3)                                                                               \
         /* ---- C: take the lowest accepted candidates, request their points and normals ---- */   \
         _Pragma("unroll") for (int k_ = 0; k_ < kTake; ++k_) {                                     \
-            nxt[k_].valid = m0 != 0u;                                                              \
-            const int j_ = nxt[k_].valid ? __ffs((int)m0) - 1 : 0;                                 \
-            m0 &= m0 - (nxt[k_].valid ? 1u : 0u);                                                  \
-            const int t_ = nxt[k_].valid ? tc0 + j_ : 0;                                           \
+            nxt[k_].valid = f0 != 0u;                                                              \
+            const int t_ = nxt[k_].valid ? (int)(f0 >> 4) + __ffs((int)f0) - 1 : 0;                \
+            f0 &= f0 - (nxt[k_].valid ? 1u : 0u);                                                  \
+            const bool pop_ = (f0 & 15u) == 0u; /* step used up: the queue moves up */             \
+            f0 = pop_ ? f1 : f0;                                                                   \
+            f1 = pop_ ? f2 : f1;                                                                   \
+            f2 = pop_ ? 0u : f2;                                                                   \
             nxt[k_].q = ld16(pts, t_);                                                             \
             nxt[k_].n = ld16(nrm, t_);                                                             \
         }                                                                                          \
@@ -616,8 +620,8 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
         }                                                                                          \
         KPL_STAMP(1)                                                                               \
         { /* ---- B ---- */                                                                        \
-            const bool adv = (m0 == 0u) & (t >= t1) & (ri < nrows);   /* move to the next row */      \
-            const bool stp = (m0 == 0u) & (t < t1);                   /* one search step */           \
+            const bool adv = (t >= t1) & (ri < nrows);                /* move to the next row */      \
+            const bool stp = (f2 == 0u) & (t < t1);                   /* one search step */           \
             /* search step on the candidates requested last iteration; strict d2 < r2 */           \
             unsigned m = 0u;                                                                       \
             _Pragma("unroll") for (int j_ = 0; j_ < kStepW; ++j_)                                  \
@@ -627,8 +631,13 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
             const bool drop = first_pending & (m != 0u); /* hpp:336 */                             \
             m &= m - (drop ? 1u : 0u);                                                             \
             first_pending = first_pending & !drop;                                                 \
-            m0 = stp ? m : m0;                                                                     \
-            tc0 = stp ? t : tc0;                                                                   \
+            { /* a step with accepted candidates joins the queue as (position << 4 | accept bits) */ \
+                const unsigned e_ = ((unsigned)t << 4) | m;                                        \
+                const bool push_ = m != 0u, h0_ = f0 == 0u, h1_ = f1 == 0u;                        \
+                f2 = (push_ & !h0_ & !h1_) ? e_ : f2;                                              \
+                f1 = (push_ & !h0_ & h1_) ? e_ : f1;                                               \
+                f0 = (push_ & h0_) ? e_ : f0;                                                      \
+            }                                                                                      \
             /* row change: nr was requested at least one iteration ago */                          \
             t = adv ? (int)nr.x : (stp ? t + kStepW : t);                                          \
             t1 = adv ? (int)nr.y : t1;                                                             \
@@ -645,7 +654,7 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
 #endif
         KPL_FEATURE_ITERATION(pa, pb)
         KPL_FEATURE_ITERATION(pb, pa)
-        busy = (ri < nrows) | (t < t1) | (m0 != 0u);
+        busy = (ri < nrows) | (t < t1) | (f0 != 0u);
 #pragma unroll
         for (int k = 0; k < kTake; ++k) busy |= pa[k].valid | pb[k].valid;
     } while (__any(busy));
