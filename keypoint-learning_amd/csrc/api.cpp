@@ -66,10 +66,10 @@ struct kpl_detector {
     double index_radius = 0.0;
 
     DevBuf stage_xyz, stage_nrm, stage_idx, stage_feat;
-    DevBuf dstate, cid, cnt, cell_start, cursor, tmp_idx, scan_tmp, pts, nrm, pos_of;
+    DevBuf dstate, cid, cnt, cell_start, tmp_idx, scan_tmp, pts, nrm, pos_of;
     DevBuf score_sorted, flags, prefix, stats, out_scores, out_kp, out_count, cand_list, cand_count;
     DevBuf draw_list, draw_count, skip, rowtab;
-    int cells_cap = 0;            // capacity (cells) of cnt / cell_start / cursor
+    int cells_cap = 0;            // capacity (cells) of cnt / cell_start
     DevState *h_state = nullptr;  // pinned copy of the device state (status read-back)
     int *h_count = nullptr;       // pinned
 
@@ -198,7 +198,6 @@ int ensure_cells(kpl_detector *h, int64_t cap) {
     KPL_HIP(h, hipDeviceSynchronize());
     KPL_HIP(h, h->cnt.ensure(sizeof(int) * ((size_t)cap + 2)));
     KPL_HIP(h, h->cell_start.ensure(sizeof(int) * ((size_t)cap + 2)));
-    KPL_HIP(h, h->cursor.ensure(sizeof(int) * ((size_t)cap + 2)));
     KPL_HIP(h, hipMemset(h->cnt.p, 0, sizeof(int) * ((size_t)cap + 2)));
     KPL_HIP(h, hipMemset(h->cell_start.p, 0, sizeof(int) * ((size_t)cap + 2)));
     h->cells_cap = (int)cap;
@@ -240,7 +239,6 @@ int prepare_index(kpl_detector *h, bool auto_cell, ViewDev &v) {
     v.cid = h->cid.as<int>();
     v.cnt = h->cnt.as<int>();
     v.cell_start = h->cell_start.as<int>();
-    v.cursor = h->cursor.as<int>();
     v.tmp_idx = h->tmp_idx.as<int>();
     v.scan_tmp = h->scan_tmp.as<int>();
     v.pts = h->pts.as<float4>();
@@ -473,7 +471,7 @@ void kpl_destroy(kpl_detector *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     DevBuf *bufs[] = {&h->d_nodes, &h->d_roots, &h->stage_xyz, &h->stage_nrm, &h->stage_idx, &h->stage_feat,
-                      &h->dstate, &h->cid, &h->cnt, &h->cell_start, &h->cursor, &h->tmp_idx, &h->scan_tmp,
+                      &h->dstate, &h->cid, &h->cnt, &h->cell_start, &h->tmp_idx, &h->scan_tmp,
                       &h->pts, &h->nrm, &h->pos_of, &h->score_sorted, &h->flags, &h->prefix, &h->stats,
                       &h->out_scores, &h->out_kp, &h->out_count, &h->cand_list, &h->cand_count,
                       &h->draw_list, &h->draw_count, &h->skip, &h->rowtab};

@@ -78,10 +78,10 @@ struct ViewDev {
     int n;
     // index ("initCompute")
     DevState *ds;
-    int cells_cap;               // capacity of cnt / cell_start / cursor
+    int cells_cap;               // capacity of cnt / cell_start
     float cell;                  // cell edge; <= 0: derived from the bounding box (cloud resolution)
     int *cid;                    // [n] cell of original point i, -1 if not finite
-    int *cnt, *cell_start, *cursor, *tmp_idx, *scan_tmp;
+    int *cnt, *cell_start, *tmp_idx, *scan_tmp;
     float4 *pts, *nrm;           // canonical storage order
     int *pos_of;
     // scoring ("runForest")

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void cell_count_kernel(Batch b) {
     const size_t stride = v.xs;
     const int n = v.n;
     const DevState *ds = v.ds;
-    int *cid = v.cid, *cnt = v.cnt;
+    int *cid = v.cid, *cnt = v.cnt, *arrival = v.pos_of;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const GridDesc g = ds->grid;
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void cell_count_kernel(Batch b) {
         int cy = cell_coord(y, g.mn[1], g.h, g.dims[1]);
         int cz = cell_coord(z, g.mn[2], g.h, g.dims[2]);
         c = (cz * g.dims[1] + cy) * g.dims[0] + cx;
-        atomicAdd(&cnt[c], 1);
+        arrival[i] = atomicAdd(&cnt[c], 1);   // the ONE atomic per point of the index build
     }
     cid[i] = c;
 }
@@ -312,15 +312,14 @@ __global__ __launch_bounds__(kScanBlock) void scan_apply_kernel(ScanJobs jobs) {
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void scatter_kernel(Batch b) {
     const ViewDev &v = b.view[blockIdx.y];
-    const int *cid = v.cid;
+    const int *cid = v.cid, *cell_start = v.cell_start, *arrival = v.pos_of;
     const int n = v.n;
-    int *cursor = v.cursor, *tmp_idx = v.tmp_idx;
+    int *tmp_idx = v.tmp_idx;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int c = cid[i];
     if (c < 0) return;
-    int slot = atomicAdd(&cursor[c], 1);
-    tmp_idx[slot] = i;
+    tmp_idx[cell_start[c] + arrival[i]] = i;
 }
 
 __global__ __launch_bounds__(256) void rank_store_kernel(Batch b) {
@@ -1103,7 +1102,7 @@ void launch_index(const Batch &b, hipStream_t st) {
     jobs.match = -1;
     for (int v = 0; v < nv; ++v) {
         const ViewDev &w = b.view[v];
-        jobs.job[v] = ScanJob{w.cnt, w.cell_start, w.cursor, &w.ds->grid.ncells, w.cells_cap, w.scan_tmp};
+        jobs.job[v] = ScanJob{w.cnt, w.cell_start, nullptr, &w.ds->grid.ncells, w.cells_cap, w.scan_tmp};
     }
     run_scan(jobs, nv, st);
     if (n > 0) {
