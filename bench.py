@@ -5,8 +5,9 @@ Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver 
 torch.distributed.run (one rank per GPU, RCCL).  One "step" = one pass of the hot path
 (pcl::Keypoint::compute = index build + feature + forest + NMS + keypoint compaction) over one
 BATCH of independent synthetic views that are already resident in HBM.  A single 200 k-point view
-is only ~3 waves per SIMD of an MI355X, so the engine scores a batch of views in one launch
-(kpl_compute_batch_device; default 4 views per step, `--batch 1` = one view per step).  Views are
+is only ~3 waves per SIMD of an MI355X, so the engine runs every kernel of the pipeline once per
+batch of views (kpl_compute_batch_device; default 8 views per step, `--batch 1` = one view per
+step) and the bench keeps two batches in flight on two HIP streams (`--groups`).  Views are
 independent, so ranks never exchange data on the data path; with N > 1 every step ends with one
 RCCL all-gather of the packed keypoint lists -- the only exchange the path has -- and scaling is
 weak (every GPU gets its own batch).
@@ -66,8 +67,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=1, help="independent views per step and GPU (1..8)")
-    ap.add_argument("--groups", type=int, default=4,
+    ap.add_argument("--batch", type=int, default=8, help="independent views per step and GPU (1..8)")
+    ap.add_argument("--groups", type=int, default=2,
                     help="batches in flight: step i runs on HIP stream i %% groups with its own handles and views, so "
                          "that the index build / NMS of one batch overlap the scoring launch of the other")
     ap.add_argument("--nx", type=int, default=500)
@@ -236,6 +237,15 @@ def main():
         mine = lists[rank * nb]
         assert np.array_equal(mine.numpy(), d_kp[g_last * nb][:len(mine)].cpu().numpy())
 
+    # the dominant kernel alone on the GPU: the same batch, one batch in flight
+    torch.cuda.synchronize()
+    dets[0].enableTiming(True)
+    for _ in range(20):
+        run_group(0)
+        torch.cuda.synchronize()
+    t_iso = dets[0].getTiming()
+    dets[0].enableTiming(False)
+
     # single view, single stream (latency mode): compute() and detect-only (index prebuilt)
     torch.cuda.synchronize()
     reps = max(20, args.steps // 4)
@@ -266,6 +276,7 @@ def main():
         b_alg_score += 24 * (st["n_scored"] + st["sum_kf"]) + 8 * st["sum_depth"] + 4 * st["n_scored"]
     score_ms = timing["score_ms"] / max(timing["calls"], 1)
     achieved = b_alg_score / (score_ms * 1e-3) if score_ms > 0 else 0.0
+    iso_ms = max(t_iso["score_ms"] / max(t_iso["calls"], 1), 1e-9)
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
@@ -322,7 +333,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 5), "traffic": traffic,
                          "kernel": "%s (feature + forest, %d view(s) per launch)" % (kernel, nb),
-                         "kernel_ms": round(score_ms, 5), "alg_bytes_per_launch": int(b_alg_score)},
+                         "kernel_ms": round(score_ms, 5), "alg_bytes_per_launch": int(b_alg_score),
+                         "alone_on_gpu": {"kernel_ms": round(iso_ms, 5),
+                                          "frac": round(b_alg_score / (iso_ms * 1e-3) / HBM_PEAK, 5)}},
             "cpu_baseline": cpu,
             "phases_ms": {k: round(timing[k] / max(timing["calls"], 1), 5) for k in ("index_ms", "score_ms", "nms_ms")},
             "single_view": {"compute_ms": round(single_ms, 5), "Mpoints_per_s": round(n / single_ms / 1e3, 2),

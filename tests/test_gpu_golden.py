@@ -207,3 +207,54 @@ def test_batched_compute_equals_single_views(kpl, oracle, cases):
     with pytest.raises(kpl.KplError):
         kpl.compute_batch_device([dets[0], dets[0]], None, [bufs[0][3][1:].data_ptr()] * 2, [4, 4],
                                  [bufs[0][3][0:1].data_ptr()] * 2, None)
+
+
+def test_batched_mixed_modes_and_shapes(kpl, oracle, cases):
+    """A full batch of 8 views that differ in everything a view descriptor carries: size (one view
+    is empty, one has 3 points), A x B and forest, NMS on/off, draws_remove on/off."""
+    import torch
+    from tools import forest_yaml, synth
+    fa30 = forest_yaml.load_forest(CFG_FOREST)
+    dev = torch.device("cuda", 0)
+    specs = [  # nx, ny, A, B, thr, non_maxima, draws_remove
+        (60, 50, 5, 6, 0.85, True, False), (0, 0, 5, 6, 0.85, True, False), (40, 45, 4, 3, 0.2, True, True),
+        (3, 1, 5, 6, 0.0, True, False), (50, 40, 5, 6, 0.5, False, False), (64, 33, 2, 2, 0.0, True, True),
+        (45, 45, 4, 3, 0.6, True, False), (70, 20, 5, 6, 0.85, True, True)]
+    forests = {(5, 6): fa30}
+    views, dets, bufs = [], [], []
+    for k, (nx, ny, A, B, thr, nms, draws) in enumerate(specs):
+        if nx * ny > 0:
+            xyz, nrm = synth.make_cloud(nx, ny, seed=40 + k, nan_points=k % 3, nan_normals=k % 2)
+            xyz, nrm = synth.shuffle_cloud(xyz, nrm, 1040 + k)
+        else:
+            xyz, nrm = np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32)
+        n = len(xyz)
+        mr = oracle.cloud_resolution(xyz) if n > 8 else 1.0
+        r, rn = float(np.float32(5 * mr)), float(np.float32(3.5 * mr))
+        if (A, B) not in forests:
+            forests[(A, B)] = cases.trained_forest(A=A, B=B, ntrees=7, max_depth=8)
+        fa = forests[(A, B)]
+        det = kpl.KeypointLearningDetector()
+        det.setNAnnulus(A); det.setNBins(B); det.setNonMaxima(nms); det.setNonMaxRadius(rn)
+        det.setNonMaximaDrawsRemove(draws); det.setNonMaximaDrawsThreshold(float(np.float32(2 * mr)))
+        det.setPredictionThreshold(float(np.float32(thr))); det.setRadiusSearch(r)
+        cases.load_arrays(det, fa)
+        dx = torch.from_numpy(np.ascontiguousarray(xyz)).to(dev) if n else torch.zeros(1, 3, device=dev)
+        dn = torch.from_numpy(np.ascontiguousarray(nrm)).to(dev) if n else torch.zeros(1, 3, device=dev)
+        ds = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
+        dk = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+        det.bindCloudDevice(dx.data_ptr(), 12, dn.data_ptr(), 12, n)
+        views.append((xyz, nrm, A, B, r, rn, float(np.float32(thr)), nms, draws, float(np.float32(2 * mr)), fa))
+        dets.append(det)
+        bufs.append((dx, dn, ds, dk))
+    for rep in range(2):
+        kpl.compute_batch_device(dets, [b[2].data_ptr() for b in bufs], [b[3][1:].data_ptr() if len(b[3]) > 1 else None for b in bufs],
+                                 [len(b[3]) - 1 for b in bufs], [b[3][0:1].data_ptr() for b in bufs], None)
+        torch.cuda.synchronize()
+        for (xyz, nrm, A, B, r, rn, thr, nms, draws, dthr, fa), det, (dx, dn, ds, dk) in zip(views, dets, bufs):
+            assert det.syncStatus(None) == kpl.OK
+            n = len(xyz)
+            o_sc, o_kp = oracle.detect(xyz, nrm, A, B, r, rn, thr, cases.oracle_forest(fa), non_maxima=nms,
+                                       draws_remove=draws, draws_threshold=dthr)
+            assert cases.same_bits(ds.cpu().numpy()[:n], o_sc)
+            assert np.array_equal(dk[1:1 + int(dk[0].item())].cpu().numpy(), o_kp)
