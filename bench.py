@@ -75,6 +75,9 @@ def main():
     ap.add_argument("--ny", type=int, default=400)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
+    ap.add_argument("--lean", action="store_true",
+                    help="profiling runs: skip the single-view and alone-on-GPU extras so that every launch of "
+                         "the dominant kernel in the trace is a launch of the timed workload")
     ap.add_argument("--no-parity", action="store_true", help="timing experiments with ablated kernels only")
     args = ap.parse_args()
 
@@ -239,30 +242,32 @@ def main():
 
     # the dominant kernel alone on the GPU: the same batch, one batch in flight
     torch.cuda.synchronize()
-    dets[0].enableTiming(True)
-    for _ in range(20):
-        run_group(0)
-        torch.cuda.synchronize()
-    t_iso = dets[0].getTiming()
-    dets[0].enableTiming(False)
+    t_iso = t_single = None
+    single_ms = detect_only_ms = 0.0
+    if not args.lean:
+        dets[0].enableTiming(True)
+        for _ in range(20):
+            run_group(0)
+            torch.cuda.synchronize()
+        t_iso = dets[0].getTiming()
+        dets[0].enableTiming(False)
 
-    # single view, single stream (latency mode): compute() and detect-only (index prebuilt)
-    torch.cuda.synchronize()
-    reps = max(20, args.steps // 4)
-    ts0 = time.perf_counter()
-    for _ in range(reps):
-        dets[0].computeDevice(p_scores[0], p_kp[0], n, p_cnt[0], stream)
-    torch.cuda.synchronize()
-    single_ms = (time.perf_counter() - ts0) * 1e3 / reps
-    dets[0].buildIndexDevice(stream)
-    dets[0].enableTiming(True)
-    td0 = time.perf_counter()
-    for _ in range(reps):
-        dets[0].detectDevice(p_scores[0], p_kp[0], n, p_cnt[0], stream)
-    torch.cuda.synchronize()
-    detect_only_ms = (time.perf_counter() - td0) * 1e3 / reps
-    t_single = dets[0].getTiming()
-    dets[0].enableTiming(False)
+        # single view, single stream (latency mode): compute() and detect-only (index prebuilt)
+        reps = max(20, args.steps // 4)
+        ts0 = time.perf_counter()
+        for _ in range(reps):
+            dets[0].computeDevice(p_scores[0], p_kp[0], n, p_cnt[0], stream)
+        torch.cuda.synchronize()
+        single_ms = (time.perf_counter() - ts0) * 1e3 / reps
+        dets[0].buildIndexDevice(stream)
+        dets[0].enableTiming(True)
+        td0 = time.perf_counter()
+        for _ in range(reps):
+            dets[0].detectDevice(p_scores[0], p_kp[0], n, p_cnt[0], stream)
+        torch.cuda.synchronize()
+        detect_only_ms = (time.perf_counter() - td0) * 1e3 / reps
+        t_single = dets[0].getTiming()
+        dets[0].enableTiming(False)
 
     # ---- algorithmic bytes from the engine's own counters -------------------------
     b_alg_total = b_alg_score = 0
@@ -276,7 +281,7 @@ def main():
         b_alg_score += 24 * (st["n_scored"] + st["sum_kf"]) + 8 * st["sum_depth"] + 4 * st["n_scored"]
     score_ms = timing["score_ms"] / max(timing["calls"], 1)
     achieved = b_alg_score / (score_ms * 1e-3) if score_ms > 0 else 0.0
-    iso_ms = max(t_iso["score_ms"] / max(t_iso["calls"], 1), 1e-9)
+    iso_ms = max(t_iso["score_ms"] / max(t_iso["calls"], 1), 1e-9) if t_iso else None
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
@@ -335,13 +340,13 @@ def main():
                          "kernel": "%s (feature + forest, %d view(s) per launch)" % (kernel, nb),
                          "kernel_ms": round(score_ms, 5), "alg_bytes_per_launch": int(b_alg_score),
                          "alone_on_gpu": {"kernel_ms": round(iso_ms, 5),
-                                          "frac": round(b_alg_score / (iso_ms * 1e-3) / HBM_PEAK, 5)}},
+                                          "frac": round(b_alg_score / (iso_ms * 1e-3) / HBM_PEAK, 5)} if iso_ms else None},
             "cpu_baseline": cpu,
             "phases_ms": {k: round(timing[k] / max(timing["calls"], 1), 5) for k in ("index_ms", "score_ms", "nms_ms")},
             "single_view": {"compute_ms": round(single_ms, 5), "Mpoints_per_s": round(n / single_ms / 1e3, 2),
                             "detect_only_ms": round(detect_only_ms, 5),
                             "score_kernel_ms": round(t_single["score_ms"] / max(t_single["calls"], 1), 5),
-                            "nms_compact_ms": round(t_single["nms_ms"] / max(t_single["calls"], 1), 5)},
+                            "nms_compact_ms": round(t_single["nms_ms"] / max(t_single["calls"], 1), 5)} if t_single else None,
             "host_enqueue_ms_per_step": round((t_enq - t0) * 1e3 / args.steps, 5),
             "alg_bytes_per_point": round(b_alg_total / max(sum(s["n_scored"] for s in stats), 1), 1),
             "pipeline_alg_GBps": round(b_alg_total / (ms * 1e-3) / 1e9, 2),

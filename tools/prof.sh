@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/${tag}_trace
-timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_trace -- python3 $R/bench.py --steps 50 --warmup 10 "$@" > $R/gpurun_out/${tag}_trace.log 2>&1 < /dev/null
+timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_trace -- python3 $R/bench.py --lean --steps 100 --warmup 10 "$@" > $R/gpurun_out/${tag}_trace.log 2>&1 < /dev/null
 echo "trace rc=$?"
 grep '^{"metric' $R/gpurun_out/${tag}_trace.log | tail -1 > $R/gpurun_out/${tag}_bench.json
 f=$(find $R/gpurun_out/${tag}_trace -name "*kernel_stats.csv" | head -1)
