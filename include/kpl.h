@@ -150,10 +150,9 @@ int kpl_compute_features_device(kpl_detector *h, const int *d_indices, int m,
                                 float *d_features, void *stream);
 /* compute() for a batch of up to 8 independent views (one handle per view, each with its cloud
  * bound, forest loaded and parameters set; all on one device).  A single 200 k-point view is only
- * ~3 waves per SIMD on an MI355X; the batch puts the scoring stage of all its views into ONE
- * launch so that the chip is full, while index build and NMS of the views run concurrently on
- * per-view streams.  Everything is ordered after prior work on `stream`, and work enqueued on
- * `stream` afterwards sees all results.  Arrays are indexed by view; d_scores may be NULL (or hold
+ * ~3 waves per SIMD on an MI355X; every kernel of the pipeline (index build, scoring, NMS,
+ * compaction) is launched ONCE for the whole batch, on `stream`, so the chip is full and the
+ * fixed cost of the ~17 launches is shared by the views.  The call only enqueues.  Arrays are indexed by view; d_scores may be NULL (or hold
  * NULLs).  Results per view are exactly those of kpl_compute_device. */
 int kpl_compute_batch_device(kpl_detector *const *handles, int count, float *const *d_scores,
                              int *const *d_kp_idx, const int *kp_caps, int *const *d_kp_counts,
