@@ -13,8 +13,10 @@
 // Without them a minimal in-repo shim (kpl_pcl_shim.h) and kpl::FeatureMatrix are used.
 //
 // Differences to the reference, all documented in DESIGN.md:
-//   * normals must be given with setNormals (TestDetector does); the reference's fallback normal
-//     estimation inside initCompute (impl/KeypointLearning.hpp:125-148) is outside this engine;
+//   * without setNormals the normals are estimated on the device with the radius search the
+//     reference's initCompute uses (impl/KeypointLearning.hpp:125-148, kpl_estimate_normals);
+//     for ORGANIZED clouds the reference switches to IntegralImageNormalEstimation, which is not
+//     provided: call setNormals for those;
 //   * only radius search with search surface == input is supported (the reference's k-search mode
 //     divides by a zero support, hpp:345; a separate surface mixes index spaces, hpp:332 vs :149);
 //   * points with non-finite xyz or normal get score NaN and keep their input index (the
@@ -24,6 +26,7 @@
 #pragma once
 
 #include <cmath>
+#include <iostream>
 #include <string>
 #include <vector>
 
@@ -168,9 +171,23 @@ protected:
             PCL_ERROR("[pcl::%s::initCompute] only setRadiusSearch(r > 0) is supported\n", this->name_.c_str());
             return false;
         }
-        if (!normals_) {
-            PCL_ERROR("[pcl::%s::initCompute] normals are required (setNormals): normal estimation is outside the accelerated path\n", this->name_.c_str());
-            return false;
+        if (!normals_) {                                                     // hpp:125-148
+            if (this->surface_->isOrganized()) {
+                PCL_ERROR("[pcl::%s::initCompute] organized cloud without normals: IntegralImageNormalEstimation is not provided, call setNormals\n", this->name_.c_str());
+                return false;
+            }
+            std::cout << "Computing normals for KPL" << std::endl;
+            PointCloudNPtr normals(new PointCloudN());
+            const int n = (int)this->surface_->points.size();
+            normals->points.resize((size_t)n);
+            normals->width = (uint32_t)n;
+            normals->height = 1;
+            int rc = kpl_estimate_normals(handle_, n ? &this->surface_->points[0].x : nullptr, sizeof(PointInT), n, 0,
+                                          this->search_radius_, nullptr,
+                                          n ? &normals->points[0].normal_x : nullptr, sizeof(NormalT),
+                                          n ? &normals->points[0].curvature : nullptr, sizeof(NormalT));
+            if (rc != KPL_OK) return report("initCompute", rc);
+            normals_ = normals;
         }
         if (normals_->size() != this->surface_->size()) {                   // hpp:149-153
             PCL_ERROR("[pcl::%s::initCompute] normals given, but the number of normals does not match the number of input points!\n", this->name_.c_str());

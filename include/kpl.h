@@ -185,6 +185,29 @@ int kpl_collect_stats(kpl_detector *h, kpl_stats *out, void *stream);
 int kpl_cloud_resolution(kpl_detector *h, const void *xyz, size_t xyz_stride, int n,
                          double *resolution);
 
+/* pcl::NormalEstimation<PointInT, NormalT> as the reference drives it, on the device:
+ *   k_search > 0 (<= 32): setKSearch(k)          -- /root/reference/src/main_test_detector.cpp:162-169
+ *                                                   (k = 10, default viewpoint (0,0,0), optional flip :172-179
+ *                                                   is the caller's)
+ *   k_search <= 0:        setRadiusSearch(radius) -- the detector's own fallback when no normals
+ *                                                   were given,
+ *                                                   /root/reference/include/impl/KeypointLearning.hpp:125-148
+ * Per point: PCA of the neighborhood (the query included), eigenvector of the smallest eigenvalue,
+ * flipped towards `viewpoint` (NULL = origin); curvature = lambda_min / trace.  Fewer than 3
+ * neighbors or a non-finite point give NaN.  normals_out: 3 floats per point at `normals_stride`
+ * bytes (pcl::Normal: 32); curvature_out (may be NULL): 1 float per point at `curvature_stride`
+ * bytes (pcl::Normal: &normals[0].curvature, 32).  Arithmetic: DESIGN.md section 2 (double
+ * two-pass PCA, cyclic Jacobi) -- PCL's float one-pass covariance and analytic eigen-solver
+ * differ from it by ~1e-4 rad ("parity unpinned", PCL absent). */
+int kpl_estimate_normals(kpl_detector *h, const void *xyz, size_t xyz_stride, int n, int k_search,
+                         double radius_search, const float *viewpoint, void *normals_out,
+                         size_t normals_stride, void *curvature_out, size_t curvature_stride);
+/* the same on the view bound with kpl_bind_cloud_device (whose normals pointer may be the very
+ * buffer that is filled here); asynchronous on `stream`; deferred errors: kpl_sync_status */
+int kpl_estimate_normals_device(kpl_detector *h, int k_search, double radius_search,
+                                const float *viewpoint, void *d_normals, size_t normals_stride,
+                                void *d_curvature, size_t curvature_stride, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

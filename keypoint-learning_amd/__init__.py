@@ -83,6 +83,9 @@ SYMBOLS = {
     "kpl_get_timing": (C.c_int, [_vp, C.POINTER(Timing)]),
     "kpl_collect_stats": (C.c_int, [_vp, C.POINTER(Stats), _vp]),
     "kpl_cloud_resolution": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
+    "kpl_estimate_normals": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, C.c_int, C.c_double, _vp, _vp, C.c_size_t,
+                                       _vp, C.c_size_t]),
+    "kpl_estimate_normals_device": (C.c_int, [_vp, C.c_int, C.c_double, _vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp]),
 }
 
 _lib = None
@@ -96,6 +99,13 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise ImportError("libkpl.so is not built: run `python keypoint-learning_amd/build.py` "
                           "(there is no CPU fallback)")
+    # A process that also uses PyTorch must load torch's bundled HIP runtime BEFORE libkpl pulls in
+    # /opt/rocm's: with the other order torch later reports "No HIP GPUs are available".  Callers of
+    # this binding (tests, bench) hand torch-owned device buffers to libkpl, so torch goes first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
@@ -306,6 +316,23 @@ class KeypointLearningDetector:
         res = C.c_double()
         self._check(self._lib.kpl_cloud_resolution(self._h, xyz.ctypes.data, xs, xyz.shape[0], C.byref(res)))
         return res.value
+
+    def estimateNormals(self, cloud, k=10, radius=0.0, viewpoint=(0.0, 0.0, 0.0)):
+        """pcl::NormalEstimation as TestDetector drives it (k-search 10) or, with k=0, as the detector's own
+        fallback does (radius search).  Returns (normals[n,3], curvature[n])."""
+        xyz, xs = self._rows(cloud)
+        n = xyz.shape[0]
+        vp = np.ascontiguousarray(viewpoint, dtype=np.float32)
+        out = np.empty((max(n, 1), 4), dtype=np.float32)
+        self._check(self._lib.kpl_estimate_normals(self._h, xyz.ctypes.data, xs, n, int(k), float(radius), vp.ctypes.data,
+                                                   out.ctypes.data, 16, out.ctypes.data + 12, 16))
+        return out[:n, :3].copy(), out[:n, 3].copy()
+
+    def estimateNormalsDevice(self, k, radius, viewpoint, d_normals, normals_stride, d_curvature=None,
+                              curvature_stride=0, stream=None):
+        vp = np.ascontiguousarray(viewpoint, dtype=np.float32)
+        self._check(self._lib.kpl_estimate_normals_device(self._h, int(k), float(radius), vp.ctypes.data, d_normals,
+                                                          normals_stride, d_curvature, curvature_stride, stream))
 
     def getKeypointsIndices(self):
         return self.keypoints_indices

@@ -208,8 +208,8 @@ int ensure_cells(kpl_detector *h, int64_t cap) {
 // -> cell ids + counts -> scan -> scatter -> rank/store.  The host does not learn the grid size;
 // a view whose grid does not fit the current cell tables sets DevState::status (kpl_sync_status).
 // prepare_index checks, allocates and fills the index half of the view descriptor.
-int prepare_index(kpl_detector *h, bool auto_cell, ViewDev &v) {
-    int rc = auto_cell ? KPL_OK : check_params_for_compute(h, false);
+int prepare_index(kpl_detector *h, bool auto_cell, ViewDev &v, double cell = 0.0) {
+    int rc = (auto_cell || cell > 0.0) ? KPL_OK : check_params_for_compute(h, false);
     if (rc) return rc;
     if (!h->bound) return fail(h, KPL_ERR_NO_CLOUD, "no cloud bound");
     if (h->n >= (1 << 28)) return fail(h, KPL_ERR_UNSUPPORTED, "more than 2^28 - 1 points per view");
@@ -235,7 +235,7 @@ int prepare_index(kpl_detector *h, bool auto_cell, ViewDev &v) {
     v.n = n;
     v.ds = h->dstate.as<DevState>();
     v.cells_cap = h->cells_cap;
-    v.cell = auto_cell ? 0.0f : (float)h->prm.radius_search;
+    v.cell = auto_cell ? 0.0f : (float)(cell > 0.0 ? cell : h->prm.radius_search);
     v.cid = h->cid.as<int>();
     v.cnt = h->cnt.as<int>();
     v.cell_start = h->cell_start.as<int>();
@@ -378,6 +378,32 @@ int run_batch(kpl_detector *const *handles, int count, float *const *d_scores, i
 int detect_on_device(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, int *d_kp_count,
                      hipStream_t st, StatsDev *d_stats, bool rebuild = false) {
     return run_batch(&h, 1, &d_scores, &d_kp_idx, &kp_cap, &d_kp_count, d_stats, rebuild, st);
+}
+
+// pcl::NormalEstimation on the bound view: index on a grid that suits the search (k-search: cell
+// from the bounding box, radius search: cell = radius), then one thread per point
+int normals_on_device(kpl_detector *h, int k, double radius, const float *viewpoint, void *d_normals, size_t ns,
+                      void *d_curv, size_t cs, hipStream_t st) {
+    if (!h->bound) return fail(h, KPL_ERR_NO_CLOUD, "no cloud bound");
+    if (k > 32) return fail(h, KPL_ERR_UNSUPPORTED, "k_search must be <= 32");
+    if (k <= 0 && (!(radius > 0.0) || !std::isfinite(radius)))
+        return fail(h, KPL_ERR_INVALID_ARG, "either k_search > 0 or radius_search > 0 is needed");
+    if (h->n > 0 && !d_normals) return fail(h, KPL_ERR_INVALID_ARG, "null normals buffer");
+    if (ns < 12 || (ns & 3) || (d_curv && (cs < 4 || (cs & 3))))
+        return fail(h, KPL_ERR_INVALID_ARG, "strides must be multiples of 4 (normals >= 12 bytes)");
+    static const float origin[3] = {0.0f, 0.0f, 0.0f};
+    Batch b{};
+    b.nviews = 1;
+    int rc = prepare_index(h, k > 0, b.view[0], k > 0 ? 0.0 : radius);
+    if (rc) return rc;
+    launch_index(b, st);
+    const ViewDev &v = b.view[0];
+    launch_normals(v.pts, v.cell_start, v.pos_of, v.ds, v.n, k, (float)(radius * radius),
+                   (float)(radius * (1.0 + 1.0 / 1024.0)), viewpoint ? viewpoint : origin, (char *)d_normals, ns,
+                   (char *)d_curv, cs, st);
+    KPL_HIP(h, hipGetLastError());
+    h->index_valid = false;        // the index holds whatever sat at the normal pointer before
+    return KPL_OK;
 }
 
 int upload_view(kpl_detector *h, const void *xyz, size_t xs, const void *nrm, size_t ns, int n) {
@@ -784,6 +810,49 @@ int kpl_collect_stats(kpl_detector *h, kpl_stats *out, void *stream) {
     out->sum_depth = (int64_t)sd.sum_depth;
     out->n_keypoints = h->h_count[0];
     out->n_cells = h->h_state->grid.ncells;
+    return KPL_OK;
+}
+
+int kpl_estimate_normals_device(kpl_detector *h, int k_search, double radius_search, const float *viewpoint,
+                                void *d_normals, size_t normals_stride, void *d_curvature, size_t curvature_stride,
+                                void *stream) {
+    if (!h) return KPL_ERR_INVALID_ARG;
+    int rc = use_device(h);
+    if (rc) return rc;
+    return normals_on_device(h, k_search, radius_search, viewpoint, d_normals, normals_stride, d_curvature,
+                             curvature_stride, (hipStream_t)stream);
+}
+
+int kpl_estimate_normals(kpl_detector *h, const void *xyz, size_t xyz_stride, int n, int k_search, double radius_search,
+                         const float *viewpoint, void *normals_out, size_t normals_stride, void *curvature_out,
+                         size_t curvature_stride) {
+    if (!h) return KPL_ERR_INVALID_ARG;
+    if (n > 0 && !normals_out) return fail(h, KPL_ERR_INVALID_ARG, "null normals buffer");
+    if (normals_stride < 12 || (normals_stride & 3) || (curvature_out && (curvature_stride < 4 || (curvature_stride & 3))))
+        return fail(h, KPL_ERR_INVALID_ARG, "strides must be multiples of 4 (normals >= 12 bytes)");
+    // staged without normals: the index build copies whatever sits at the normal pointer
+    int rc = upload_view(h, xyz, xyz_stride, xyz, xyz_stride, n);
+    if (rc) return rc;
+    h->d_nrm = h->d_xyz;
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    KPL_HIP(h, h->stage_feat.ensure(sizeof(float) * 4 * nn));       // (nx, ny, nz, curvature) per point
+    hipStream_t st = nullptr;
+    for (int attempt = 0;; ++attempt) {
+        rc = normals_on_device(h, k_search, radius_search, viewpoint, h->stage_feat.p, 16,
+                               (char *)h->stage_feat.p + 12, 16, st);
+        if (rc) return rc;
+        rc = sync_status(h, st);
+        if (rc == KPL_ERR_RETRY && attempt == 0) continue;
+        if (rc) return rc;
+        break;
+    }
+    h->bound = false;              // the staged view has no normals: not usable for detection
+    std::vector<float> tmp(4 * nn);
+    KPL_HIP(h, hipMemcpy(tmp.data(), h->stage_feat.p, sizeof(float) * 4 * (size_t)n, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) {
+        memcpy((char *)normals_out + (size_t)i * normals_stride, &tmp[4 * (size_t)i], 12);
+        if (curvature_out) memcpy((char *)curvature_out + (size_t)i * curvature_stride, &tmp[4 * (size_t)i + 3], 4);
+    }
     return KPL_OK;
 }
 

@@ -142,4 +142,11 @@ void launch_features(const float4 *pts, const float4 *nrm, const int *cell_start
 void launch_resolution(const float4 *pts, const int *cell_start, const int *pos_of, const DevState *ds,
                        int n, float *val, double *out, hipStream_t st);
 
+// normals of every point of the indexed view (pcl::NormalEstimation restated, see kernels.hip):
+// k > 0: k-search (k <= 32) on any grid; k <= 0: radius search, r2/rr as in FeatDesc, on the grid
+// whose cell edge is that radius.  Output at byte strides, in original point order.
+void launch_normals(const float4 *pts, const int *cell_start, const int *pos_of, const DevState *ds, int n,
+                    int k, float r2, float rr, const float *viewpoint, char *normals, size_t normals_stride,
+                    char *curvature, size_t curvature_stride, hipStream_t st);
+
 }  // namespace kpl

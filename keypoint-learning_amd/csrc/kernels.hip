@@ -1020,6 +1020,235 @@ __global__ __launch_bounds__(64) void ordered_sum_kernel(const float *__restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Normal estimation: pcl::NormalEstimation as the reference uses it
+// (/root/reference/src/main_test_detector.cpp:162-169 k-search 10, viewpoint (0,0,0);
+// /root/reference/include/impl/KeypointLearning.hpp:125-148 radius search with search_radius_).
+// Arithmetic as fixed in DESIGN.md section 2 (normal estimation): mean and covariance in
+// double, two passes, sequential sums in neighbor order; cyclic Jacobi in double; flip towards the
+// viewpoint.  One thread per ORIGINAL point; output in original order.
+// ---------------------------------------------------------------------------------------------
+struct NormalAcc {
+    double sx, sy, sz;        // pass 1
+    double mx, my, mz;        // mean
+    double c00, c01, c02, c11, c12, c22;   // pass 2
+    int m;
+};
+
+__device__ __forceinline__ void jacobi_smallest(double a[3][3], double v[3], double &lambda, double &trace) {
+    double e[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 24; ++sweep) {
+        const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
+        const double dg = a[0][0] * a[0][0] + a[1][1] * a[1][1] + a[2][2] * a[2][2];
+        if (!(off > 1e-36 * dg)) break;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = p + 1; q < 3; ++q) {
+                const double apq = a[p][q];
+                if (apq != 0.0) {
+                    const double theta = (a[q][q] - a[p][p]) / (2.0 * apq);
+                    double t = 1.0 / (fabs(theta) + sqrt(theta * theta + 1.0));
+                    if (theta < 0.0) t = -t;
+                    const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const double akp = a[k][p], akq = a[k][q];
+                        a[k][p] = c * akp - s * akq;
+                        a[k][q] = s * akp + c * akq;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const double apk = a[p][k], aqk = a[q][k];
+                        a[p][k] = c * apk - s * aqk;
+                        a[q][k] = s * apk + c * aqk;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const double ekp = e[k][p], ekq = e[k][q];
+                        e[k][p] = c * ekp - s * ekq;
+                        e[k][q] = s * ekp + c * ekq;
+                    }
+                }
+            }
+    }
+    const bool m1 = a[1][1] < a[0][0];
+    const double d01 = m1 ? a[1][1] : a[0][0];
+    const bool m2 = a[2][2] < d01;
+    lambda = m2 ? a[2][2] : d01;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v[k] = m2 ? e[k][2] : (m1 ? e[k][1] : e[k][0]);
+    trace = a[0][0] + a[1][1] + a[2][2];
+}
+
+__device__ __forceinline__ void store_normal(const NormalAcc &acc, const float4 &p, float vx, float vy,
+                                             float vz, char *out, size_t out_stride, char *curv,
+                                             size_t curv_stride, int i) {
+    float *o = reinterpret_cast<float *>(out + (size_t)i * out_stride);
+    float *cv = curv ? reinterpret_cast<float *>(curv + (size_t)i * curv_stride) : nullptr;
+    if (acc.m < 3) {
+        o[0] = o[1] = o[2] = NAN;
+        if (cv) *cv = NAN;
+        return;
+    }
+    double a[3][3] = {{acc.c00, acc.c01, acc.c02}, {acc.c01, acc.c11, acc.c12}, {acc.c02, acc.c12, acc.c22}};
+    double v[3], lambda, trace;
+    jacobi_smallest(a, v, lambda, trace);
+    const double dot = v[0] * ((double)vx - (double)p.x) + v[1] * ((double)vy - (double)p.y) +
+                       v[2] * ((double)vz - (double)p.z);
+    if (dot < 0.0) {
+        v[0] = -v[0];
+        v[1] = -v[1];
+        v[2] = -v[2];
+    }
+    o[0] = (float)v[0];
+    o[1] = (float)v[1];
+    o[2] = (float)v[2];
+    if (cv) *cv = trace != 0.0 ? (float)fabs(lambda / trace) : 0.0f;
+}
+
+__device__ __forceinline__ void acc_sum(NormalAcc &a, const float4 &q) {
+    a.sx += (double)q.x;
+    a.sy += (double)q.y;
+    a.sz += (double)q.z;
+    ++a.m;
+}
+__device__ __forceinline__ void acc_mean(NormalAcc &a) {
+    a.mx = a.sx / (double)a.m;
+    a.my = a.sy / (double)a.m;
+    a.mz = a.sz / (double)a.m;
+}
+__device__ __forceinline__ void acc_cov(NormalAcc &a, const float4 &q) {
+    const double dx = (double)q.x - a.mx, dy = (double)q.y - a.my, dz = (double)q.z - a.mz;
+    a.c00 += dx * dx;
+    a.c01 += dx * dy;
+    a.c02 += dx * dz;
+    a.c11 += dy * dy;
+    a.c12 += dy * dz;
+    a.c22 += dz * dz;
+}
+
+struct NormalOut {
+    char *normals;            // 3 floats per point at byte stride
+    size_t normals_stride;
+    char *curvature;          // 1 float per point at byte stride, may be null
+    size_t curvature_stride;
+    float vx, vy, vz;         // viewpoint
+};
+
+// k-search: the KCAP best (d2, index) are kept sorted in registers, the first k of them are used;
+// the searched block of cells grows until the k-th distance is safe (as second_nn_kernel)
+template <int KCAP>
+__global__ __launch_bounds__(128) void knn_normals_kernel(const float4 *__restrict__ pts,
+                                                          const int *__restrict__ cell_start,
+                                                          const int *__restrict__ pos_of,
+                                                          const DevState *__restrict__ ds, int n, int k,
+                                                          NormalOut out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const GridDesc g = ds->grid;
+    const int s = g.ncells > 0 ? pos_of[i] : -1;
+    NormalAcc acc = {};
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (s >= 0) {
+        p = pts[s];
+        const int cx = cell_coord(p.x, g.mn[0], g.h, g.dims[0]);
+        const int cy = cell_coord(p.y, g.mn[1], g.h, g.dims[1]);
+        const int cz = cell_coord(p.z, g.mn[2], g.h, g.dims[2]);
+        const int maxring = max(g.dims[0], max(g.dims[1], g.dims[2]));
+        float bd[KCAP];
+        int bi[KCAP], bt[KCAP];
+        for (int ring = 1; ring <= maxring; ++ring) {
+            const int x0 = max(cx - ring, 0), x1 = min(cx + ring, g.dims[0] - 1);
+            const int y0 = max(cy - ring, 0), y1 = min(cy + ring, g.dims[1] - 1);
+            const int z0 = max(cz - ring, 0), z1 = min(cz + ring, g.dims[2] - 1);
+#pragma unroll
+            for (int u = 0; u < KCAP; ++u) {
+                bd[u] = INFINITY;
+                bi[u] = 0x7fffffff;
+                bt[u] = 0;
+            }
+            for (int z = z0; z <= z1; ++z)
+                for (int y = y0; y <= y1; ++y) {
+                    const int row = (z * g.dims[1] + y) * g.dims[0];
+                    const int t0 = cell_start[row + x0], t1 = cell_start[row + x1 + 1];
+                    for (int t = t0; t < t1; ++t) {
+                        const float4 q = pts[t];
+                        const float d2 = dist2(p.x, p.y, p.z, q);
+                        const int j = __float_as_int(q.w);
+                        if (d2 < bd[KCAP - 1] || (d2 == bd[KCAP - 1] && j < bi[KCAP - 1])) {
+                            bool lt[KCAP];
+#pragma unroll
+                            for (int u = 0; u < KCAP; ++u) lt[u] = d2 < bd[u] || (d2 == bd[u] && j < bi[u]);
+#pragma unroll
+                            for (int u = KCAP - 1; u >= 0; --u) {
+                                const bool here = lt[u] && (u == 0 || !lt[u - 1]);
+                                const float pd = u > 0 ? bd[u - 1] : 0.f;
+                                const int pi = u > 0 ? bi[u - 1] : 0, pt = u > 0 ? bt[u - 1] : 0;
+                                bd[u] = !lt[u] ? bd[u] : (here ? d2 : pd);
+                                bi[u] = !lt[u] ? bi[u] : (here ? j : pi);
+                                bt[u] = !lt[u] ? bt[u] : (here ? t : pt);
+                            }
+                        }
+                    }
+                }
+            float dk = INFINITY;
+#pragma unroll
+            for (int u = 0; u < KCAP; ++u) dk = (u == k - 1) ? bd[u] : dk;
+            // every point outside the block is at least ring*h away (0.999: slack for the float cell edges)
+            if (isfinite(dk) && (double)sqrtf(dk) <= (double)ring * (double)g.h * 0.999) break;
+            if (x0 == 0 && y0 == 0 && z0 == 0 && x1 == g.dims[0] - 1 && y1 == g.dims[1] - 1 && z1 == g.dims[2] - 1) break;
+        }
+#pragma unroll
+        for (int u = 0; u < KCAP; ++u)
+            if (u < k && isfinite(bd[u])) acc_sum(acc, pts[bt[u]]);
+        if (acc.m >= 3) {
+            acc_mean(acc);
+#pragma unroll
+            for (int u = 0; u < KCAP; ++u)
+                if (u < k && isfinite(bd[u])) acc_cov(acc, pts[bt[u]]);
+        }
+    }
+    store_normal(acc, p, out.vx, out.vy, out.vz, out.normals, out.normals_stride, out.curvature,
+                 out.curvature_stride, i);
+}
+
+// radius search on the grid whose cell edge is the radius: neighbors in canonical order
+__global__ __launch_bounds__(128) void radius_normals_kernel(const float4 *__restrict__ pts,
+                                                             const int *__restrict__ cell_start,
+                                                             const int *__restrict__ pos_of,
+                                                             const DevState *__restrict__ ds, int n,
+                                                             float r2, float rr, NormalOut out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const GridDesc g = ds->grid;
+    const int s = g.ncells > 0 ? pos_of[i] : -1;
+    NormalAcc acc = {};
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (s >= 0) {
+        p = pts[s];
+        const CellBox b = make_box(g, p.x, p.y, p.z, rr);
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int z = b.lo[2]; z <= b.hi[2]; ++z)
+                for (int y = b.lo[1]; y <= b.hi[1]; ++y) {
+                    const int row = (z * g.dims[1] + y) * g.dims[0];
+                    const int t0 = cell_start[row + b.lo[0]], t1 = cell_start[row + b.hi[0] + 1];
+                    for (int t = t0; t < t1; ++t) {
+                        const float4 q = pts[t];
+                        if (dist2(p.x, p.y, p.z, q) < r2) {
+                            if (pass == 0) acc_sum(acc, q);
+                            else acc_cov(acc, q);
+                        }
+                    }
+                }
+            if (acc.m < 3) break;
+            if (pass == 0) acc_mean(acc);
+        }
+    }
+    store_normal(acc, p, out.vx, out.vy, out.vz, out.normals, out.normals_stride, out.curvature,
+                 out.curvature_stride, i);
+}
+
 // ordered compaction; also leaves flags[] and the candidate counter clean for the next call
 __global__ __launch_bounds__(256) void compact_kernel(Batch b) {
     const ViewDev &v = b.view[blockIdx.y];
@@ -1182,6 +1411,17 @@ void launch_resolution(const float4 *pts, const int *cell_start, const int *pos_
                        int n, float *val, double *out, hipStream_t st) {
     if (n > 0) second_nn_kernel<<<div_up(n, 256), 256, 0, st>>>(pts, cell_start, pos_of, ds, n, val);
     ordered_sum_kernel<<<1, 64, 0, st>>>(val, n, out);
+}
+
+void launch_normals(const float4 *pts, const int *cell_start, const int *pos_of, const DevState *ds, int n,
+                    int k, float r2, float rr, const float *viewpoint, char *normals, size_t normals_stride,
+                    char *curvature, size_t curvature_stride, hipStream_t st) {
+    if (n <= 0) return;
+    NormalOut out{normals, normals_stride, curvature, curvature_stride, viewpoint[0], viewpoint[1], viewpoint[2]};
+    const int blocks = div_up(n, 128);
+    if (k <= 0) radius_normals_kernel<<<blocks, 128, 0, st>>>(pts, cell_start, pos_of, ds, n, r2, rr, out);
+    else if (k <= 16) knn_normals_kernel<16><<<blocks, 128, 0, st>>>(pts, cell_start, pos_of, ds, n, k, out);
+    else knn_normals_kernel<32><<<blocks, 128, 0, st>>>(pts, cell_start, pos_of, ds, n, k, out);
 }
 
 }  // namespace kpl

@@ -4,9 +4,9 @@
 // annuli / bins (were #defines, :105-106), radiusInMr (radii given in units of the cloud
 // resolution) and json.  No viewer (:191-210 dropped).
 //
-// Everything before detector->compute() is host-side preparation exactly as in the reference
-// main (PCD load :143, UniformSampling :145-157, k = 10 normals :162-169, flip :173-179); it is
-// not part of the accelerated path and is written for clarity, not speed.
+// Preparation as in the reference main: PCD load (:143) and UniformSampling (:145-157) on the
+// host; cloud resolution (for --radiusInMr) and the k = 10 normals (:162-169) on the device
+// through libkpl (kpl_cloud_resolution, kpl_estimate_normals); flip (:173-179) on the host.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -52,10 +52,12 @@ const char *kUsage =
     "  --radiusInMr                  radiusFeatures / radiusNMS / leaf are multiples of the cloud resolution.\n"
     "  --device arg (=0)             HIP device ordinal.\n"
     "  --json                        print one JSON line with counts and timings.\n"
-    "  --printResolution             print the cloud resolution (mean 2nd-NN distance) and exit.\n";
+    "  --printResolution             print the cloud resolution (mean 2nd-NN distance) and exit.\n"
+    "  --detectorNormals             do not pass normals: the detector estimates them itself (radius search\n"
+    "                                with radiusFeatures, as the reference's initCompute does).\n";
 
 bool parse(int argc, char **argv, Options &o) {
-    static const char *flags[] = {"help", "flipNormals", "subSampling", "radiusInMr", "json", "printResolution"};
+    static const char *flags[] = {"help", "flipNormals", "subSampling", "radiusInMr", "json", "printResolution", "detectorNormals"};
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         if (a == "-h") a = "--help";
@@ -153,118 +155,41 @@ bool save_pcd_ascii(const std::string &path, const pcl::PointCloud<KeypointT> &k
 }
 
 // ---- host-side helpers on a hash grid -----------------------------------------------------------
-struct HashGrid {
-    double cell;
-    std::unordered_map<long long, std::vector<int>> cells;
-    // exact key: 21 bits per axis around 0 (cells further out than 2^20 would alias; clouds that large
-    // relative to their resolution are not expected on this host-side helper)
-    static long long key(long long x, long long y, long long z) {
-        const long long m = (1LL << 21) - 1, o = 1LL << 20;
-        return (((x + o) & m) << 42) | (((y + o) & m) << 21) | ((z + o) & m);
+// exact voxel key: 21 bits per axis around 0 (voxels further out than 2^20 would alias; clouds that
+// large relative to the leaf are not expected here)
+long long voxel_key(long long x, long long y, long long z) {
+    const long long m = (1LL << 21) - 1, o = 1LL << 20;
+    return (((x + o) & m) << 42) | (((y + o) & m) << 21) | ((z + o) & m);
+}
+
+// owns a plain libkpl handle for the preparation steps that run on the device
+struct Prep {
+    kpl_detector *h = nullptr;
+    explicit Prep(int device) {
+        if (kpl_create(&h, device) != KPL_OK) { fprintf(stderr, "no HIP device %d\n", device); h = nullptr; }
     }
-    long long c(double v) const { return (long long)std::floor(v / cell); }
-    HashGrid(const pcl::PointCloud<PointInT> &cloud, double cell_) : cell(cell_) {
-        for (int i = 0; i < (int)cloud.size(); ++i)
-            if (pcl::isFinite(cloud[i])) cells[key(c(cloud[i].x), c(cloud[i].y), c(cloud[i].z))].push_back(i);
+    ~Prep() { if (h) kpl_destroy(h); }
+    // computeCloudResolution, /root/reference/include/impl/point_cloud_utilities.hpp:120-151
+    bool resolution(const pcl::PointCloud<PointInT> &cloud, double &mr) const {
+        const int n = (int)cloud.size();
+        int rc = kpl_cloud_resolution(h, n ? &cloud.points[0].x : nullptr, sizeof(PointInT), n, &mr);
+        if (rc != KPL_OK) fprintf(stderr, "cloud resolution: %s\n", kpl_last_error(h));
+        return rc == KPL_OK;
     }
-    // k nearest (squared distance, index), growing the searched block until it is safe
-    void knn(const pcl::PointCloud<PointInT> &cloud, int i, int k, std::vector<std::pair<double, int>> &out) const {
-        const PointInT &p = cloud[i];
-        const long long cx = c(p.x), cy = c(p.y), cz = c(p.z);
-        for (int ring = 1;; ++ring) {
-            out.clear();
-            for (long long z = cz - ring; z <= cz + ring; ++z)
-                for (long long y = cy - ring; y <= cy + ring; ++y)
-                    for (long long x = cx - ring; x <= cx + ring; ++x) {
-                        auto it = cells.find(key(x, y, z));
-                        if (it == cells.end()) continue;
-                        for (int j : it->second) {
-                            const double dx = cloud[j].x - p.x, dy = cloud[j].y - p.y, dz = cloud[j].z - p.z;
-                            out.emplace_back(dx * dx + dy * dy + dz * dz, j);
-                        }
-                    }
-            if ((int)out.size() >= k) {
-                std::partial_sort(out.begin(), out.begin() + k, out.end());
-                if (std::sqrt(out[k - 1].first) <= ring * cell || ring > 64) { out.resize(k); return; }
-            } else if (ring > 64) { std::sort(out.begin(), out.end()); return; }
-        }
+    // pcl::NormalEstimation with setKSearch(10), viewpoint (0,0,0) -- main_test_detector.cpp:162-169
+    bool normals(const pcl::PointCloud<PointInT> &cloud, int k, pcl::PointCloud<PointNormalT> &out) const {
+        const int n = (int)cloud.size();
+        out.clear();
+        out.points.resize((size_t)n);
+        out.width = (uint32_t)n;
+        out.height = 1;
+        int rc = kpl_estimate_normals(h, n ? &cloud.points[0].x : nullptr, sizeof(PointInT), n, k, 0.0, nullptr,
+                                      n ? &out.points[0].normal_x : nullptr, sizeof(PointNormalT),
+                                      n ? &out.points[0].curvature : nullptr, sizeof(PointNormalT));
+        if (rc != KPL_OK) fprintf(stderr, "normal estimation: %s\n", kpl_last_error(h));
+        return rc == KPL_OK;
     }
 };
-
-double bbox_cell_guess(const pcl::PointCloud<PointInT> &cloud) {
-    double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
-    size_t n = 0;
-    for (auto &p : cloud.points) if (pcl::isFinite(p)) { ++n; const double v[3] = {p.x, p.y, p.z}; for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], v[k]); mx[k] = std::max(mx[k], v[k]); } }
-    if (n < 2) return 1.0;
-    double e[3] = {mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]};
-    std::sort(e, e + 3);
-    const double area = e[2] * (e[1] > 0 ? e[1] : e[2]);
-    return area > 0 ? std::sqrt(area / n * 4.0) : 1.0;
-}
-
-// computeCloudResolution, /root/reference/include/impl/point_cloud_utilities.hpp:120-151
-double cloud_resolution(const pcl::PointCloud<PointInT> &cloud, const HashGrid &g) {
-    double res = 0.0;
-    int n = 0;
-    std::vector<std::pair<double, int>> nn;
-    for (int i = 0; i < (int)cloud.size(); ++i) {
-        if (!std::isfinite(cloud[i].x)) continue;
-        g.knn(cloud, i, 2, nn);
-        if (nn.size() == 2) { res += std::sqrt((float)nn[1].first); ++n; }
-    }
-    return n ? res / n : 0.0;
-}
-
-// smallest-eigenvalue eigenvector of a symmetric 3x3 matrix (cyclic Jacobi)
-void smallest_eigenvector(double a[3][3], double v[3]) {
-    double e[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
-    for (int sweep = 0; sweep < 32; ++sweep) {
-        double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
-        if (off < 1e-30) break;
-        for (int p = 0; p < 2; ++p)
-            for (int q = p + 1; q < 3; ++q) {
-                if (std::fabs(a[p][q]) < 1e-300) continue;
-                const double theta = (a[q][q] - a[p][p]) / (2 * a[p][q]);
-                const double t = (theta >= 0 ? 1 : -1) / (std::fabs(theta) + std::sqrt(theta * theta + 1));
-                const double c = 1 / std::sqrt(t * t + 1), s = t * c;
-                for (int k = 0; k < 3; ++k) { const double akp = a[k][p], akq = a[k][q]; a[k][p] = c * akp - s * akq; a[k][q] = s * akp + c * akq; }
-                for (int k = 0; k < 3; ++k) { const double apk = a[p][k], aqk = a[q][k]; a[p][k] = c * apk - s * aqk; a[q][k] = s * apk + c * aqk; }
-                for (int k = 0; k < 3; ++k) { const double ekp = e[k][p], ekq = e[k][q]; e[k][p] = c * ekp - s * ekq; e[k][q] = s * ekp + c * ekq; }
-            }
-    }
-    int m = 0;
-    for (int k = 1; k < 3; ++k) if (a[k][k] < a[m][m]) m = k;
-    for (int k = 0; k < 3; ++k) v[k] = e[k][m];
-}
-
-// pcl::NormalEstimation with setKSearch(10), viewpoint (0,0,0) -- main_test_detector.cpp:162-169
-void estimate_normals(const pcl::PointCloud<PointInT> &cloud, const HashGrid &g, int k, pcl::PointCloud<PointNormalT> &out) {
-    out.clear();
-    out.points.resize(cloud.size());
-    std::vector<std::pair<double, int>> nn;
-    for (int i = 0; i < (int)cloud.size(); ++i) {
-        PointNormalT &n = out.points[i];
-        n.normal_x = n.normal_y = n.normal_z = NAN;
-        if (!pcl::isFinite(cloud[i])) continue;
-        g.knn(cloud, i, k, nn);
-        if (nn.size() < 3) continue;
-        double mean[3] = {0, 0, 0};
-        for (auto &e : nn) { mean[0] += cloud[e.second].x; mean[1] += cloud[e.second].y; mean[2] += cloud[e.second].z; }
-        for (double &m : mean) m /= nn.size();
-        double cov[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-        for (auto &e : nn) {
-            const double d[3] = {cloud[e.second].x - mean[0], cloud[e.second].y - mean[1], cloud[e.second].z - mean[2]};
-            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) cov[r][c] += d[r] * d[c];
-        }
-        double v[3];
-        smallest_eigenvector(cov, v);
-        // flipNormalTowardsViewpoint with the default viewpoint (0, 0, 0)
-        if (v[0] * (0 - cloud[i].x) + v[1] * (0 - cloud[i].y) + v[2] * (0 - cloud[i].z) < 0) { v[0] = -v[0]; v[1] = -v[1]; v[2] = -v[2]; }
-        n.normal_x = (float)v[0]; n.normal_y = (float)v[1]; n.normal_z = (float)v[2];
-    }
-    out.width = (uint32_t)out.points.size();
-    out.height = 1;
-}
 
 // pcl::UniformSampling: one point per leaf-sized voxel, the one closest to the voxel centre
 void uniform_sampling(pcl::PointCloud<PointInT> &cloud, double leaf) {
@@ -275,8 +200,8 @@ void uniform_sampling(pcl::PointCloud<PointInT> &cloud, double leaf) {
         const long long x = (long long)std::floor(p.x / leaf), y = (long long)std::floor(p.y / leaf), z = (long long)std::floor(p.z / leaf);
         const double cx = (x + 0.5) * leaf, cy = (y + 0.5) * leaf, cz = (z + 0.5) * leaf;
         const double d = (p.x - cx) * (p.x - cx) + (p.y - cy) * (p.y - cy) + (p.z - cz) * (p.z - cz);
-        auto it = best.find(HashGrid::key(x, y, z));
-        if (it == best.end() || d < it->second.first) best[HashGrid::key(x, y, z)] = {d, i};
+        auto it = best.find(voxel_key(x, y, z));
+        if (it == best.end() || d < it->second.first) best[voxel_key(x, y, z)] = {d, i};
     }
     std::vector<int> keep;
     for (auto &kv : best) keep.push_back(kv.second.second);
@@ -304,18 +229,21 @@ int main(int argc, char **argv) {
     const int annuli = (int)vm.num("annuli", 5), bins = (int)vm.num("bins", 10);
     const bool json = vm.has("json");
 
-    if (vm.has("printResolution")) {           // host-only helper, no device needed
+    const int device = (int)vm.num("device", 0);
+    Prep prep(device);
+    if (!prep.h) return -1;
+    if (vm.has("printResolution")) {
         pcl::PointCloud<PointInT> c;
         pcl::PointCloud<PointNormalT> nn;
-        if (!load_pcd(path_cloud, c, nn)) return -1;
-        HashGrid g(c, bbox_cell_guess(c));
-        printf("%.17g\n", cloud_resolution(c, g));
+        double mr = 0.0;
+        if (!load_pcd(path_cloud, c, nn) || !prep.resolution(c, mr)) return -1;
+        printf("%.17g\n", mr);
         return 0;
     }
 
     // create detector (:123-130)
     pcl::keypoints::KeypointLearningDetector<PointInT, KeypointT>::Ptr detector(
-        new pcl::keypoints::KeypointLearningDetector<PointInT, KeypointT>(0.5, true, true, 0.0, 5, 10, (int)vm.num("device", 0)));
+        new pcl::keypoints::KeypointLearningDetector<PointInT, KeypointT>(0.5, true, true, 0.0, 5, 10, device));
     detector->setNAnnulus(annuli);
     detector->setNBins(bins);
     detector->setNonMaxima(true);
@@ -332,11 +260,10 @@ int main(int argc, char **argv) {
     pcl::PointCloud<PointNormalT>::Ptr normals(new pcl::PointCloud<PointNormalT>());
     if (!load_pcd(path_cloud, *cloud, *normals)) return -1;
     auto t_prep = std::chrono::steady_clock::now();
-    std::unique_ptr<HashGrid> grid(new HashGrid(*cloud, bbox_cell_guess(*cloud)));
     double mr = 0.0;
     float leaf = (float)vm.num("leaf", 0.0);
     if (vm.has("radiusInMr")) {
-        mr = cloud_resolution(*cloud, *grid);
+        if (!prep.resolution(*cloud, mr)) return -1;
         radius_features = (float)(radius_features * mr);
         radius_nms = (float)(radius_nms * mr);
         leaf = (float)(leaf * mr);
@@ -344,14 +271,14 @@ int main(int argc, char **argv) {
     if (vm.has("subSampling")) {
         uniform_sampling(*cloud, leaf);
         normals->clear();
-        grid.reset(new HashGrid(*cloud, bbox_cell_guess(*cloud)));
     }
     if (!json) printf("Point cloud loaded\n");
 
     // Compute normals (:162-169) unless the file carried them
-    if (normals->size() != cloud->size()) estimate_normals(*cloud, *grid, 10, *normals);
-    if (!json) printf("Normals Computed\n");
-    if (vm.has("flipNormals")) {                                             // :172-179
+    const bool own_normals = vm.has("detectorNormals");
+    if (!own_normals && normals->size() != cloud->size() && !prep.normals(*cloud, 10, *normals)) return -1;
+    if (!json && !own_normals) printf("Normals Computed\n");
+    if (vm.has("flipNormals") && !own_normals) {                                             // :172-179
         if (!json) printf("Flipping \n");
         for (auto &n : normals->points) { n.normal_x *= -1; n.normal_y *= -1; n.normal_z *= -1; }
     }
@@ -360,7 +287,7 @@ int main(int argc, char **argv) {
     detector->setNonMaxRadius(radius_nms);
     detector->setRadiusSearch(radius_features);
     detector->setInputCloud(cloud);
-    detector->setNormals(normals);
+    if (!own_normals) detector->setNormals(normals);          // else: impl/KeypointLearning.hpp:125-148
 
     // detect keypoints (:186-187)
     pcl::PointCloud<KeypointT>::Ptr keypoint(new pcl::PointCloud<KeypointT>());

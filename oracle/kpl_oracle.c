@@ -500,7 +500,9 @@ void kplo_alg_counters(const kplo_grid *g, const float *xyz, const float *nrm, i
  * computeCloudResolution, include/impl/point_cloud_utilities.hpp:120-151: mean over points
  * with finite x of sqrt(second smallest squared distance), double accumulator.
  * ---------------------------------------------------------------------------------------- */
-double kplo_cloud_resolution(const float *xyz, int n)
+/* grid for nearest-neighbor queries without a radius: about two points per cell on a
+ * surface-like cloud (the results do not depend on the cell size, only the work does) */
+static kplo_grid *auto_grid(const float *xyz, int n)
 {
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     int nf = 0;
@@ -513,8 +515,7 @@ double kplo_cloud_resolution(const float *xyz, int n)
             if (p[k] > mx[k]) mx[k] = p[k];
         }
     }
-    if (nf < 2) return 0.0;
-    /* cell size heuristic: about two points per cell on a surface-like cloud */
+    if (nf == 0) return kplo_grid_create(xyz, n, 1.0);
     double ext[3] = {mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]};
     double e0 = ext[0], e1 = ext[1], e2 = ext[2], t;
     if (e0 < e1) { t = e0; e0 = e1; e1 = t; }
@@ -524,6 +525,13 @@ double kplo_cloud_resolution(const float *xyz, int n)
     if (!(cell > 0)) cell = 1.0;
     kplo_grid *g = NULL;
     while (!(g = kplo_grid_create(xyz, n, cell))) cell *= 2.0;
+    return g;
+}
+
+double kplo_cloud_resolution(const float *xyz, int n)
+{
+    kplo_grid *g = auto_grid(xyz, n);
+    if (g->nfinite < 2) { kplo_grid_free(g); return 0.0; }
     double res = 0.0;
     int n_points = 0;
     for (int i = 0; i < n; ++i) {
@@ -561,4 +569,174 @@ double kplo_cloud_resolution(const float *xyz, int n)
     kplo_grid_free(g);
     if (n_points != 0) res /= n_points;                                   /* :145-148 */
     return res;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Normal estimation: pcl::NormalEstimation as the reference uses it --
+ *   src/main_test_detector.cpp:162-169   setKSearch(10), viewpoint (0,0,0)
+ *   include/impl/KeypointLearning.hpp:125-148   setRadiusSearch(search_radius_) when the caller
+ *                                               gave no normals (unorganized cloud)
+ * PCL is absent from the image, so this is a restatement of its published algorithm
+ * (computePointNormal: PCA of the neighborhood, eigenvector of the smallest eigenvalue,
+ * flipNormalTowardsViewpoint, curvature = lambda_min / trace) with the arithmetic fixed as
+ * follows ("parity unpinned": PCL accumulates the covariance in float in one pass and solves the
+ * eigenproblem analytically in float; results agree to ~1e-4 rad, not bitwise):
+ *   neighbors   k-search: the k smallest (d2, index), d2 as in dist2(), the query included,
+ *               in that order; radius search: kplo_radius_search order (grid cell = radius)
+ *   fewer than 3 neighbors, or a non-finite query: NaN normal and curvature
+ *   mean, covariance: double, two passes, sequential sums in neighbor order
+ *   eigenvectors: cyclic Jacobi in double (pairs (0,1),(0,2),(1,2), at most 24 sweeps, stops
+ *               when the off-diagonal energy is below 1e-36 of the diagonal energy);
+ *               smallest diagonal entry, first one on ties
+ *   flip        if n . (viewpoint - p) < 0 (double)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    float d2;
+    int idx;
+} knn_item;
+
+static int knn_less(float d2, int idx, const knn_item *b)
+{
+    return d2 < b->d2 || (d2 == b->d2 && idx < b->idx);
+}
+
+/* the k nearest finite points of point i (itself included), ascending (d2, index) */
+static int knn_search(const kplo_grid *g, const float *xyz, int i, int k, knn_item *best)
+{
+    const float *p = xyz + 3 * (size_t)i;
+    int c[3], m = 0;
+    for (int a = 0; a < 3; ++a) c[a] = cell_coord(p[a], g->mn[a], g->h, g->dims[a]);
+    int maxring = g->dims[0] > g->dims[1] ? g->dims[0] : g->dims[1];
+    if (g->dims[2] > maxring) maxring = g->dims[2];
+    for (int ring = 1; ring <= maxring; ++ring) {
+        search_box b;
+        b.r2 = 0;
+        for (int a = 0; a < 3; ++a) {
+            b.lo[a] = c[a] - ring < 0 ? 0 : c[a] - ring;
+            b.hi[a] = c[a] + ring >= g->dims[a] ? g->dims[a] - 1 : c[a] + ring;
+        }
+        m = 0;
+        FOR_EACH_CANDIDATE(g, b, j, {
+            float d2 = dist2(p, xyz + 3 * (size_t)j);
+            if (m < k || knn_less(d2, j, &best[m - 1])) {
+                int pos = m < k ? m++ : k - 1;
+                while (pos > 0 && knn_less(d2, j, &best[pos - 1])) {
+                    best[pos] = best[pos - 1];
+                    --pos;
+                }
+                best[pos].d2 = d2;
+                best[pos].idx = j;
+            }
+        })
+        /* every point outside the block is at least ring*h away (0.999: slack for float cell edges) */
+        if (m == k && (double)sqrtf(best[k - 1].d2) <= ring * (double)g->h * 0.999) break;
+        if (b.lo[0] == 0 && b.lo[1] == 0 && b.lo[2] == 0 && b.hi[0] == g->dims[0] - 1 &&
+            b.hi[1] == g->dims[1] - 1 && b.hi[2] == g->dims[2] - 1)
+            break;
+    }
+    return m;
+}
+
+/* eigenvector of the smallest eigenvalue of the symmetric 3x3 matrix a (destroyed) */
+static void jacobi_smallest(double a[3][3], double v[3], double *lambda, double *trace)
+{
+    double e[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 24; ++sweep) {
+        const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
+        const double dg = a[0][0] * a[0][0] + a[1][1] * a[1][1] + a[2][2] * a[2][2];
+        if (!(off > 1e-36 * dg)) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                const double apq = a[p][q];
+                if (apq == 0.0) continue;
+                const double theta = (a[q][q] - a[p][p]) / (2.0 * apq);
+                double t = 1.0 / (fabs(theta) + sqrt(theta * theta + 1.0));
+                if (theta < 0.0) t = -t;
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 3; ++k) {
+                    const double akp = a[k][p], akq = a[k][q];
+                    a[k][p] = c * akp - s * akq;
+                    a[k][q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double apk = a[p][k], aqk = a[q][k];
+                    a[p][k] = c * apk - s * aqk;
+                    a[q][k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double ekp = e[k][p], ekq = e[k][q];
+                    e[k][p] = c * ekp - s * ekq;
+                    e[k][q] = s * ekp + c * ekq;
+                }
+            }
+    }
+    int m = 0;
+    for (int k = 1; k < 3; ++k)
+        if (a[k][k] < a[m][m]) m = k;
+    for (int k = 0; k < 3; ++k) v[k] = e[k][m];
+    *lambda = a[m][m];
+    *trace = a[0][0] + a[1][1] + a[2][2];
+}
+
+static void normal_from_neighbors(const float *xyz, const float *p, const int *idx, int m,
+                                  const float *vp, float *out, float *curv)
+{
+    if (m < 3) {
+        out[0] = out[1] = out[2] = NAN;
+        if (curv) *curv = NAN;
+        return;
+    }
+    double sum[3] = {0, 0, 0};
+    for (int t = 0; t < m; ++t)
+        for (int a = 0; a < 3; ++a) sum[a] += (double)xyz[3 * (size_t)idx[t] + a];
+    double mean[3];
+    for (int a = 0; a < 3; ++a) mean[a] = sum[a] / (double)m;
+    double cov[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (int t = 0; t < m; ++t) {
+        const float *q = xyz + 3 * (size_t)idx[t];
+        const double dx = (double)q[0] - mean[0], dy = (double)q[1] - mean[1], dz = (double)q[2] - mean[2];
+        cov[0][0] += dx * dx; cov[0][1] += dx * dy; cov[0][2] += dx * dz;
+        cov[1][1] += dy * dy; cov[1][2] += dy * dz; cov[2][2] += dz * dz;
+    }
+    cov[1][0] = cov[0][1]; cov[2][0] = cov[0][2]; cov[2][1] = cov[1][2];
+    double v[3], lambda, trace;
+    jacobi_smallest(cov, v, &lambda, &trace);
+    const double dot = v[0] * ((double)vp[0] - (double)p[0]) + v[1] * ((double)vp[1] - (double)p[1]) +
+                       v[2] * ((double)vp[2] - (double)p[2]);
+    if (dot < 0.0) { v[0] = -v[0]; v[1] = -v[1]; v[2] = -v[2]; }
+    out[0] = (float)v[0]; out[1] = (float)v[1]; out[2] = (float)v[2];
+    if (curv) *curv = trace != 0.0 ? (float)fabs(lambda / trace) : 0.0f;
+}
+
+void kplo_estimate_normals(const float *xyz, int n, int k, double radius, const float *viewpoint,
+                           float *normals_out, float *curvature_out)
+{
+    const int use_k = k > 0;
+    kplo_grid *g = use_k ? auto_grid(xyz, n) : kplo_grid_create(xyz, n, radius);
+    int cap = use_k ? k : 64;
+    int *idx = (int *)malloc(sizeof(int) * (size_t)cap);
+    knn_item *best = use_k ? (knn_item *)malloc(sizeof(knn_item) * (size_t)k) : NULL;
+    for (int i = 0; i < n; ++i) {
+        const float *p = xyz + 3 * (size_t)i;
+        float *out = normals_out + 3 * (size_t)i;
+        float *cv = curvature_out ? curvature_out + i : NULL;
+        int m = 0;
+        if (g && finite3(p) && g->ncells > 0) {
+            if (use_k) {
+                m = knn_search(g, xyz, i, k, best);
+                for (int t = 0; t < m; ++t) idx[t] = best[t].idx;
+            } else {
+                m = kplo_radius_search(g, xyz, i, radius, idx, NULL, cap);
+                if (m > cap) {
+                    cap = m * 2;
+                    idx = (int *)realloc(idx, sizeof(int) * (size_t)cap);
+                    m = kplo_radius_search(g, xyz, i, radius, idx, NULL, cap);
+                }
+            }
+        }
+        normal_from_neighbors(xyz, p, idx, m, viewpoint, out, cv);
+    }
+    free(idx);
+    free(best);
+    kplo_grid_free(g);
 }

@@ -94,6 +94,12 @@ void kplo_alg_counters(const kplo_grid *g, const float *xyz, const float *nrm, i
 /* include/impl/point_cloud_utilities.hpp:120-151: mean over finite points of sqrt(2nd-NN d2). */
 double kplo_cloud_resolution(const float *xyz, int n);
 
+/* pcl::NormalEstimation restated (src/main_test_detector.cpp:162-169 k-search 10;
+ * include/impl/KeypointLearning.hpp:125-148 radius search): k > 0 selects the k-search, else the
+ * radius search.  normals_out[3n], curvature_out[n] (may be NULL).  "parity unpinned" (PCL absent). */
+void kplo_estimate_normals(const float *xyz, int n, int k, double radius, const float *viewpoint,
+                           float *normals_out, float *curvature_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -75,6 +75,8 @@ def lib():
     L.kplo_alg_counters.restype = None
     L.kplo_cloud_resolution.argtypes = [fp, C.c_int]
     L.kplo_cloud_resolution.restype = C.c_double
+    L.kplo_estimate_normals.argtypes = [fp, C.c_int, C.c_int, C.c_double, fp, fp, fp]
+    L.kplo_estimate_normals.restype = None
     _lib = L
     return L
 
@@ -246,3 +248,15 @@ def detect(xyz, nrm, A, B, r_feat, r_nms, threshold, forest, non_maxima=True,
 def cloud_resolution(xyz):
     xyz = _f32(xyz).reshape(-1, 3)
     return lib().kplo_cloud_resolution(_p(xyz, C.c_float), xyz.shape[0])
+
+
+def estimate_normals(xyz, k=10, radius=0.0, viewpoint=(0.0, 0.0, 0.0)):
+    """pcl::NormalEstimation restated: k > 0 = k-search, else radius search.  Returns (normals[n,3], curvature[n])."""
+    xyz = _f32(xyz).reshape(-1, 3)
+    n = xyz.shape[0]
+    vp = _f32(np.asarray(viewpoint, dtype=np.float32))
+    nrm = np.empty((max(n, 1), 3), dtype=np.float32)
+    cv = np.empty(max(n, 1), dtype=np.float32)
+    lib().kplo_estimate_normals(_p(xyz, C.c_float), n, int(k), float(radius), _p(vp, C.c_float),
+                                _p(nrm, C.c_float), _p(cv, C.c_float))
+    return nrm[:n], cv[:n]

@@ -53,18 +53,44 @@ def test_cli_on_cheff_view(tmp_path, binary):
 
 
 def test_cli_estimates_normals_and_resolution(tmp_path):
-    """No normals in the file: the CLI estimates them (k = 10) like the reference main; radii in mr."""
+    """No normals in the file: the CLI gets them from kpl_estimate_normals (k = 10) like the reference main and
+    the radii from kpl_cloud_resolution; the whole run equals the oracle pipeline on the same file."""
+    from oracle import kplo
+    from tests import helpers
+    from tools import forest_yaml
     z = np.load(os.path.join(GOLD, "small_case.npz"))
-    xyz = z["xyz"][np.isfinite(z["xyz"]).all(axis=1)]
-    pcd = tmp_path / "small.pcd"
+    xyz = np.ascontiguousarray(z["xyz"][np.isfinite(z["xyz"]).all(axis=1)])
+    pcd, out = tmp_path / "small.pcd", tmp_path / "kp.pcd"
     write_pcd(pcd, xyz, None, True)
-    cmd = [EXE, "--pathCloud", str(pcd), "--pathRF", os.path.join(GOLD, "small_forest.yaml.gz"), "--radiusFeatures", "6",
+    forest = os.path.join(GOLD, "small_forest.yaml.gz")
+    cmd = [EXE, "--pathCloud", str(pcd), "--pathRF", forest, "--radiusFeatures", "6", "--pathKP=%s" % out,
            "--radiusNMS", "4", "--radiusInMr", "--annuli", "5", "--bins", "6", "-t", "0.5", "--flipNormals", "--json"]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stderr
     info = json.loads(res.stdout.strip().splitlines()[-1])
-    assert abs(info["mr"] - float(z["mr"])) < 1e-3 * float(z["mr"])
-    assert info["points"] == len(xyz) and 0 < info["keypoints"] < len(xyz)
+    mr = kplo.cloud_resolution(xyz)
+    assert info["mr"] == pytest.approx(mr, rel=1e-8)          # printed with 9 digits
+    nrm, _ = kplo.estimate_normals(xyz, k=10, viewpoint=(0, 0, 0))
+    nrm = -nrm                                                  # --flipNormals
+    r, rn = float(np.float32(6 * mr)), float(np.float32(4 * mr))
+    fa = forest_yaml.load_forest(forest)
+    o_sc, o_kp = kplo.detect(xyz, nrm, 5, 6, r, rn, float(np.float32(0.5)), helpers.oracle_forest(fa))
+    kp = np.loadtxt(out, skiprows=11, dtype=np.float32).reshape(-1, 4)
+    assert info["points"] == len(xyz) and info["keypoints"] == len(o_kp) > 0
+    assert np.array_equal(kp[:, :3], xyz[o_kp]) and np.array_equal(kp[:, 3], o_sc[o_kp])
+    res = subprocess.run([EXE, "--pathCloud", str(pcd), "--printResolution"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and float(res.stdout.strip().splitlines()[-1]) == mr
+    # no setNormals at all: the detector's own fallback (radius search with the feature radius, hpp:125-148)
+    cmd = [c for c in cmd if c != "--flipNormals"] + ["--detectorNormals"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    assert "Computing normals for KPL" in res.stdout
+    info = json.loads(res.stdout.strip().splitlines()[-1])
+    nrm, _ = kplo.estimate_normals(xyz, k=0, radius=r, viewpoint=(0, 0, 0))
+    o_sc, o_kp = kplo.detect(xyz, nrm, 5, 6, r, rn, float(np.float32(0.5)), helpers.oracle_forest(fa))
+    kp = np.loadtxt(out, skiprows=11, dtype=np.float32).reshape(-1, 4)
+    assert info["keypoints"] == len(o_kp) > 0
+    assert np.array_equal(kp[:, :3], xyz[o_kp]) and np.array_equal(kp[:, 3], o_sc[o_kp])
 
 
 def test_cli_errors():

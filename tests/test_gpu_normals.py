@@ -1,0 +1,91 @@
+"""GPU normal estimation (kpl_estimate_normals[_device], the step before the path: pcl::NormalEstimation,
+/root/reference/src/main_test_detector.cpp:162-169 and include/impl/KeypointLearning.hpp:125-148) against the
+oracle: same neighbors, same double arithmetic, so normals and curvature are compared bit for bit
+(tolerance the north star would allow for this step: 1e-4 rad)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def same(a, b):
+    return np.array_equal(np.asarray(a, np.float32).view(np.uint32), np.asarray(b, np.float32).view(np.uint32))
+
+
+@pytest.mark.parametrize("k", [10, 3, 16, 25])
+def test_k_search_bit_exact(kpl, oracle, cases, k):
+    xyz, _ = cases.cloud(90, 70, seed=11, nan_points=5)
+    det = kpl.KeypointLearningDetector()
+    vp = (3.0, -2.0, 500.0)
+    nrm, curv = det.estimateNormals(xyz, k=k, viewpoint=vp)
+    o_nrm, o_curv = oracle.estimate_normals(xyz, k=k, viewpoint=vp)
+    assert np.isfinite(o_nrm).all(1).sum() == len(xyz) - 5
+    assert same(nrm, o_nrm) and same(curv, o_curv)
+
+
+@pytest.mark.parametrize("rmul", [1.5, 3.0, 6.0])
+def test_radius_search_bit_exact(kpl, oracle, cases, rmul):
+    xyz, _ = cases.cloud(80, 60, seed=12, nan_points=3, layers=2)
+    mr = oracle.cloud_resolution(xyz)
+    r = float(np.float32(rmul * mr))
+    det = kpl.KeypointLearningDetector()
+    nrm, curv = det.estimateNormals(xyz, k=0, radius=r, viewpoint=(0, 0, 0))
+    o_nrm, o_curv = oracle.estimate_normals(xyz, k=0, radius=r, viewpoint=(0, 0, 0))
+    assert same(nrm, o_nrm) and same(curv, o_curv)
+
+
+def test_lattice_ties_and_small_inputs(kpl, oracle):
+    g = np.stack(np.meshgrid(np.arange(12), np.arange(9), [0.0]), -1).reshape(-1, 3).astype(np.float32)
+    g[:, 2] = 0.25 * g[:, 1]
+    det = kpl.KeypointLearningDetector()
+    for k in (4, 9, 10):
+        nrm, curv = det.estimateNormals(g, k=k, viewpoint=(0, 0, 50))
+        o_nrm, o_curv = oracle.estimate_normals(g, k=k, viewpoint=(0, 0, 50))
+        assert same(nrm, o_nrm) and same(curv, o_curv)
+    for n in (0, 1, 2, 3, 7):
+        nrm, curv = det.estimateNormals(g[:n], k=10)
+        o_nrm, o_curv = oracle.estimate_normals(g[:n], k=10)
+        assert nrm.shape == (n, 3) and same(nrm, o_nrm) and same(curv, o_curv)
+    with pytest.raises(kpl.KplError):
+        det.estimateNormals(g, k=33)
+    with pytest.raises(kpl.KplError):
+        det.estimateNormals(g, k=0, radius=0.0)
+
+
+def test_full_size_view_then_detect_on_estimated_normals(kpl, oracle, cases):
+    """200 k points: normals on the device, straight into pcl::Normal-shaped storage (32-byte records), then the
+    hot path on them; everything equal to the oracle run on the oracle's normals."""
+    import torch
+    from tools import forest_yaml, synth
+    import os
+    root = os.path.dirname(os.path.dirname(__file__))
+    forest = os.path.join(root, "data", "forests", "synth200k_a5b6_t10.yaml.gz")
+    xyz, _ = synth.make_cloud(500, 400, seed=1)
+    n = len(xyz)
+    dev = torch.device("cuda", 0)
+    det = kpl.KeypointLearningDetector()
+    mr = det.cloudResolution(xyz)
+    r, rn, thr = float(np.float32(6 * mr)), float(np.float32(4 * mr)), float(np.float32(0.85))
+    det.setNAnnulus(5); det.setNBins(6); det.setNonMaxima(True); det.setNonMaxRadius(rn)
+    det.setNonMaximaDrawsRemove(False); det.setPredictionThreshold(thr); det.setRadiusSearch(r)
+    assert det.loadForest(forest)
+    dx = torch.from_numpy(xyz).to(dev)
+    dnrm = torch.zeros(n, 8, dtype=torch.float32, device=dev)          # pcl::Normal: nx ny nz pad curvature pad pad pad
+    det.bindCloudDevice(dx.data_ptr(), 12, dnrm.data_ptr(), 32, n)
+    det.estimateNormalsDevice(10, 0.0, (0, 0, 1e4), dnrm.data_ptr(), 32, dnrm.data_ptr() + 16, 32, None)
+    assert det.syncStatus(None) in (kpl.OK, kpl.ERR_RETRY)
+    det.estimateNormalsDevice(10, 0.0, (0, 0, 1e4), dnrm.data_ptr(), 32, dnrm.data_ptr() + 16, 32, None)
+    assert det.syncStatus(None) == kpl.OK
+    o_nrm, o_curv = oracle.estimate_normals(xyz, k=10, viewpoint=(0, 0, 1e4))
+    got = dnrm.cpu().numpy()
+    assert same(got[:, :3], o_nrm) and same(got[:, 4], o_curv)
+    ds = torch.empty(n, dtype=torch.float32, device=dev)
+    dk = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+    for _ in range(2):
+        det.computeDevice(ds.data_ptr(), dk[1:].data_ptr(), n, dk[0:1].data_ptr(), None)
+        rc = det.syncStatus(None)
+    assert rc == kpl.OK
+    fa = forest_yaml.load_forest(forest)
+    o_sc, o_kp = oracle.detect(xyz, o_nrm, 5, 6, r, rn, thr, cases.oracle_forest(fa), threads=cases.usable_cores())
+    assert same(ds.cpu().numpy(), o_sc)
+    assert np.array_equal(dk[1:1 + int(dk[0].item())].cpu().numpy(), o_kp)
