@@ -866,13 +866,14 @@ int kpl_cloud_resolution(kpl_detector *h, const void *xyz, size_t xyz_stride, in
     h->d_nrm = h->d_xyz;
     const size_t nn = (size_t)(n > 0 ? n : 1);
     KPL_HIP(h, h->stage_feat.ensure(sizeof(float) * nn));
-    KPL_HIP(h, h->out_scores.ensure(2 * sizeof(double)));
+    KPL_HIP(h, h->out_scores.ensure(3 * sizeof(double)));
+    KPL_HIP(h, h->out_kp.ensure(resolution_scratch_bytes()));
     hipStream_t st = nullptr;
     for (int attempt = 0;; ++attempt) {
         rc = build_index(h, st, true);
         if (rc) return rc;
         launch_resolution(h->pts.as<float4>(), h->cell_start.as<int>(), h->pos_of.as<int>(), h->dstate.as<DevState>(), n,
-                          h->stage_feat.as<float>(), h->out_scores.as<double>(), st);
+                          h->stage_feat.as<float>(), h->out_scores.as<double>(), h->out_kp.p, st);
         KPL_HIP(h, hipGetLastError());
         rc = sync_status(h, st);
         if (rc == KPL_ERR_RETRY && attempt == 0) continue;

@@ -139,8 +139,10 @@ void launch_features(const float4 *pts, const float4 *nrm, const int *cell_start
                      uint2 *rowtab, float *out, hipStream_t st);
 
 // cloud resolution: val[n] scratch, out[0] = ordered double sum of the 2nd-NN distances, out[1] = count
+// (out holds 3 doubles; scratch holds resolution_scratch_bytes())
 void launch_resolution(const float4 *pts, const int *cell_start, const int *pos_of, const DevState *ds,
-                       int n, float *val, double *out, hipStream_t st);
+                       int n, float *val, double *out, void *scratch, hipStream_t st);
+size_t resolution_scratch_bytes();
 
 // normals of every point of the indexed view (pcl::NormalEstimation restated, see kernels.hip):
 // k > 0: k-search (k <= 32) on any grid; k <= 0: radius search, r2/rr as in FeatDesc, on the grid

@@ -998,9 +998,74 @@ __global__ __launch_bounds__(256) void second_nn_kernel(const float4 *__restrict
     val[i] = isfinite(best1) ? sqrtf(best1) : NAN;                                 // hpp:141
 }
 
-// res += sqrt(...) over the points in index order, double accumulator (hpp:141-148): one wave,
-// 64 values fetched at a time, added one after the other so that the sum is the sequential one
+// res += sqrt(...) over the points in index order, double accumulator (hpp:141-148).  The sum of
+// the reference is the SEQUENTIAL one.  All values are >= 0 and multiples of q = the smallest ulp
+// among them; if the total stays below q * 2^52 every partial sum of every summation order is
+// exactly representable, so a parallel reduction gives the sequential result bit for bit.  That
+// is checked on the device (resolution_finish_kernel); only if it fails does one wave add the
+// values one after the other.
+struct SumPart {
+    double sum;
+    long long cnt;
+    int emin;      // smallest ulp exponent among the non-zero values (INT_MAX if none)
+    int pad;
+};
+constexpr int kSumBlocks = 256;
+
+__device__ __forceinline__ SumPart sum_merge(SumPart a, const SumPart &b) {
+    a.sum += b.sum;
+    a.cnt += b.cnt;
+    a.emin = min(a.emin, b.emin);
+    return a;
+}
+
+__device__ __forceinline__ SumPart block_sum(SumPart v) {
+    __shared__ SumPart red[256 / kWave];
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        SumPart o;
+        o.sum = __shfl_xor(v.sum, off);
+        o.cnt = __shfl_xor(v.cnt, off);
+        o.emin = __shfl_xor(v.emin, off);
+        v = sum_merge(v, o);
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = v;
+    __syncthreads();
+    SumPart t = red[0];
+    for (int w = 1; w < 256 / kWave; ++w) t = sum_merge(t, red[w]);
+    return t;
+}
+
+__global__ __launch_bounds__(256) void resolution_partial_kernel(const float *__restrict__ val, int n, SumPart *part) {
+    SumPart v{0.0, 0, 0x7fffffff, 0};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float x = val[i];
+        if (!isnan(x)) {
+            v.sum += (double)x;
+            ++v.cnt;
+            const int ef = (int)((__float_as_uint(x) >> 23) & 0xffu);
+            if (x != 0.0f) v.emin = min(v.emin, max(ef, 1) - 150);
+        }
+    }
+    v = block_sum(v);
+    if (threadIdx.x == 0) part[blockIdx.x] = v;
+}
+
+// out[0] = sum, out[1] = count, out[2] = 1 if the parallel sum is the sequential one
+__global__ __launch_bounds__(256) void resolution_finish_kernel(const SumPart *part, int nparts, double *out) {
+    SumPart v{0.0, 0, 0x7fffffff, 0};
+    if ((int)threadIdx.x < nparts) v = part[threadIdx.x];
+    v = block_sum(v);
+    if (threadIdx.x == 0) {
+        const bool exact = v.emin == 0x7fffffff || v.sum < ldexp(1.0, v.emin + 52);
+        out[0] = v.sum;
+        out[1] = (double)v.cnt;
+        out[2] = exact ? 1.0 : 0.0;
+    }
+}
+
+// fallback: one wave, 64 values fetched at a time, added one after the other
 __global__ __launch_bounds__(64) void ordered_sum_kernel(const float *__restrict__ val, int n, double *out) {
+    if (out[2] != 0.0) return;
     double sum = 0.0;
     long long cnt = 0;
     for (int b = 0; b < n; b += 64) {
@@ -1408,10 +1473,15 @@ void launch_post(const Batch &b, hipStream_t st) {
 }
 
 void launch_resolution(const float4 *pts, const int *cell_start, const int *pos_of, const DevState *ds,
-                       int n, float *val, double *out, hipStream_t st) {
+                       int n, float *val, double *out, void *scratch, hipStream_t st) {
     if (n > 0) second_nn_kernel<<<div_up(n, 256), 256, 0, st>>>(pts, cell_start, pos_of, ds, n, val);
+    SumPart *part = static_cast<SumPart *>(scratch);
+    resolution_partial_kernel<<<kSumBlocks, 256, 0, st>>>(val, n, part);
+    resolution_finish_kernel<<<1, 256, 0, st>>>(part, kSumBlocks, out);
     ordered_sum_kernel<<<1, 64, 0, st>>>(val, n, out);
 }
+
+size_t resolution_scratch_bytes() { return sizeof(SumPart) * kSumBlocks; }
 
 void launch_normals(const float4 *pts, const int *cell_start, const int *pos_of, const DevState *ds, int n,
                     int k, float r2, float rr, const float *viewpoint, char *normals, size_t normals_stride,

@@ -254,3 +254,18 @@ def test_cloud_resolution_bit_exact(kpl, oracle, cases):
     assert det.cloudResolution(xyz[:1]) == 0.0 and det.cloudResolution(xyz[:0].reshape(0, 3)) == 0.0
     two = np.array([[0, 0, 0], [3, 4, 0]], dtype=np.float32)
     assert det.cloudResolution(two) == 5.0
+
+
+def test_cloud_resolution_sum_order_fallback(kpl, oracle, cases):
+    """The device adds the distances in parallel only when that provably equals the reference's sequential
+    double sum; a cloud whose distances span ~50 binades (a nearly coincident pair next to far-apart points)
+    must take the sequential fallback and still match bit for bit."""
+    det = kpl.KeypointLearningDetector()
+    rng = np.random.default_rng(9)
+    xyz = (rng.uniform(0, 1, size=(3000, 3)) * np.float32(3.0e7)).astype(np.float32)
+    xyz[1] = xyz[0] + np.float32([0, 0, 2.0])         # ulp at 3e7 is 2: the closest representable pair
+    tiny = rng.uniform(0, 1, size=(500, 3)).astype(np.float32) * np.float32(1e-9)
+    both = np.concatenate([xyz, tiny]).astype(np.float32)
+    expect = oracle.cloud_resolution(both)
+    assert det.cloudResolution(both) == expect
+    assert det.cloudResolution(both[::-1].copy()) == oracle.cloud_resolution(both[::-1].copy())
