@@ -258,3 +258,46 @@ def test_batched_mixed_modes_and_shapes(kpl, oracle, cases):
                                        draws_remove=draws, draws_threshold=dthr)
             assert cases.same_bits(ds.cpu().numpy()[:n], o_sc)
             assert np.array_equal(dk[1:1 + int(dk[0].item())].cpu().numpy(), o_kp)
+
+
+def test_batch_call_can_be_captured_in_a_hip_graph(kpl, oracle, cases):
+    """kpl_compute_batch_device only enqueues (no host sync, no allocation once the scratch is sized), so a
+    caller can capture it with hipStreamBeginCapture -- here through torch.cuda.graph -- and replay it."""
+    import torch
+    from tools import forest_yaml
+    fa = forest_yaml.load_forest(CFG_FOREST)
+    of = cases.oracle_forest(fa)
+    dev = torch.device("cuda", 0)
+    dets, bufs, views = [], [], []
+    for k in range(3):
+        xyz, nrm = cases.cloud(60 + 10 * k, 50, seed=70 + k)
+        mr = oracle.cloud_resolution(xyz)
+        r, rn, thr = float(np.float32(6 * mr)), float(np.float32(4 * mr)), float(np.float32(0.85))
+        det = detector(kpl, 5, 6, r, rn, thr, CFG_FOREST)
+        n = len(xyz)
+        dx, dn = torch.from_numpy(xyz.copy()).to(dev), torch.from_numpy(nrm.copy()).to(dev)
+        ds = torch.empty(n, dtype=torch.float32, device=dev)
+        dk = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+        det.bindCloudDevice(dx.data_ptr(), 12, dn.data_ptr(), 12, n)
+        dets.append(det); bufs.append((dx, dn, ds, dk)); views.append((xyz, nrm, r, rn, thr))
+    args = (dets, [b[2].data_ptr() for b in bufs], [b[3][1:].data_ptr() for b in bufs], [len(b[2]) for b in bufs],
+            [b[3][0:1].data_ptr() for b in bufs])
+    st = torch.cuda.Stream()
+    for _ in range(2):                              # sizes the scratch (and grows the cell tables once)
+        kpl.compute_batch_device(*args, st.cuda_stream)
+        st.synchronize()
+        for d in dets:
+            d.syncStatus(st.cuda_stream)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=st):
+        kpl.compute_batch_device(*args, torch.cuda.current_stream().cuda_stream)
+    for rep in range(3):
+        for b in bufs:
+            b[2].fill_(-1.0); b[3].zero_()
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        for (xyz, nrm, r, rn, thr), (dx, dn, ds, dk) in zip(views, bufs):
+            o_sc, o_kp = oracle.detect(xyz, nrm, 5, 6, r, rn, thr, of)
+            assert cases.same_bits(ds.cpu().numpy(), o_sc)
+            assert np.array_equal(dk[1:1 + int(dk[0].item())].cpu().numpy(), o_kp)
