@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -81,6 +82,35 @@ bool parse(int argc, char **argv, Options &o) {
 }
 
 // ---- PCD (ascii / binary; float32 fields) -------------------------------------------------------
+// LZF (the codec of PCD "binary_compressed"): a control byte < 32 starts a run of ctrl + 1 literals;
+// otherwise it is a back reference of length (ctrl >> 5) + 2 (7 = extended by the next byte) at
+// distance ((ctrl & 31) << 8 | next byte) + 1
+bool lzf_decompress(const unsigned char *in, size_t in_len, unsigned char *out, size_t out_len) {
+    size_t ip = 0, op = 0;
+    while (ip < in_len) {
+        unsigned ctrl = in[ip++];
+        if (ctrl < 32) {
+            const size_t run = ctrl + 1;
+            if (ip + run > in_len || op + run > out_len) return false;
+            memcpy(out + op, in + ip, run);
+            ip += run;
+            op += run;
+        } else {
+            size_t len = ctrl >> 5;
+            if (len == 7) {
+                if (ip >= in_len) return false;
+                len += in[ip++];
+            }
+            if (ip >= in_len) return false;
+            const size_t dist = ((size_t)(ctrl & 31) << 8 | in[ip++]) + 1;
+            len += 2;
+            if (dist > op || op + len > out_len) return false;
+            for (size_t k = 0; k < len; ++k, ++op) out[op] = out[op - dist];     // may overlap itself
+        }
+    }
+    return op == out_len;
+}
+
 bool load_pcd(const std::string &path, pcl::PointCloud<PointInT> &cloud, pcl::PointCloud<PointNormalT> &normals) {
     std::ifstream f(path, std::ios::binary);
     if (!f) { fprintf(stderr, "cannot open %s\n", path.c_str()); return false; }
@@ -135,8 +165,29 @@ bool load_pcd(const std::string &path, pcl::PointCloud<PointInT> &cloud, pcl::Po
             cloud.push_back(PointInT(get(p, ix), get(p, iy), get(p, iz)));
             if (has_n) { PointNormalT n; n.normal_x = get(p, inx); n.normal_y = get(p, iny); n.normal_z = get(p, inz); normals.push_back(n); }
         }
+    } else if (data_kind == "binary_compressed") {
+        // uint32 compressed size, uint32 uncompressed size, LZF stream; the payload is field-major
+        // (all x, then all y, ...) instead of point-major
+        uint32_t csize = 0, usize = 0;
+        f.read((char *)&csize, 4);
+        f.read((char *)&usize, 4);
+        if (!f || usize != rec * npoints) { fprintf(stderr, "%s: bad binary_compressed sizes\n", path.c_str()); return false; }
+        std::vector<unsigned char> in(csize), buf(usize);
+        f.read((char *)in.data(), (std::streamsize)in.size());
+        if ((size_t)f.gcount() != in.size() || !lzf_decompress(in.data(), in.size(), buf.data(), buf.size())) {
+            fprintf(stderr, "%s: corrupt binary_compressed data\n", path.c_str());
+            return false;
+        }
+        std::vector<size_t> plane(fields.size());     // start of each field's block
+        size_t at = 0;
+        for (size_t i = 0; i < fields.size(); ++i) { plane[i] = at; at += (size_t)sizes[i] * counts[i] * npoints; }
+        auto get = [&](size_t p, int fi) { float v; memcpy(&v, &buf[plane[fi] + p * 4 * counts[fi]], 4); return v; };
+        for (size_t p = 0; p < npoints; ++p) {
+            cloud.push_back(PointInT(get(p, ix), get(p, iy), get(p, iz)));
+            if (has_n) { PointNormalT n; n.normal_x = get(p, inx); n.normal_y = get(p, iny); n.normal_z = get(p, inz); normals.push_back(n); }
+        }
     } else {
-        fprintf(stderr, "%s: PCD DATA '%s' is not supported (ascii and binary are)\n", path.c_str(), data_kind.c_str());
+        fprintf(stderr, "%s: PCD DATA '%s' is not supported (ascii, binary and binary_compressed are)\n", path.c_str(), data_kind.c_str());
         return false;
     }
     cloud.is_dense = true;

@@ -30,6 +30,83 @@ def write_pcd(path, xyz, nrm=None, binary=True):
                 f.write((" ".join("%.9g" % v for v in row) + "\n").encode())
 
 
+def lzf_compress(data):
+    """Small greedy LZF encoder (test helper): hash of 3 bytes -> last position, literals otherwise."""
+    out, lit, table, i, n = bytearray(), bytearray(), {}, 0, len(data)
+
+    def flush():
+        for k in range(0, len(lit), 32):
+            chunk = lit[k:k + 32]
+            out.append(len(chunk) - 1)
+            out.extend(chunk)
+        lit.clear()
+    while i < n:
+        key = bytes(data[i:i + 3])
+        ref = table.get(key) if len(key) == 3 else None
+        if len(key) == 3:
+            table[key] = i
+        if ref is not None and 0 < i - ref <= 8192:
+            length = 3
+            while i + length < n and length < 264 and data[ref + length] == data[i + length]:
+                length += 1
+            flush()
+            dist, l2 = i - ref - 1, length - 2
+            if l2 < 7:
+                out.append((l2 << 5) | (dist >> 8))
+            else:
+                out.append((7 << 5) | (dist >> 8))
+                out.append(l2 - 7)
+            out.append(dist & 0xff)
+            i += length
+        else:
+            lit.append(data[i])
+            i += 1
+    flush()
+    return bytes(out)
+
+
+def write_pcd_compressed(path, xyz, nrm):
+    import struct
+    arr = np.concatenate([xyz, nrm], axis=1).astype(np.float32)
+    payload = np.ascontiguousarray(arr.T).tobytes()             # field-major
+    comp = lzf_compress(payload)
+    hdr = ("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z normal_x normal_y normal_z\nSIZE 4 4 4 4 4 4\n"
+           "TYPE F F F F F F\nCOUNT 1 1 1 1 1 1\nWIDTH %d\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS %d\nDATA binary_compressed\n"
+           % (len(arr), len(arr)))
+    with open(path, "wb") as f:
+        f.write(hdr.encode())
+        f.write(struct.pack("<II", len(comp), len(payload)))
+        f.write(comp)
+    return len(comp), len(payload)
+
+
+def test_cli_reads_binary_compressed_pcd(tmp_path):
+    z = np.load(os.path.join(GOLD, "cheff000.npz"))
+    n = 12000
+    xyz, nrm = z["xyz"][:n].copy(), z["nrm"][:n].copy()
+    xyz[100:4000] = xyz[100]                                     # long repeats: exercises back references
+    a, b = tmp_path / "c.pcd", tmp_path / "b.pcd"
+    csize, usize = write_pcd_compressed(a, xyz, nrm)
+    assert csize < usize
+    write_pcd(b, xyz, nrm, True)
+    outs = []
+    for pcd in (a, b):
+        out = tmp_path / (pcd.name + ".kp")
+        cmd = [EXE, "--pathCloud", str(pcd), "--pathRF", os.path.join(ROOT, "data", "forests", "synth200k_a5b6_t10.yaml.gz"),
+               "--pathKP=%s" % out, "--radiusFeatures", "%.9g" % float(z["r_feat"]), "--radiusNMS", "%.9g" % float(z["r_nms"]),
+               "-t", "0.85", "--annuli", "5", "--bins", "6", "--json"]
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, res.stderr
+        outs.append(open(out).read())
+    assert outs[0] == outs[1] and outs[0].count("\n") > 12
+    bad = tmp_path / "bad.pcd"
+    raw = open(a, "rb").read()
+    open(bad, "wb").write(raw[:-50])
+    res = subprocess.run([EXE, "--pathCloud", str(bad), "--pathRF", os.path.join(GOLD, "small_forest.yaml.gz")],
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0 and "corrupt binary_compressed" in res.stderr
+
+
 @pytest.mark.parametrize("binary", [True, False])
 def test_cli_on_cheff_view(tmp_path, binary):
     assert os.path.exists(EXE), "TestDetector is not built (python keypoint-learning_amd/build.py)"
