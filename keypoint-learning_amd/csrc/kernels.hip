@@ -371,14 +371,12 @@ __device__ __forceinline__ float div_rn(float a, float b, float rb) {
 __device__ __forceinline__ void soft_pair(int n, float v, float dim, float half_dim, float rdim,
                                           int &k, int &p, float &w) {
     k = (int)floorf(div_rn(v, dim, rdim));
-    if (k == n) k--;
-    k = min(max(k, 0), n - 1);
+    k = min(max(k, 0), n - 1);            // includes "if (k == n) k--" (cpp:47-48, :78-79): n -> n - 1
     float center = ((float)k * dim) + half_dim;
     float wt = v - center;
     wt = div_rn(wt, dim, rdim);
     p = (wt > 0) ? k + 1 : k - 1;
-    if (p == -1) p = 0;
-    if (p == n) p = k;
+    p = min(max(p, 0), n - 1);            // p == -1 -> 0; p == n (only from k == n - 1) -> k (cpp:59-60, :88-89)
     w = fabsf(wt);
 }
 
@@ -398,12 +396,20 @@ __device__ __forceinline__ CellBox make_box(const GridDesc &g, float x, float y,
     return b;
 }
 
-// FLANN L2_Simple<float>: d = dx*dx; d += dy*dy; d += dz*dz
+// FLANN L2_Simple<float>: d = dx*dx; d += dy*dy; d += dz*dz.  x and y go through the packed
+// (2 x f32) add / multiply of gfx950 as ONE pair per candidate -- the same IEEE operations in the
+// same order; left to itself the compiler pairs components of two different candidates and pays
+// for it in register moves.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float dist2(float px, float py, float pz, const float4 &q) {
-    float dx = px - q.x, dy = py - q.y, dz = pz - q.z;
-    float d = dx * dx;
-    d += dy * dy;
+    const f32x2 pxy = {px, py}, qxy = {q.x, q.y};
+    const f32x2 dxy = pxy - qxy;
+    const f32x2 sq = dxy * dxy;
+    const float dz = pz - q.z;
+    float d = sq.x;
+    d += sq.y;
     d += dz * dz;
+    asm("" : "+v"(d));   // keeps the vectorizer from pairing this chain with another candidate's
     return d;
 }
 
@@ -422,7 +428,8 @@ __device__ __forceinline__ float dist2(float px, float py, float pz, const float
 constexpr int kLanes = 64;   // one wave per workgroup: waves never synchronise with each other
 constexpr int kMaxRows = 16; // a search box spans at most 4 x 4 rows of cells (cell edge = radius)
 
-// what one accepted neighbor adds to the histogram: 4 cells and 4 weights (hpp:342-355)
+// what one accepted neighbor adds to the histogram: 4 cells and 4 weights (hpp:342-355).  The
+// cells are byte offsets of the lane's entries from H (cell c of lane l lives at (c * 64 + l) * 4)
 struct Contribution {
     int c0, c1, c2, c3;
     float w00, w01, w10, w11;
@@ -443,28 +450,34 @@ __device__ __forceinline__ Contribution neighbor_contribution(const FeatDesc &f,
     c.w01 = bw * (1 - aw);
     c.w10 = (1 - bw) * aw;
     c.w11 = bw * aw;
-    c.c0 = a * f.B + bi;
-    c.c1 = a * f.B + bp;
-    c.c2 = ap * f.B + bi;
-    c.c3 = ap * f.B + bp;
+    const int row_bytes = f.B * (kLanes * 4), lane_bytes = (int)threadIdx.x * 4;
+    const int ra = __mul24(a, row_bytes) + lane_bytes, rap = __mul24(ap, row_bytes) + lane_bytes;
+    const int cb = bi * (kLanes * 4), cbp = bp * (kLanes * 4);
+    c.c0 = ra + cb;
+    c.c1 = ra + cbp;
+    c.c2 = rap + cb;
+    c.c3 = rap + cbp;
     return c;
 }
 
+__device__ __forceinline__ float &hist_at(float *H, int byte_offset) {
+    return *reinterpret_cast<float *>(reinterpret_cast<char *>(H) + byte_offset);
+}
+
 __device__ __forceinline__ void apply_contribution(float *H, const Contribution &c) {
-    float *h = H + threadIdx.x;
 #if defined(KPL_ABLATE) && (KPL_ABLATE & 8)
-    h[0] += (c.w00 + c.w01 + c.w10 + c.w11) * (float)(c.c0 + c.c1 + c.c2 + c.c3);   // timing experiment
+    hist_at(H, c.c0) += (c.w00 + c.w01 + c.w10 + c.w11) * (float)(c.c0 + c.c1 + c.c2 + c.c3);   // timing experiment
     return;
 #endif
-    const float v0 = h[c.c0 * kLanes], v1 = h[c.c1 * kLanes], v2 = h[c.c2 * kLanes], v3 = h[c.c3 * kLanes];
+    const float v0 = hist_at(H, c.c0), v1 = hist_at(H, c.c1), v2 = hist_at(H, c.c2), v3 = hist_at(H, c.c3);
     const float x0 = v0 + c.w00;                                                                   // hpp:350
     const float x1 = ((c.c1 == c.c0) ? x0 : v1) + c.w01;                                           // hpp:351
     const float x2 = ((c.c2 == c.c1) ? x1 : (c.c2 == c.c0) ? x0 : v2) + c.w10;                     // hpp:354
     const float x3 = ((c.c3 == c.c2) ? x2 : (c.c3 == c.c1) ? x1 : (c.c3 == c.c0) ? x0 : v3) + c.w11;  // hpp:355
-    h[c.c0 * kLanes] = x0;
-    h[c.c1 * kLanes] = x1;
-    h[c.c2 * kLanes] = x2;
-    h[c.c3 * kLanes] = x3;
+    hist_at(H, c.c0) = x0;
+    hist_at(H, c.c1) = x1;
+    hist_at(H, c.c2) = x2;
+    hist_at(H, c.c3) = x3;
 }
 
 // 16-byte / 4-byte loads addressed by a 32-bit byte offset from a wave-uniform base (one shift
@@ -475,6 +488,9 @@ __device__ __forceinline__ float4 ld16(const float4 *__restrict__ base, int idx)
 __device__ __forceinline__ int ld4(const int *__restrict__ base, int idx) {
     return *reinterpret_cast<const int *>(reinterpret_cast<const char *>(base) + ((unsigned)idx << 2));
 }
+__device__ __forceinline__ uint2 ld8(const uint2 *base, int idx) {
+    return *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(base) + ((unsigned)idx << 3));
+}
 
 constexpr int kStepW = 4;   // candidates tested per search step (4 and 8 measure the same; 4 keeps fewer loads in flight)
 constexpr int kTake = 1;    // accepted neighbors accumulated per iteration (2 and 3 measure slightly slower)
@@ -483,13 +499,14 @@ struct Cand {
     float4 q[kStepW];
 };
 
-// the kStepW candidates starting at storage position t of a row ending at t1 (indices clamped into
-// the row, so every load is issued unconditionally)
-__device__ __forceinline__ Cand load_cand(const float4 *__restrict__ pts, int t, int t1) {
-    const int last = t1 - 1;
+// the kStepW candidates starting at storage position t: ONE address, constant offsets.  Positions
+// past the end of the row hold other cells' points (or, past the last point, the kStepW - 1 padding
+// elements of the array); their accept bits are masked by the row end
+__device__ __forceinline__ Cand load_cand(const float4 *__restrict__ pts, int t) {
+    const float4 *b = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(pts) + ((unsigned)t << 4));
     Cand c;
 #pragma unroll
-    for (int j = 0; j < kStepW; ++j) c.q[j] = ld16(pts, min(t + j, last));
+    for (int j = 0; j < kStepW; ++j) c.q[j] = b[j];
     return c;
 }
 
@@ -542,7 +559,9 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
     int ri = 0;                       // rows taken from the table so far
     int t = 0, t1 = 0;                // current row: next candidate, end
     uint2 nr = rw[0];                 // next row of the table, requested ahead of its use
-    Cand pre = load_cand(pts, 0, 1);
+    // candidates of the next search step, requested one iteration ahead; two sets used alternately
+    // like the neighbor registers below
+    Cand prea = load_cand(pts, 0), preb = prea;
     int kf = 0;
     bool first_pending = true;   // the first accepted neighbor has not been dropped yet (hpp:336)
     // search steps with accepted candidates not taken yet, oldest first: (position of the step's
@@ -584,7 +603,7 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
 #else
 #define KPL_STAMP(i)
 #endif
-#define KPL_FEATURE_ITERATION(now, nxt)                                                            \
+#define KPL_FEATURE_ITERATION(now, nxt, pre, pren)                                                 \
     {                                                                                              \
         KPL_STAMP(3)                                                                               \
         /* ---- C: take the lowest accepted candidates, request their points and normals ---- */   \
@@ -641,8 +660,8 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
             t = adv ? (int)nr.x : (stp ? t + kStepW : t);                                          \
             t1 = adv ? (int)nr.y : t1;                                                             \
             ri += adv ? 1 : 0;                                                                     \
-            nr = rw[min(ri, kMaxRows - 1) * kLanes];                                               \
-            pre = load_cand(pts, min(t, t_max), max(min(t1, t_max + 1), 1));                       \
+            nr = ld8(rows, min(ri, kMaxRows - 1) * kLanes + tid);                                  \
+            pren = load_cand(pts, min(t, t_max));                                                  \
         }                                                                                          \
         KPL_STAMP(2)                                                                               \
     }
@@ -651,8 +670,8 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
 #if defined(KPL_ABLATE) && (KPL_ABLATE & 64)
         dbg_iters += 2;
 #endif
-        KPL_FEATURE_ITERATION(pa, pb)
-        KPL_FEATURE_ITERATION(pb, pa)
+        KPL_FEATURE_ITERATION(pa, pb, prea, preb)
+        KPL_FEATURE_ITERATION(pb, pa, preb, prea)
         busy = (ri < nrows) | (t < t1) | (f0 != 0u);
 #pragma unroll
         for (int k = 0; k < kTake; ++k) busy |= pa[k].valid | pb[k].valid;
