@@ -442,8 +442,7 @@ __device__ __forceinline__ Contribution neighbor_contribution(const FeatDesc &f,
     int a, ap, bi, bp;
     float aw, bw;
     soft_pair(f.A, sqrtf(d2), f.ann_dim, f.ann_half, f.ann_rdim, a, ap, aw);       // hpp:345
-    if (cosine < 0) cosine = 0;                                                    // cpp:70-73
-    if (cosine > 2) cosine = 2;
+    cosine = fminf(fmaxf(cosine, 0.0f), 2.0f);                                     // cpp:70-73
     soft_pair(f.B, cosine, f.bin_dim, f.bin_half, f.bin_rdim, bi, bp, bw);         // hpp:348
     Contribution c;
     c.w00 = (1 - bw) * (1 - aw);
@@ -503,10 +502,9 @@ struct Cand {
 // past the end of the row hold other cells' points (or, past the last point, the kStepW - 1 padding
 // elements of the array); their accept bits are masked by the row end
 __device__ __forceinline__ Cand load_cand(const float4 *__restrict__ pts, int t) {
-    const float4 *b = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(pts) + ((unsigned)t << 4));
     Cand c;
 #pragma unroll
-    for (int j = 0; j < kStepW; ++j) c.q[j] = b[j];
+    for (int j = 0; j < kStepW; ++j) c.q[j] = ld16(pts + j, t);   // uniform base + j, one 32-bit offset
     return c;
 }
 
@@ -643,7 +641,8 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
             /* search step on the candidates requested last iteration; strict d2 < r2 */           \
             unsigned m = 0u;                                                                       \
             _Pragma("unroll") for (int j_ = 0; j_ < kStepW; ++j_)                                  \
-                m |= (unsigned)((dist2(p.x, p.y, p.z, pre.q[j_]) < f.r2) & (t + j_ < t1)) << j_;   \
+                m |= (unsigned)(dist2(p.x, p.y, p.z, pre.q[j_]) < f.r2) << j_;                     \
+            m &= (1u << (min(t1 - t, kStepW) & 31)) - 1u;             /* the row ends here */         \
             m = stp ? m : 0u;                                                                      \
             kf += __popc(m);                                                                       \
             const bool drop = first_pending & (m != 0u); /* hpp:336 */                             \
