@@ -702,7 +702,10 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
 // walk "val <= thr ? left : right", double sum of leaf values in tree order, (float)sum,
 // score = 1 - sum / (T * 1.0f).  kTreeWays trees are walked at once per lane so that several
 // dependent node loads are in flight; a finished walk re-reads its leaf until the others end.
-constexpr int kTreeWays = 4;
+#ifndef KPL_TREE_WAYS
+#define KPL_TREE_WAYS 5   /* 10 trees = 2 rounds; 4 and 10 ways measure 2 % slower */
+#endif
+constexpr int kTreeWays = KPL_TREE_WAYS;
 
 template <bool STATS>
 __device__ __forceinline__ float forest_sum(const ForestDev &forest, const float *H, int &depth) {
