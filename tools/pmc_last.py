@@ -1,6 +1,7 @@
 """prints per-dispatch counter values of the kernels matching argv[2] in a rocprofv3 --pmc csv dir (largest grids last)"""
 import collections, csv, glob, sys
-f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)
+import os
+f = sorted(glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)[-1:]
 if not f:
     sys.exit("no counter_collection.csv under " + sys.argv[1])
 by = collections.OrderedDict()

@@ -2,6 +2,7 @@
 import collections
 import csv
 import glob
+import os
 import re
 import sys
 
@@ -9,7 +10,8 @@ import sys
 def summarize(d, only="kpl"):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     meta = {}
-    for f in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
+    files = sorted(glob.glob(d + "/**/*_counter_collection.csv", recursive=True), key=os.path.getmtime)
+    for f in files[-1:]:          # gpurun_out/ accumulates the files of earlier runs: newest only
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"]
             if only and only not in name:

@@ -20,9 +20,9 @@ def main():
     tag, trace, fetch, write = sys.argv[1:5]
     prof = os.path.join(ROOT, "profiles")
     os.makedirs(prof, exist_ok=True)
-    stats = glob.glob(os.path.join(trace, "**", "*_kernel_stats.csv"), recursive=True)
+    stats = sorted(glob.glob(os.path.join(trace, "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime)
     if stats:
-        shutil.copy(stats[0], os.path.join(prof, tag + "_kernel_stats.csv"))
+        shutil.copy(stats[-1], os.path.join(prof, tag + "_kernel_stats.csv"))
     out = {}
     for name, d in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write)):
         agg, meta = summarize(d)
