@@ -492,7 +492,6 @@ __device__ __forceinline__ uint2 ld8(const uint2 *base, int idx) {
 }
 
 constexpr int kStepW = 4;   // candidates tested per search step (4 and 8 measure the same; 4 keeps fewer loads in flight)
-constexpr int kTake = 1;    // accepted neighbors accumulated per iteration (2 and 3 measure slightly slower)
 
 struct Cand {
     float4 q[kStepW];
@@ -511,15 +510,18 @@ __device__ __forceinline__ Cand load_cand(const float4 *__restrict__ pts, int t)
 // Returns K_f.
 //
 // One loop, three stages per iteration, each lane taking part in the stages it has work for:
-//   C  take the (up to kTake) lowest accepted candidates of the last search step and request
-//      their points and normals -- they are accumulated NEXT iteration;
-//   A  accumulate the neighbors taken one iteration ago, in order (their data has had a whole
-//      iteration to arrive);
-//   B  if the lane has no accepted candidate left: one search step (kStepW distance tests on the
-//      candidates requested one iteration ago, the next kStepW requested), or a move to its next
+//   C  take the next accepted candidate from the lane's queue of search steps and request its
+//      point and normal -- it is accumulated NEXT iteration;
+//   A  accumulate the neighbor taken one iteration ago (its data has had a whole iteration to
+//      arrive);
+//   B  while the queue has room: one search step (kStepW distance tests on the candidates
+//      requested one iteration ago, the next kStepW requested), or a move to the lane's next
 //      non-empty row of cells (row table built once per point, next entry requested ahead).
-// A lane needs about (sum over search steps of max(1, ceil(accepted / kTake)) + non-empty rows)
-// iterations and the wave as many as its busiest lane; neighbors never go through memory.
+// A lane needs about max(K_f, search steps + non-empty rows) iterations and the wave as many as
+// its busiest lane; neighbors never go through memory.  The kernel is VALU-issue bound, so the
+// code below is written for instruction count: selects instead of branches around loads, one
+// address per search step, LDS byte offsets instead of cell indices, two register sets used
+// alternately instead of copies.
 __device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
                                               const float4 *__restrict__ nrm,
                                               const int *__restrict__ cell_start,
@@ -573,68 +575,32 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
         bool valid;
         float4 q, n;
     };
-    Taken pa[kTake], pb[kTake];
-#pragma unroll
-    for (int k = 0; k < kTake; ++k) {
-        pa[k].valid = pb[k].valid = false;
-        pa[k].q = pa[k].n = pb[k].q = pb[k].n = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    Taken pa, pb;
+    pa.valid = pb.valid = false;
+    pa.q = pa.n = pb.q = pb.n = make_float4(0.f, 0.f, 0.f, 0.f);
 #if defined(KPL_ABLATE) && (KPL_ABLATE & 64)
     int dbg_iters = 0;
 #endif
     // One iteration: C (take the next neighbor into `nxt`), A (accumulate `now`), B (search).
     // Every global load is issued unconditionally with a clamped address and its result selected
     // afterwards: a load behind a branch makes the compiler wait for it at the join.
-#if defined(KPL_ABLATE) && (KPL_ABLATE & 0x380)
-    unsigned long long dbg_t[4] = {0, 0, 0, 0};
-#define KPL_STAMP(i)                                                                               \
-    {                                                                                              \
-        unsigned long long st_;                                                                    \
-        __builtin_amdgcn_sched_barrier(0);                                                         \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_)::"memory");               \
-        __builtin_amdgcn_sched_barrier(0);                                                         \
-        dbg_t[i] += st_ - dbg_last;                                                                \
-        dbg_last = st_;                                                                            \
-    }
-    unsigned long long dbg_last;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dbg_last)::"memory");
-#else
-#define KPL_STAMP(i)
-#endif
 #define KPL_FEATURE_ITERATION(now, nxt, pre, pren)                                                 \
     {                                                                                              \
-        KPL_STAMP(3)                                                                               \
-        /* ---- C: take the lowest accepted candidates, request their points and normals ---- */   \
-        _Pragma("unroll") for (int k_ = 0; k_ < kTake; ++k_) {                                     \
-            nxt[k_].valid = f0 != 0u;                                                              \
-            const int t_ = nxt[k_].valid ? (int)(f0 >> 4) + __ffs((int)f0) - 1 : 0;                \
-            f0 &= f0 - (nxt[k_].valid ? 1u : 0u);                                                  \
-            const bool pop_ = (f0 & 15u) == 0u; /* step used up: the queue moves up */             \
-            f0 = pop_ ? f1 : f0;                                                                   \
-            f1 = pop_ ? f2 : f1;                                                                   \
-            f2 = pop_ ? 0u : f2;                                                                   \
-            nxt[k_].q = ld16(pts, t_);                                                             \
-            nxt[k_].n = ld16(nrm, t_);                                                             \
-        }                                                                                          \
-        KPL_STAMP(0)                                                                               \
-        /* ---- A: accumulate the neighbors taken last iteration, in order (hpp:338: a neighbor   \
-         * with a non-finite normal is skipped) ---- */                                            \
-        {                                                                                          \
-            bool do_[kTake], any_ = false;                                                         \
-            _Pragma("unroll") for (int k_ = 0; k_ < kTake; ++k_) {                                 \
-                do_[k_] = now[k_].valid & (now[k_].n.w != 0.0f);                                   \
-                any_ |= do_[k_];                                                                   \
-                now[k_].valid = false;                                                             \
-            }                                                                                      \
-            if (any_) { /* contributions first (independent chains), then applied in order */      \
-                Contribution c_[kTake];                                                            \
-                _Pragma("unroll") for (int k_ = 0; k_ < kTake; ++k_)                               \
-                    c_[k_] = neighbor_contribution(f, dist2(p.x, p.y, p.z, now[k_].q), np, now[k_].n); \
-                _Pragma("unroll") for (int k_ = 0; k_ < kTake; ++k_)                               \
-                    if (do_[k_]) apply_contribution(H, c_[k_]);                                    \
-            }                                                                                      \
-        }                                                                                          \
-        KPL_STAMP(1)                                                                               \
+        /* ---- C: take the lowest accepted candidate, request its point and normal ---- */        \
+        nxt.valid = f0 != 0u;                                                                      \
+        const int t_ = nxt.valid ? (int)(f0 >> 4) + __ffs((int)f0) - 1 : 0;                        \
+        f0 &= f0 - (nxt.valid ? 1u : 0u);                                                          \
+        const bool pop_ = (f0 & 15u) == 0u; /* step used up: the queue moves up */                 \
+        f0 = pop_ ? f1 : f0;                                                                       \
+        f1 = pop_ ? f2 : f1;                                                                       \
+        f2 = pop_ ? 0u : f2;                                                                       \
+        nxt.q = ld16(pts, t_);                                                                     \
+        nxt.n = ld16(nrm, t_);                                                                     \
+        /* ---- A: accumulate the neighbor taken last iteration (hpp:338: a neighbor with a      \
+         * non-finite normal is skipped) ---- */                                                   \
+        if (now.valid & (now.n.w != 0.0f))                                                         \
+            apply_contribution(H, neighbor_contribution(f, dist2(p.x, p.y, p.z, now.q), np, now.n)); \
+        now.valid = false;                                                                         \
         { /* ---- B ---- */                                                                        \
             const bool adv = (t >= t1) & (ri < nrows);                /* move to the next row */      \
             const bool stp = (f2 == 0u) & (t < t1);                   /* one search step */           \
@@ -662,21 +628,15 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
             nr = ld8(rows, min(ri, kMaxRows - 1) * kLanes + tid);                                  \
             pren = load_cand(pts, min(t, t_max));                                                  \
         }                                                                                          \
-        KPL_STAMP(2)                                                                               \
     }
-    bool busy = false;
     do {
 #if defined(KPL_ABLATE) && (KPL_ABLATE & 64)
         dbg_iters += 2;
 #endif
         KPL_FEATURE_ITERATION(pa, pb, prea, preb)
         KPL_FEATURE_ITERATION(pb, pa, preb, prea)
-        busy = (ri < nrows) | (t < t1) | (f0 != 0u);
-#pragma unroll
-        for (int k = 0; k < kTake; ++k) busy |= pa[k].valid | pb[k].valid;
-    } while (__any(busy));
+    } while (__any((ri < nrows) | (t < t1) | (f0 != 0u) | pa.valid | pb.valid));
 #undef KPL_FEATURE_ITERATION
-#undef KPL_STAMP
     for (int a = 0; a < f.A; ++a) {                                                // hpp:360-370
         float *h = H + (a * f.B) * kLanes + tid;
         float s = 0.0f;
@@ -690,10 +650,6 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
     }
 #if defined(KPL_ABLATE) && (KPL_ABLATE & 64)
     return dbg_iters;   // diagnostic build only
-#endif
-#if defined(KPL_ABLATE) && (KPL_ABLATE & 0x380)
-    // diagnostic build only: cycles spent in stage C (0x80), A (0x100), B (0x200)
-    return (int)dbg_t[(KPL_ABLATE & 0x80) ? 0 : (KPL_ABLATE & 0x100) ? 1 : 2];
 #endif
     return kf;
 }
@@ -793,7 +749,7 @@ __device__ __forceinline__ void score_wave(const ViewDev &a, int chunk, float *H
 #if defined(KPL_ABLATE) && (KPL_ABLATE & 16)
     score = (float)(__builtin_amdgcn_s_memtime() - stamp0);   // diagnostic build only
 #endif
-#if defined(KPL_ABLATE) && (KPL_ABLATE & (64 | 0x380))
+#if defined(KPL_ABLATE) && (KPL_ABLATE & 64)
     score = (float)kf;   // diagnostic build only: loop iterations / stage cycles of the wave
 #endif
     a.score_sorted[s] = score;

@@ -1,6 +1,7 @@
 #!/bin/bash
 # timing experiments: builds libkpl variants with parts of the score kernel compiled out
-# (KPL_ABLATE bit 0 = no forest walk, bit 1 = no histogram accumulation) into build/ablate/
+# (KPL_ABLATE: 1 = no forest walk, 8 = histogram update reduced to one add, 16 = score := cycles the
+# wave lived, 64 = score := iterations of the feature loop) into build/ablate/
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p build/ablate
