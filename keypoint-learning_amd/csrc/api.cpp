@@ -222,7 +222,7 @@ int prepare_index(kpl_detector *h, bool auto_cell, ViewDev &v, double cell = 0.0
         if (rc) return rc;
     }
     KPL_HIP(h, h->cid.ensure(sizeof(int) * nn));
-    KPL_HIP(h, h->tmp_idx.ensure(sizeof(int) * nn));
+    KPL_HIP(h, h->tmp_idx.ensure(sizeof(int2) * nn));
     const size_t scan_len = (size_t)(h->cells_cap > n ? h->cells_cap : n) + 1;
     KPL_HIP(h, h->scan_tmp.ensure(sizeof(int) * (scan_len / 4096 + 4)));
     KPL_HIP(h, h->pts.ensure(sizeof(float4) * nn));
@@ -239,7 +239,7 @@ int prepare_index(kpl_detector *h, bool auto_cell, ViewDev &v, double cell = 0.0
     v.cid = h->cid.as<int>();
     v.cnt = h->cnt.as<int>();
     v.cell_start = h->cell_start.as<int>();
-    v.tmp_idx = h->tmp_idx.as<int>();
+    v.tmp_idx = h->tmp_idx.as<int2>();
     v.scan_tmp = h->scan_tmp.as<int>();
     v.pts = h->pts.as<float4>();
     v.nrm = h->nrm.as<float4>();

@@ -81,7 +81,8 @@ struct ViewDev {
     int cells_cap;               // capacity of cnt / cell_start
     float cell;                  // cell edge; <= 0: derived from the bounding box (cloud resolution)
     int *cid;                    // [n] cell of original point i, -1 if not finite
-    int *cnt, *cell_start, *tmp_idx, *scan_tmp;
+    int *cnt, *cell_start, *scan_tmp;
+    int2 *tmp_idx;               // [n] (original index, cell) in arrival order inside each cell
     float4 *pts, *nrm;           // canonical storage order
     int *pos_of;
     // scoring ("runForest")

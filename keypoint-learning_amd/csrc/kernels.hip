@@ -314,12 +314,12 @@ __global__ __launch_bounds__(256) void scatter_kernel(Batch b) {
     const ViewDev &v = b.view[blockIdx.y];
     const int *cid = v.cid, *cell_start = v.cell_start, *arrival = v.pos_of;
     const int n = v.n;
-    int *tmp_idx = v.tmp_idx;
+    int2 *tmp = v.tmp_idx;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int c = cid[i];
     if (c < 0) return;
-    tmp_idx[cell_start[c] + arrival[i]] = i;
+    tmp[cell_start[c] + arrival[i]] = make_int2(i, c);   // the cell travels along: no random read of cid later
 }
 
 __global__ __launch_bounds__(256) void rank_store_kernel(Batch b) {
@@ -327,7 +327,8 @@ __global__ __launch_bounds__(256) void rank_store_kernel(Batch b) {
     const char *xyz = v.xyz, *nrm = v.nrmsrc;
     const size_t xs = v.xs, ns = v.ns;
     const int n = v.n;
-    const int *cid = v.cid, *cell_start = v.cell_start, *tmp_idx = v.tmp_idx;
+    const int *cid = v.cid, *cell_start = v.cell_start;
+    const int2 *tmp = v.tmp_idx;
     float4 *pts = v.pts, *nrmo = v.nrm;
     int *pos_of = v.pos_of;
     int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -335,11 +336,11 @@ __global__ __launch_bounds__(256) void rank_store_kernel(Batch b) {
     if (s < n && cid[s] < 0) pos_of[s] = -1;   // non-finite original point s
     const int nfinite = cell_start[g.ncells];
     if (s >= nfinite) return;
-    const int i = tmp_idx[s];
-    const int c = cid[i];
-    const int s0 = cell_start[c], s1 = cell_start[c + 1];
+    const int2 ic = tmp[s];
+    const int i = ic.x;
+    const int s0 = cell_start[ic.y], s1 = cell_start[ic.y + 1];
     int rank = 0;
-    for (int t = s0; t < s1; ++t) rank += (tmp_idx[t] < i);
+    for (int t = s0; t < s1; ++t) rank += (tmp[t].x < i);
     const int pos = s0 + rank;
     const float *p = point_at(xyz, xs, i);
     const float *q = point_at(nrm, ns, i);
@@ -1363,7 +1364,7 @@ void launch_index(const Batch &b, hipStream_t st) {
     if (nv <= 0) return;
     if (n > 0) {
         int blocks = div_up(n, 256);
-        if (blocks > 512) blocks = 512;
+        if (blocks > 64) blocks = 64;                   // 6 same-address atomics per block: keep them few
         bbox_kernel<<<dim3(blocks, nv), 256, 0, st>>>(b);
     }
     grid_setup_kernel<<<dim3(1, nv), 64, 0, st>>>(b);
