@@ -185,6 +185,17 @@ int kpl_collect_stats(kpl_detector *h, kpl_stats *out, void *stream);
 int kpl_cloud_resolution(kpl_detector *h, const void *xyz, size_t xyz_stride, int n,
                          double *resolution);
 
+/* Grid frame for a view that is a SLAB of a larger cloud (one cloud split over several GPUs; no
+ * reference counterpart, the reference is single process).  The canonical neighbor order -- and
+ * with it every float sum of the path -- is defined on the grid whose origin is the minimum of
+ * the finite points of the view.  A slab that passes the origin of the WHOLE cloud here (and keeps
+ * its points in ascending global index order) sees exactly the cells and the order the whole
+ * cloud would give, so scores of points whose radius neighborhood lies inside the slab are
+ * bit-identical to a single-GPU run.  origin must be <= the slab's own minimum (else
+ * KPL_ERR_INVALID_ARG, deferred to kpl_sync_status on the device entry points); NULL restores the
+ * automatic origin. */
+int kpl_set_grid_origin(kpl_detector *h, const float *origin);
+
 /* pcl::NormalEstimation<PointInT, NormalT> as the reference drives it, on the device:
  *   k_search > 0 (<= 32): setKSearch(k)          -- /root/reference/src/main_test_detector.cpp:162-169
  *                                                   (k = 10, default viewpoint (0,0,0), optional flip :172-179

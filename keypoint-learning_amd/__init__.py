@@ -83,6 +83,7 @@ SYMBOLS = {
     "kpl_get_timing": (C.c_int, [_vp, C.POINTER(Timing)]),
     "kpl_collect_stats": (C.c_int, [_vp, C.POINTER(Stats), _vp]),
     "kpl_cloud_resolution": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
+    "kpl_set_grid_origin": (C.c_int, [_vp, _vp]),
     "kpl_estimate_normals": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, C.c_int, C.c_double, _vp, _vp, C.c_size_t,
                                        _vp, C.c_size_t]),
     "kpl_estimate_normals_device": (C.c_int, [_vp, C.c_int, C.c_double, _vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp]),
@@ -316,6 +317,14 @@ class KeypointLearningDetector:
         res = C.c_double()
         self._check(self._lib.kpl_cloud_resolution(self._h, xyz.ctypes.data, xs, xyz.shape[0], C.byref(res)))
         return res.value
+
+    def setGridOrigin(self, origin):
+        """kpl_set_grid_origin: the whole cloud's origin for a view that is a slab of it (None = automatic)."""
+        if origin is None:
+            self._check(self._lib.kpl_set_grid_origin(self._h, None))
+        else:
+            o = np.ascontiguousarray(origin, dtype=np.float32)
+            self._check(self._lib.kpl_set_grid_origin(self._h, o.ctypes.data))
 
     def estimateNormals(self, cloud, k=10, radius=0.0, viewpoint=(0.0, 0.0, 0.0)):
         """pcl::NormalEstimation as TestDetector drives it (k-search 10) or, with k=0, as the detector's own

@@ -64,6 +64,8 @@ struct kpl_detector {
     bool bound = false;
     bool index_valid = false;
     double index_radius = 0.0;
+    bool has_origin = false;      // kpl_set_grid_origin
+    float origin[3] = {0.0f, 0.0f, 0.0f};
 
     DevBuf stage_xyz, stage_nrm, stage_idx, stage_feat;
     DevBuf dstate, cid, cnt, cell_start, tmp_idx, scan_tmp, pts, nrm, pos_of;
@@ -236,6 +238,8 @@ int prepare_index(kpl_detector *h, bool auto_cell, ViewDev &v, double cell = 0.0
     v.ds = h->dstate.as<DevState>();
     v.cells_cap = h->cells_cap;
     v.cell = auto_cell ? 0.0f : (float)(cell > 0.0 ? cell : h->prm.radius_search);
+    v.has_origin = (h->has_origin && !auto_cell) ? 1 : 0;
+    for (int k = 0; k < 3; ++k) v.origin[k] = h->origin[k];
     v.cid = h->cid.as<int>();
     v.cnt = h->cnt.as<int>();
     v.cell_start = h->cell_start.as<int>();
@@ -279,6 +283,8 @@ int sync_status(kpl_detector *h, hipStream_t st) {
     KPL_HIP(h, hipStreamSynchronize(st));
     if (h->h_state->status == kStatusGridTooLarge)
         return fail(h, KPL_ERR_GRID_TOO_LARGE, "bounding box / radius needs more than 2^28 grid cells");
+    if (h->h_state->status == kStatusBadOrigin)
+        return fail(h, KPL_ERR_INVALID_ARG, "the grid origin (kpl_set_grid_origin) exceeds the minimum of the view");
     if (h->h_state->status == kStatusCellCapacity) {
         const int64_t need = h->h_state->ncells_needed;
         h->index_valid = false;
@@ -621,6 +627,16 @@ int kpl_forest_export_arrays(const void *data, size_t len, int64_t node_cap, int
     if (left) memcpy(left, m.left.data(), sizeof(int) * nn);
     if (right) memcpy(right, m.right.data(), sizeof(int) * nn);
     if (value) memcpy(value, m.value.data(), sizeof(double) * nn);
+    return KPL_OK;
+}
+
+int kpl_set_grid_origin(kpl_detector *h, const float *origin) {
+    if (!h) return KPL_ERR_INVALID_ARG;
+    if (origin && !(std::isfinite(origin[0]) && std::isfinite(origin[1]) && std::isfinite(origin[2])))
+        return fail(h, KPL_ERR_INVALID_ARG, "grid origin must be finite");
+    h->has_origin = origin != nullptr;
+    for (int k = 0; k < 3; ++k) h->origin[k] = origin ? origin[k] : 0.0f;
+    h->index_valid = false;
     return KPL_OK;
 }
 

@@ -80,6 +80,8 @@ struct ViewDev {
     DevState *ds;
     int cells_cap;               // capacity of cnt / cell_start
     float cell;                  // cell edge; <= 0: derived from the bounding box (cloud resolution)
+    float origin[3];             // grid origin when has_origin, else the minimum of the finite points
+    int has_origin;
     int *cid;                    // [n] cell of original point i, -1 if not finite
     int *cnt, *cell_start, *scan_tmp;
     int2 *tmp_idx;               // [n] (original index, cell) in arrival order inside each cell
@@ -110,7 +112,7 @@ struct Batch {
 
 // Device-resident state of one handle: the grid descriptor is computed ON the device from the
 // bounding box, so the host never waits between the kernels of a call.
-constexpr int kStatusOk = 0, kStatusGridTooLarge = 1, kStatusCellCapacity = 2;
+constexpr int kStatusOk = 0, kStatusGridTooLarge = 1, kStatusCellCapacity = 2, kStatusBadOrigin = 3;
 constexpr long long kMaxGridCells = 1ll << 28;
 struct DevState {
     GridDesc grid;        // written by grid_setup_kernel, read by every later kernel

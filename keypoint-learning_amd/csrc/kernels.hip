@@ -123,11 +123,19 @@ __global__ void grid_setup_kernel(Batch b) {
     long long nc = any ? 1 : 0;
     int status = 0;
     for (int k = 0; k < 3; ++k) {
-        const float mn = any ? dec_f32_dev(ds->bbox[k]) : 0.0f;
+        float mn = any ? dec_f32_dev(ds->bbox[k]) : 0.0f;
         const float mx = any ? dec_f32_dev(ds->bbox[3 + k]) : 0.0f;
+        if (v.has_origin) {             // the caller's grid frame (a slab of a larger cloud)
+            if (any && !(v.origin[k] <= mn)) status = kStatusBadOrigin;
+            mn = v.origin[k];
+        }
         g.mn[k] = mn;
         g.dims[k] = 0;
         if (!any) continue;
+        if (status != 0) {
+            nc = 0;
+            break;
+        }
         const float t = floorf((mx - mn) / h);
         if (!(t < 1.0e9f)) {
             status = kStatusGridTooLarge;

@@ -45,3 +45,55 @@ def unpack_keypoints(gathered):
     g = gathered.cpu()
     cap = g.shape[1] - 1
     return [g[r, 1:1 + max(0, min(int(g[r, 0]), cap))].clone() for r in range(g.shape[0])]
+
+
+# ---- one large cloud over several GPUs ("single huge cloud"): slabs with a halo ----
+
+def slab_plan(xyz, parts, halo, axis=None):
+    """Splits a cloud into `parts` slabs along `axis` (default: the longest extent) at point-count
+    quantiles.  Slab k gets the points whose coordinate lies in [lo_k - halo, hi_k + halo); its
+    INTERIOR is [lo_k, hi_k).  With halo >= r_feat + r_nms every interior point sees, inside the slab,
+    all its NMS neighbors and all THEIR feature neighbors, so -- run with the whole cloud's grid
+    origin (kpl_set_grid_origin) -- the slab reproduces the whole-cloud scores and keypoint decisions
+    of its interior bit for bit.  Points with a non-finite coordinate belong to no slab (their score
+    is NaN anyway).
+
+    Returns (origin, plans): origin = float32[3] minimum of the finite points; plans[k] = dict with
+    'idx' (ascending global indices of the slab's points) and 'interior' (bool mask over idx)."""
+    import numpy as np
+    xyz = np.asarray(xyz, dtype=np.float32).reshape(-1, 3)
+    finite = np.isfinite(xyz).all(axis=1)
+    good = np.nonzero(finite)[0]
+    if len(good) == 0:
+        return np.zeros(3, np.float32), [dict(idx=np.zeros(0, np.int64), interior=np.zeros(0, bool)) for _ in range(parts)]
+    pts = xyz[good].astype(np.float64)
+    origin = xyz[good].min(axis=0)
+    if axis is None:
+        axis = int(np.argmax(pts.max(axis=0) - pts.min(axis=0)))
+    c = pts[:, axis]
+    cuts = np.quantile(c, np.linspace(0.0, 1.0, parts + 1)[1:-1]) if parts > 1 else np.zeros(0)
+    lo = np.concatenate([[-np.inf], cuts])
+    hi = np.concatenate([cuts, [np.inf]])
+    plans = []
+    for k in range(parts):
+        inside = (c >= lo[k] - halo) & (c < hi[k] + halo)
+        idx = good[inside]                       # ascending global index: keeps the canonical order
+        interior = (c[inside] >= lo[k]) & (c[inside] < hi[k])
+        plans.append(dict(idx=idx, interior=interior))
+    return origin, plans
+
+
+def merge_slabs(n, plans, slab_scores, slab_keypoints):
+    """Puts the interiors back together: scores[n] (NaN where no slab owns the point) and the sorted
+    global keypoint indices.  slab_scores[k] / slab_keypoints[k] are slab k's outputs (keypoints as
+    indices INTO the slab)."""
+    import numpy as np
+    scores = np.full(n, np.nan, dtype=np.float32)
+    kps = []
+    for plan, sc, kp in zip(plans, slab_scores, slab_keypoints):
+        idx, interior = plan["idx"], plan["interior"]
+        scores[idx[interior]] = np.asarray(sc, dtype=np.float32)[interior]
+        kp = np.asarray(kp, dtype=np.int64)
+        kps.append(idx[kp[interior[kp]]])
+    kp_all = np.sort(np.concatenate(kps)) if kps else np.zeros(0, np.int64)
+    return scores, kp_all.astype(np.int32)
