@@ -236,6 +236,63 @@ protected:
         output.is_dense = non_maxima_ ? true : this->input_->is_dense;       // hpp:193
     }
 
+    // hpp:267-296: the forest response of every point with finite xyz and normal, input order (one
+    // device pass with the NMS switched off; valid after initCompute(), like the reference's)
+    virtual void runForest(PointCloudOut &output) const {
+        const int n = (int)this->input_->points.size();
+        kpl_params p, saved;
+        if (kpl_get_params(handle_, &saved) != KPL_OK) return;
+        p = saved;
+        p.non_maxima = 0;
+        kpl_set_params(handle_, &p);
+        std::vector<float> scores((size_t)(n > 0 ? n : 1));
+        std::vector<int> idx((size_t)(n > 0 ? n : 1));
+        int count = 0;
+        int rc = kpl_detect(handle_, n ? &this->input_->points[0].x : nullptr, sizeof(PointInT),
+                            n ? &normals_->points[0].normal_x : nullptr, sizeof(NormalT), n,
+                            scores.data(), idx.data(), n, &count);
+        kpl_set_params(handle_, &saved);
+        if (rc != KPL_OK) {
+            report("runForest", rc);
+            return;
+        }
+        for (int k = 0; k < count; ++k) {
+            const PointInT &in = this->input_->points[idx[k]];
+            PointOutT out;
+            out.x = in.x;
+            out.y = in.y;
+            out.z = in.z;
+            out.intensity = scores[idx[k]];
+            output.points.push_back(out);
+        }
+        output.height = 1;
+        output.width = static_cast<uint32_t>(output.points.size());
+        output.is_dense = true;
+    }
+
+    // hpp:321-376: the feature row of one input point
+    kpl::FeatureMat computePointFeatures(int point_index) const {
+        kpl::FeatureMat features;
+        const int F = n_annulus_ * n_bins_;
+        std::vector<float> buf((size_t)F);
+        int rc = kpl_compute_features(handle_, &this->input_->points[0].x, sizeof(PointInT),
+                                      &normals_->points[0].normal_x, sizeof(NormalT),
+                                      (int)this->input_->points.size(), &point_index, 1, buf.data());
+        if (rc != KPL_OK) {
+            report("computePointFeatures", rc);
+            return features;
+        }
+#ifdef KPL_USE_OPENCV
+        features = cv::Mat(1, F, CV_32F);
+        std::copy(buf.begin(), buf.end(), features.ptr<float>(0));
+#else
+        features.rows = 1;
+        features.cols = F;
+        features.data.swap(buf);
+#endif
+        return features;
+    }
+
     bool report(const char *where, int rc) const {
         PCL_ERROR("[pcl::%s::%s] %s: %s\n", this->name_.c_str(), where, kpl_status_string(rc),
                   handle_ ? kpl_last_error(handle_) : "no HIP device (there is no CPU fallback)");

@@ -58,7 +58,7 @@ const char *kUsage =
     "                                with radiusFeatures, as the reference's initCompute does).\n";
 
 bool parse(int argc, char **argv, Options &o) {
-    static const char *flags[] = {"help", "flipNormals", "subSampling", "radiusInMr", "json", "printResolution", "detectorNormals"};
+    static const char *flags[] = {"help", "flipNormals", "subSampling", "radiusInMr", "json", "printResolution", "detectorNormals", "checkProtected"};
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         if (a == "-h") a = "--help";
@@ -262,6 +262,38 @@ void uniform_sampling(pcl::PointCloud<PointInT> &cloud, double leaf) {
     cloud = out;
 }
 
+// --checkProtected: a subclass reaches the protected members the reference declares
+// (runForest, computePointFeatures: /root/reference/include/KeypointLearning.h:170-177)
+struct ProbeDetector : pcl::keypoints::KeypointLearningDetector<PointInT, KeypointT> {
+    using Base = pcl::keypoints::KeypointLearningDetector<PointInT, KeypointT>;
+    ProbeDetector(int device) : Base(0.5, true, true, 0.0, 5, 10, device) {}
+    // returns the number of mismatches between runForest / computePointFeatures and compute()
+    int check(const pcl::PointCloud<PointInT> &cloud) {
+        pcl::PointCloud<KeypointT> kp, all;
+        this->compute(kp);
+        const std::vector<float> scores = this->getScores();
+        if (!this->initCompute()) return -1;
+        this->runForest(all);
+        size_t k = 0;
+        int bad = 0;
+        for (size_t i = 0; i < scores.size(); ++i) {
+            if (std::isnan(scores[i])) continue;
+            if (k >= all.size() || all[k].x != cloud[i].x || memcmp(&all[k].intensity, &scores[i], 4) != 0) ++bad;
+            ++k;
+        }
+        if (k != all.size()) ++bad;
+        pcl::PointIndices::Ptr one(new pcl::PointIndices());
+        for (int i : {0, (int)cloud.size() / 2, (int)cloud.size() - 1}) {
+            one->indices.assign(1, i);
+            kpl::FeatureMat a = this->computePointFeatures(i);
+            kpl::FeatureMat b = this->computePointsForTrainingFeatures(one);
+            this->setInputCloud(this->input_);       // (the reference resets surface_ in the call above)
+            if (a.rows != 1 || a.cols != b.cols || memcmp(a.data.data(), b.data.data(), sizeof(float) * (size_t)a.cols) != 0) ++bad;
+        }
+        return bad;
+    }
+};
+
 double seconds_since(std::chrono::steady_clock::time_point t0) {
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
@@ -334,6 +366,18 @@ int main(int argc, char **argv) {
         for (auto &n : normals->points) { n.normal_x *= -1; n.normal_y *= -1; n.normal_z *= -1; }
     }
     const double prep_s = seconds_since(t_prep);
+
+    if (vm.has("checkProtected")) {
+        ProbeDetector probe(device);
+        probe.setNAnnulus(annuli); probe.setNBins(bins); probe.setNonMaxima(true); probe.setNonMaximaDrawsRemove(false);
+        probe.setPredictionThreshold(threshold); probe.setNonMaxRadius(radius_nms); probe.setRadiusSearch(radius_features);
+        if (!probe.loadForest(path_rf)) return -1;
+        probe.setInputCloud(cloud);
+        probe.setNormals(normals);
+        const int bad = probe.check(*cloud);
+        printf("checkProtected: %d mismatches\n", bad);
+        return bad == 0 ? 0 : 2;
+    }
 
     detector->setNonMaxRadius(radius_nms);
     detector->setRadiusSearch(radius_features);

@@ -170,6 +170,20 @@ def test_cli_estimates_normals_and_resolution(tmp_path):
     assert np.array_equal(kp[:, :3], xyz[o_kp]) and np.array_equal(kp[:, 3], o_sc[o_kp])
 
 
+def test_protected_members_of_the_class(tmp_path):
+    """runForest / computePointFeatures (protected in the reference, include/KeypointLearning.h:164-177) through a
+    subclass: same scores and feature rows as the public path."""
+    z = np.load(os.path.join(GOLD, "small_case.npz"))
+    ok = np.isfinite(z["xyz"]).all(axis=1)
+    pcd = tmp_path / "small.pcd"
+    write_pcd(pcd, z["xyz"][ok], z["nrm"][ok], True)          # some normals are non-finite: those points are skipped
+    cmd = [EXE, "--pathCloud", str(pcd), "--pathRF", os.path.join(GOLD, "small_forest.yaml.gz"), "--radiusFeatures", "6",
+           "--radiusNMS", "4", "--radiusInMr", "--annuli", "5", "--bins", "6", "-t", "0.5", "--checkProtected"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "checkProtected: 0 mismatches" in res.stdout
+
+
 def test_cli_errors():
     res = subprocess.run([EXE, "--pathRF", "/nonexistent.yaml.gz"], capture_output=True, text=True)
     assert res.returncode != 0 and "impossible to load random forest" in res.stderr
