@@ -45,3 +45,24 @@ def test_snap_to_cloud():
     q = np.float32([[0.9, 0.1, 0], [0, 1.6, 0.1], [0.1, 0, 0]])
     assert train_detector.snap_to_cloud(xyz, q).tolist() == [1, 2, 0]
     assert len(train_detector.snap_to_cloud(xyz, q[:0])) == 0
+
+
+def test_ply_reader(tmp_path):
+    from tools import cloud_io
+    rng = np.random.default_rng(1)
+    xyz = rng.normal(size=(50, 3)).astype(np.float32)
+    a = tmp_path / "a.ply"
+    with open(a, "w") as f:
+        f.write("ply\nformat ascii 1.0\nelement vertex 50\nproperty float x\nproperty float y\nproperty float z\n"
+                "element face 0\nproperty list uchar int vertex_indices\nend_header\n")
+        for p in xyz:
+            f.write("%.9g %.9g %.9g\n" % tuple(p))
+    assert np.array_equal(cloud_io.read_cloud_xyz(str(a)), xyz)
+    b = tmp_path / "b.ply"
+    rec = np.zeros(50, dtype=[("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("red", "u1"), ("nx", "<f8")])
+    rec["x"], rec["y"], rec["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    with open(b, "wb") as f:
+        f.write(b"ply\nformat binary_little_endian 1.0\nelement vertex 50\nproperty float x\nproperty float y\n"
+                b"property float z\nproperty uchar red\nproperty double nx\nend_header\n")
+        f.write(rec.tobytes())
+    assert np.array_equal(cloud_io.read_cloud_xyz(str(b)), xyz)

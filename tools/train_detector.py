@@ -11,7 +11,7 @@ first 80 % of the rows (:496-499; label 0 = keypoint, 1 = not a keypoint, :405-4
 OpenCV RTrees YAML layout libkpl / cv::ml::RTrees::load read (:512).
 
 Layout of the inputs (the reference's, with '/' separators):
-    <pathDataset>/<model>/<view><ext>                 the views          (.pcd: ascii / binary, x y z)
+    <pathDataset>/<model>/<view><ext>                 the views          (.pcd or .ply, ascii / binary, x y z)
     <pathTrainingData>/<model>/positives/<view>.pcd   keypoints          (x y z [intensity])
     <pathTrainingData>/<model>/negatives/<view>.pcd   non-keypoints
 
@@ -130,7 +130,7 @@ def collect(args, log=print):
                 continue
             if not os.path.exists(neg_p):
                 raise SystemExit("Impossible to read negatives cloud for: " + name)   # :333-337 (exit)
-            xyz = cloud_io.read_pcd_xyz(os.path.join(mdir, name))
+            xyz = cloud_io.read_cloud_xyz(os.path.join(mdir, name))     # .pcd or .ply (:296-310)
             xyz = np.ascontiguousarray(xyz[np.isfinite(xyz).all(axis=1)])
             if args.subSampling:
                 xyz = np.ascontiguousarray(xyz[uniform_sampling(xyz, args.leaf)])
