@@ -89,3 +89,14 @@ def test_full_size_view_then_detect_on_estimated_normals(kpl, oracle, cases):
     o_sc, o_kp = oracle.detect(xyz, o_nrm, 5, 6, r, rn, thr, cases.oracle_forest(fa), threads=cases.usable_cores())
     assert same(ds.cpu().numpy(), o_sc)
     assert np.array_equal(dk[1:1 + int(dk[0].item())].cpu().numpy(), o_kp)
+
+
+def test_committed_fixture(kpl):
+    """no oracle in the loop: the committed normals of the small case"""
+    import os
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    z, c = np.load(os.path.join(gold, "normals_case.npz")), np.load(os.path.join(gold, "small_case.npz"))
+    det = kpl.KeypointLearningDetector()
+    nk, ck = det.estimateNormals(c["xyz"], k=int(z["k"]), viewpoint=z["viewpoint"])
+    nr, cr = det.estimateNormals(c["xyz"], k=0, radius=float(z["radius"]), viewpoint=z["viewpoint"])
+    assert same(nk, z["nrm_k"]) and same(ck, z["curv_k"]) and same(nr, z["nrm_r"]) and same(cr, z["curv_r"])

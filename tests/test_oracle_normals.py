@@ -90,3 +90,13 @@ def test_k_search_ties_are_broken_by_index():
     assert np.isfinite(n1).all()
     expect = np.float64([-0.1, 0, 1]) / np.sqrt(1.01)
     assert np.all(angle(n1, np.tile(expect, (len(g), 1))) < 1e-6)
+
+
+def test_committed_normals_fixture():
+    import os
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    z, c = np.load(os.path.join(gold, "normals_case.npz")), np.load(os.path.join(gold, "small_case.npz"))
+    nk, ck = kplo.estimate_normals(c["xyz"], k=int(z["k"]), viewpoint=z["viewpoint"])
+    nr, cr = kplo.estimate_normals(c["xyz"], k=0, radius=float(z["radius"]), viewpoint=z["viewpoint"])
+    for a, b in ((nk, z["nrm_k"]), (ck, z["curv_k"]), (nr, z["nrm_r"]), (cr, z["curv_r"])):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))

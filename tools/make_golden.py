@@ -4,6 +4,7 @@
                      functions (oracle/_ref, compiled from /root/reference/src/KeypointLearning.cpp
                      in place) -- the one part of the path that can be pinned to reference code.
   small_case.npz     seeded 40x40 cloud, forest, and the oracle's features / scores / keypoints
+  normals_case.npz   the oracle's normals (k-search and radius search) of that cloud
                      (regression anchor for the oracle and expected values for the HIP path).
   cheff000.npz       the reference's data/point_cloud_test/cheff000.pcd (a data file) with k=10
                      PCA normals and the oracle's keypoints for config 1.
@@ -97,6 +98,20 @@ def make_small_case():
     print("small_case.npz:", len(xyz), "points", {k: len(v) for k, v in out.items() if k.startswith("kp_")})
 
 
+def make_normals_case():
+    """normals of the small case's cloud: k-search 10 (TestDetector, main_test_detector.cpp:162-169) and radius
+    search (the detector's fallback, impl/KeypointLearning.hpp:125-148), viewpoint off the origin"""
+    z = np.load(os.path.join(GOLD, "small_case.npz"))
+    xyz, mr = z["xyz"], float(z["mr"])
+    vp = np.float32([3.0, -2.0, 40.0])
+    nk, ck = kplo.estimate_normals(xyz, k=10, viewpoint=vp)
+    r = f32(3 * mr)
+    nr, cr = kplo.estimate_normals(xyz, k=0, radius=r, viewpoint=vp)
+    np.savez_compressed(os.path.join(GOLD, "normals_case.npz"), viewpoint=vp, k=np.int32(10), nrm_k=nk, curv_k=ck,
+                        radius=np.float64(r), nrm_r=nr, curv_r=cr)
+    print("normals_case.npz:", len(xyz), "points,", int(np.isfinite(nk).all(1).sum()), "finite k-normals")
+
+
 def make_cheff():
     src = os.path.join(REF, "data", "point_cloud_test", "cheff000.pcd")
     xyz = cloud_io.read_pcd_xyz(src)
@@ -121,4 +136,5 @@ if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     make_pair_kat()
     make_small_case()
+    make_normals_case()
     make_cheff()
