@@ -109,6 +109,7 @@ struct Batch {
     int nviews;
     ViewDev view[kMaxBatch];
 };
+static_assert(sizeof(Batch) <= 4096, "a Batch travels as kernel arguments: 4 KB is the limit");
 
 // Device-resident state of one handle: the grid descriptor is computed ON the device from the
 // bounding box, so the host never waits between the kernels of a call.
