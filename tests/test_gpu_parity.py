@@ -269,3 +269,52 @@ def test_cloud_resolution_sum_order_fallback(kpl, oracle, cases):
     expect = oracle.cloud_resolution(both)
     assert det.cloudResolution(both) == expect
     assert det.cloudResolution(both[::-1].copy()) == oracle.cloud_resolution(both[::-1].copy())
+
+
+def test_cell_tables_grow_on_demand(kpl, oracle, cases):
+    """A sparse view needs far more grid cells than the initial tables hold: the host entry point retries by itself,
+    the asynchronous one reports KPL_ERR_RETRY once (count = -1) and succeeds on the next call."""
+    import torch
+    rng = np.random.default_rng(12)
+    xyz = rng.uniform(0, 150, size=(3000, 3)).astype(np.float32)          # ~150^3 / 1.5^3 = 1 M cells
+    xyz[:600] = rng.uniform(70, 80, size=(600, 3)).astype(np.float32)     # a dense clump so that features exist
+    nrm = rng.normal(size=(3000, 3)).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    A, B, r, rn, thr = 5, 6, 1.5, 1.0, 0.0
+    fa = cases.trained_forest(A, B)
+    o_sc, o_kp = oracle.detect(xyz, nrm, A, B, r, rn, thr, cases.oracle_forest(fa))
+    det = make_det(kpl, A, B, r, rn, thr, fa)
+    det.setInputCloud(xyz); det.setNormals(nrm)
+    _, sc = det.compute()                                                  # kpl_detect: internal retry
+    assert cases.same_bits(sc, o_sc) and np.array_equal(det.getKeypointsIndices(), o_kp)
+    det2 = make_det(kpl, A, B, r, rn, thr, fa)
+    dev = torch.device("cuda", 0)
+    dx, dn = torch.from_numpy(xyz).to(dev), torch.from_numpy(nrm).to(dev)
+    ds = torch.empty(len(xyz), dtype=torch.float32, device=dev)
+    dk = torch.zeros(len(xyz) + 1, dtype=torch.int32, device=dev)
+    det2.bindCloudDevice(dx.data_ptr(), 12, dn.data_ptr(), 12, len(xyz))
+    det2.computeDevice(ds.data_ptr(), dk[1:].data_ptr(), len(xyz), dk[0:1].data_ptr(), None)
+    assert det2.syncStatus(None) == kpl.ERR_RETRY and int(dk[0].item()) == -1
+    det2.computeDevice(ds.data_ptr(), dk[1:].data_ptr(), len(xyz), dk[0:1].data_ptr(), None)
+    assert det2.syncStatus(None) == kpl.OK
+    assert cases.same_bits(ds.cpu().numpy(), o_sc)
+    assert np.array_equal(dk[1:1 + int(dk[0].item())].cpu().numpy(), o_kp)
+
+
+def test_far_from_the_origin(kpl, oracle, cases):
+    """coordinates around 1e5 with unit spacing (a geo-referenced scan): float cell arithmetic far from zero"""
+    xyz, nrm = cases.cloud(70, 50, seed=21)
+    xyz = (xyz + np.float32([123456.0, -98765.0, 4321.0])).astype(np.float32)
+    A, B = 5, 6
+    fa = cases.trained_forest(A, B)
+    mr = oracle.cloud_resolution(xyz)
+    r, rn = float(np.float32(6 * mr)), float(np.float32(4 * mr))
+    det = make_det(kpl, A, B, r, rn, 0.5, fa)
+    det.setInputCloud(xyz); det.setNormals(nrm)
+    _, sc = det.compute()
+    o_sc, o_kp = oracle.detect(xyz, nrm, A, B, r, rn, 0.5, cases.oracle_forest(fa))
+    assert cases.same_bits(sc, o_sc) and np.array_equal(det.getKeypointsIndices(), o_kp)
+    assert det.cloudResolution(xyz) == mr
+    n1, c1 = det.estimateNormals(xyz, k=10)
+    o1, oc1 = oracle.estimate_normals(xyz, k=10)
+    assert cases.same_bits(n1, o1) and cases.same_bits(c1, oc1)
