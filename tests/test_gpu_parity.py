@@ -318,3 +318,26 @@ def test_far_from_the_origin(kpl, oracle, cases):
     n1, c1 = det.estimateNormals(xyz, k=10)
     o1, oc1 = oracle.estimate_normals(xyz, k=10)
     assert cases.same_bits(n1, o1) and cases.same_bits(c1, oc1)
+
+
+def test_largest_histogram(kpl, oracle, cases):
+    """n_annulus * n_bins = 255 is the documented limit (one byte of the packed forest node names the variable;
+    the wave's histogram is then 65 280 B of LDS); 256 is refused."""
+    xyz, nrm = cases.cloud(50, 40, seed=4)
+    mr = oracle.cloud_resolution(xyz)
+    r = float(np.float32(6 * mr))
+    det = kpl.KeypointLearningDetector()
+    det.setNAnnulus(15); det.setNBins(17); det.setRadiusSearch(r); det.setNonMaxRadius(1.0)
+    det.setInputCloud(xyz); det.setNormals(nrm)
+    q = np.arange(0, len(xyz), 9, dtype=np.int32)
+    feat = det.computePointsForTrainingFeatures(q)
+    assert cases.same_bits(feat, oracle.Grid(xyz, r).features(nrm, 15, 17, r, q))
+    fa = cases.trained_forest(15, 17, ntrees=3, max_depth=5)
+    cases.load_arrays(det, fa)
+    _, sc = det.compute()
+    o_sc, o_kp = oracle.detect(xyz, nrm, 15, 17, r, 1.0, 0.5, cases.oracle_forest(fa))
+    assert cases.same_bits(sc, o_sc) and np.array_equal(det.getKeypointsIndices(), o_kp)
+    det.setNAnnulus(16); det.setNBins(16)
+    with pytest.raises(kpl.KplError) as e:
+        det.computePointsForTrainingFeatures(q)
+    assert e.value.status == kpl.ERR_UNSUPPORTED
