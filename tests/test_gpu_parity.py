@@ -341,3 +341,15 @@ def test_largest_histogram(kpl, oracle, cases):
     with pytest.raises(kpl.KplError) as e:
         det.computePointsForTrainingFeatures(q)
     assert e.value.status == kpl.ERR_UNSUPPORTED
+
+
+def test_randomised_soak():
+    """tools/fuzz_parity.py for a few seconds (random clouds, shapes, forests, NMS modes, normals, resolution):
+    the long runs (tens of thousands of cases) are recorded in BASELINE.md."""
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "8", "5"], capture_output=True,
+                         text=True, timeout=300, cwd=root)
+    assert out.returncode == 0 and "all bit-exact" in out.stdout, out.stdout + out.stderr

@@ -1,0 +1,105 @@
+"""Randomised parity soak: random small clouds, radii, histogram shapes, forests, thresholds and NMS modes through
+libkpl and through the oracle; every score must match bit for bit and every keypoint list exactly.
+    python tools/fuzz_parity.py [seconds] [seed]
+"""
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import kplo  # noqa: E402
+from tests import helpers  # noqa: E402
+from tools import synth  # noqa: E402
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    kpl = importlib.import_module("keypoint-learning_amd")
+    rng = np.random.default_rng(seed)
+    det = kpl.KeypointLearningDetector()
+    t0, cases, points = time.time(), 0, 0
+    while time.time() - t0 < budget:
+        kind = rng.integers(0, 5)
+        if kind == 0:
+            nx, ny = int(rng.integers(1, 70)), int(rng.integers(1, 60))
+            xyz, nrm = synth.make_cloud(nx, ny, seed=int(rng.integers(1, 1 << 30)), nan_points=int(rng.integers(0, 4)),
+                                        nan_normals=int(rng.integers(0, 4)), overlap_layers=int(rng.integers(1, 4)))
+        elif kind == 1:                                # random volume
+            n = int(rng.integers(0, 2500))
+            xyz = rng.uniform(-1, 1, size=(n, 3)).astype(np.float32) * np.float32(rng.uniform(0.5, 30))
+            nrm = rng.normal(size=(n, 3)).astype(np.float32)
+        elif kind == 2:                                # lattice with exact ties and duplicates
+            g = np.stack(np.meshgrid(np.arange(int(rng.integers(2, 25))), np.arange(int(rng.integers(2, 25))), [0.0]), -1)
+            xyz = g.reshape(-1, 3).astype(np.float32)
+            xyz = np.concatenate([xyz, xyz[: len(xyz) // 3]])
+            nrm = np.tile(np.float32([[0, 0, 1]]), (len(xyz), 1))
+            nrm[::7] = np.float32([0, 0.6, 0.8])
+        elif kind == 3:                                # far from the origin, anisotropic
+            n = int(rng.integers(10, 2000))
+            xyz = (rng.uniform(0, 1, size=(n, 3)) * [200, 3, 0.5] + [5e4, -3e4, 100]).astype(np.float32)
+            nrm = rng.normal(size=(n, 3)).astype(np.float32)
+        else:                                          # clumps: very uneven cell populations
+            n = int(rng.integers(50, 3000))
+            centres = rng.uniform(-20, 20, size=(6, 3))
+            xyz = (centres[rng.integers(0, 6, size=n)] + rng.normal(0, rng.uniform(0.05, 2.0), size=(n, 3))).astype(np.float32)
+            nrm = rng.normal(size=(n, 3)).astype(np.float32)
+        if len(xyz) and rng.random() < 0.5:
+            xyz, nrm = synth.shuffle_cloud(xyz, nrm, int(rng.integers(1, 1 << 30)))
+        n = len(xyz)
+        A, B = [(5, 6), (5, 10), (8, 10), (1, 1), (2, 7), (15, 17), (3, 3)][int(rng.integers(0, 7))]
+        mr = kplo.cloud_resolution(xyz) if n > 1 else 1.0
+        mr = mr if mr > 0 else 1.0
+        r = float(np.float32(mr * rng.uniform(1.5, 9.0)))
+        rn = float(np.float32(mr * rng.uniform(0.0, 6.0)))
+        thr = float(np.float32(rng.choice([0.0, 0.3, 0.5, 0.85, 1.0])))
+        nms, draws = bool(rng.random() < 0.85), bool(rng.random() < 0.4)
+        dthr = float(np.float32(mr * rng.uniform(0, 4)))
+        fa = synth.random_forest(A * B, ntrees=int(rng.integers(1, 14)), max_depth=int(rng.integers(1, 12)),
+                                 seed=int(rng.integers(1, 1 << 30)), target_nodes_per_tree=int(rng.integers(3, 400)))
+        if rng.random() < 0.5:                         # coarse leaf values: many exact score ties
+            fa.value[:] = np.round(fa.value * 2) / 2
+        det.setNAnnulus(A); det.setNBins(B); det.setNonMaxima(nms); det.setNonMaxRadius(rn)
+        det.setNonMaximaDrawsRemove(draws); det.setNonMaximaDrawsThreshold(dthr)
+        det.setPredictionThreshold(thr); det.setRadiusSearch(r)
+        helpers.load_arrays(det, fa)
+        det.setInputCloud(np.ascontiguousarray(xyz).reshape(-1, 3)); det.setNormals(np.ascontiguousarray(nrm).reshape(-1, 3))
+        try:
+            _, sc = det.compute()
+        except kpl.KplError as e:
+            if e.status == kpl.ERR_GRID_TOO_LARGE:
+                continue
+            raise
+        o_sc, o_kp = kplo.detect(xyz, nrm, A, B, r, rn, thr, helpers.oracle_forest(fa), non_maxima=nms,
+                                 draws_remove=draws, draws_threshold=dthr)
+        ok = helpers.same_bits(sc, o_sc) and np.array_equal(det.getKeypointsIndices(), o_kp)
+        if not ok:
+            np.savez("fuzz_failure.npz", xyz=xyz, nrm=nrm, A=A, B=B, r=r, rn=rn, thr=thr, nms=nms, draws=draws, dthr=dthr,
+                     root=fa.root, var=fa.var, thrs=fa.thr, left=fa.left, right=fa.right, value=fa.value)
+            print("MISMATCH case %d kind %d n %d A %d B %d r %g rn %g thr %g nms %d draws %d -> fuzz_failure.npz"
+                  % (cases, kind, n, A, B, r, rn, thr, nms, draws))
+            return 1
+        if rng.random() < 0.25 and n > 0:               # the preparation steps as well
+            k = int(rng.integers(3, 33))
+            nk, ck = det.estimateNormals(xyz, k=k, viewpoint=(1.0, 2.0, 300.0))
+            o_nk, o_ck = kplo.estimate_normals(xyz, k=k, viewpoint=(1.0, 2.0, 300.0))
+            nr, cr = det.estimateNormals(xyz, k=0, radius=r)
+            o_nr, o_cr = kplo.estimate_normals(xyz, k=0, radius=r)
+            res_ok = det.cloudResolution(xyz) == kplo.cloud_resolution(xyz)
+            if not (helpers.same_bits(nk, o_nk) and helpers.same_bits(ck, o_ck) and helpers.same_bits(nr, o_nr)
+                    and helpers.same_bits(cr, o_cr) and res_ok):
+                np.savez("fuzz_failure.npz", xyz=xyz, k=k, r=r)
+                print("MISMATCH in normals / resolution: case %d kind %d n %d k %d r %g -> fuzz_failure.npz" % (cases, kind, n, k, r))
+                return 1
+        cases += 1
+        points += n
+    print("fuzz parity: %d cases, %d points, all bit-exact (seed %d, %.0f s)" % (cases, points, seed, time.time() - t0))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
