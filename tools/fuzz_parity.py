@@ -16,6 +16,63 @@ from tests import helpers  # noqa: E402
 from tools import synth  # noqa: E402
 
 
+def random_view(rng):
+    n = int(rng.integers(0, 1500))
+    if rng.random() < 0.5 and n > 20:
+        nx = max(2, int(np.sqrt(n)))
+        xyz, nrm = synth.make_cloud(nx, max(2, n // nx), seed=int(rng.integers(1, 1 << 30)), nan_points=int(rng.integers(0, 3)))
+    else:
+        xyz = (rng.uniform(-1, 1, size=(n, 3)) * rng.uniform(1, 20)).astype(np.float32)
+        nrm = rng.normal(size=(n, 3)).astype(np.float32)
+    return np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3), np.ascontiguousarray(nrm, dtype=np.float32).reshape(-1, 3)
+
+
+def batch_case(kpl, rng):
+    """2..8 random views with their own shapes, forests and NMS modes through kpl_compute_batch_device"""
+    import torch
+    dev = torch.device("cuda", 0)
+    k = int(rng.integers(2, 9))
+    dets, bufs, expect = [], [], []
+    for _ in range(k):
+        xyz, nrm = random_view(rng)
+        n = len(xyz)
+        A, B = [(5, 6), (5, 10), (2, 7), (1, 1)][int(rng.integers(0, 4))]
+        mr = kplo.cloud_resolution(xyz) if n > 1 else 1.0
+        mr = mr if mr > 0 else 1.0
+        r, rn = float(np.float32(mr * rng.uniform(2, 7))), float(np.float32(mr * rng.uniform(0.5, 5)))
+        thr = float(np.float32(rng.choice([0.0, 0.5, 0.85])))
+        nms, draws = bool(rng.random() < 0.8), bool(rng.random() < 0.4)
+        dthr = float(np.float32(mr * rng.uniform(0, 3)))
+        fa = synth.random_forest(A * B, ntrees=int(rng.integers(1, 12)), max_depth=int(rng.integers(1, 10)),
+                                 seed=int(rng.integers(1, 1 << 30)), target_nodes_per_tree=int(rng.integers(3, 200)))
+        det = kpl.KeypointLearningDetector()
+        det.setNAnnulus(A); det.setNBins(B); det.setNonMaxima(nms); det.setNonMaxRadius(rn)
+        det.setNonMaximaDrawsRemove(draws); det.setNonMaximaDrawsThreshold(dthr)
+        det.setPredictionThreshold(thr); det.setRadiusSearch(r)
+        helpers.load_arrays(det, fa)
+        dx = torch.from_numpy(xyz).to(dev) if n else torch.zeros(1, 3, device=dev)
+        dn = torch.from_numpy(nrm).to(dev) if n else torch.zeros(1, 3, device=dev)
+        ds = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
+        dk = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+        det.bindCloudDevice(dx.data_ptr(), 12, dn.data_ptr(), 12, n)
+        dets.append(det); bufs.append((dx, dn, ds, dk, n))
+        expect.append(kplo.detect(xyz, nrm, A, B, r, rn, thr, helpers.oracle_forest(fa), non_maxima=nms,
+                                  draws_remove=draws, draws_threshold=dthr))
+    args = (dets, [b[2].data_ptr() for b in bufs], [b[3][1:].data_ptr() if b[4] else None for b in bufs],
+            [b[4] for b in bufs], [b[3][0:1].data_ptr() for b in bufs])
+    for attempt in range(2):
+        kpl.compute_batch_device(*args, None)
+        torch.cuda.synchronize()
+        st = [d.syncStatus(None) for d in dets]
+        if all(x == kpl.OK for x in st):
+            break
+    for (dx, dn, ds, dk, n), (o_sc, o_kp) in zip(bufs, expect):
+        cnt = int(dk[0].item())
+        if not (helpers.same_bits(ds.cpu().numpy()[:n], o_sc) and np.array_equal(dk[1:1 + cnt].cpu().numpy(), o_kp)):
+            return False
+    return True
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -95,6 +152,9 @@ def main():
                 np.savez("fuzz_failure.npz", xyz=xyz, k=k, r=r)
                 print("MISMATCH in normals / resolution: case %d kind %d n %d k %d r %g -> fuzz_failure.npz" % (cases, kind, n, k, r))
                 return 1
+        if cases % 40 == 39 and not batch_case(kpl, rng):
+            print("MISMATCH in a batched call after case %d" % cases)
+            return 1
         cases += 1
         points += n
     print("fuzz parity: %d cases, %d points, all bit-exact (seed %d, %.0f s)" % (cases, points, seed, time.time() - t0))
