@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libkpl.so")
 SOURCES = ["kernels.hip", "api.cpp", "forest.cpp"]
 HEADERS = ["kernels.h", "forest.h", os.path.join("..", "..", "include", "kpl.h")]
-TOOLS = {"TestDetector": ["test_detector_main.cpp"]}
+TOOLS = {"TestDetector": ["test_detector_main.cpp"], "DetectViews": ["batch_views_main.cpp"]}
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
@@ -50,9 +50,13 @@ def build(force=False, verbose=False):
         if not all(os.path.exists(p) for p in tpaths):
             continue
         exe = os.path.join(HERE, name)
-        if force or _stale(exe, tpaths + [LIB, os.path.join(HERE, "..", "include", "KeypointLearning.h")]):
-            cmd = ["g++", "-O2", "-std=c++14", "-I", os.path.join(HERE, "..", "include")] + tpaths + \
-                  ["-o", exe, "-L", HERE, "-lkpl", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
+        if force or _stale(exe, tpaths + [LIB, os.path.join(HERE, "..", "include", "KeypointLearning.h"), os.path.join(CSRC, "pcd_io.h")]):
+            # plain g++: the tools are ordinary host programs (DetectViews also uses the HIP runtime API for its
+            # own device buffers)
+            cmd = ["g++", "-O2", "-std=c++14", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(HERE, "..", "include"),
+                   "-I", "/opt/rocm/include"] + tpaths + \
+                  ["-o", exe, "-L", HERE, "-lkpl", "-L", "/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,$ORIGIN",
+                   "-Wl,-rpath,/opt/rocm/lib"]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

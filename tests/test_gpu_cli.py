@@ -184,6 +184,40 @@ def test_protected_members_of_the_class(tmp_path):
     assert "checkProtected: 0 mismatches" in res.stdout
 
 
+def test_detect_views_batches_like_single_runs(tmp_path):
+    """DetectViews: plain C++ over the C-ABI, caller-owned device buffers (hipMalloc), normals estimated on the
+    device into pcl::Normal records, three views in ONE kpl_compute_batch_device call -- same keypoints as the
+    oracle pipeline per view."""
+    from oracle import kplo
+    from tests import helpers
+    from tools import forest_yaml, synth
+    exe = os.path.join(ROOT, "keypoint-learning_amd", "DetectViews")
+    assert os.path.exists(exe)
+    forest = os.path.join(ROOT, "data", "forests", "synth200k_a5b6_t10.yaml.gz")
+    fa = forest_yaml.load_forest(forest)
+    files, expect = [], []
+    for k, (nx, ny) in enumerate([(60, 50), (45, 70), (80, 30)]):
+        xyz, _ = synth.make_cloud(nx, ny, seed=60 + k)
+        pcd = tmp_path / ("v%d.pcd" % k)
+        write_pcd(pcd, xyz, None, k != 1)                     # one of them ascii
+        if k == 1:
+            xyz = np.loadtxt(pcd, skiprows=11, dtype=np.float32).reshape(-1, 3)   # what the ascii round trip keeps
+        mr = kplo.cloud_resolution(xyz)
+        nrm, _ = kplo.estimate_normals(xyz, k=10)
+        r, rn = float(np.float32(6 * mr)), float(np.float32(4 * mr))
+        _, kp = kplo.detect(xyz, -nrm, 5, 6, r, rn, float(np.float32(0.85)), helpers.oracle_forest(fa))
+        files.append(str(pcd)); expect.append((len(xyz), kp))
+    cmd = [exe, "--pathRF", forest, "--radiusFeatures", "6", "--radiusNMS", "4", "--radiusInMr", "--annuli", "5", "--bins", "6",
+           "-t", "0.85", "--flipNormals", "--pathKP", str(tmp_path / "kp")] + files
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    rows = [json.loads(ln) for ln in res.stdout.strip().splitlines()]
+    assert len(rows) == 3
+    for row, (n, kp) in zip(rows, expect):
+        assert row["points"] == n and row["keypoints"] == len(kp) > 0 and row["index_checksum"] == int(kp.astype(np.int64).sum())
+    assert os.path.exists(tmp_path / "kp2.pcd")
+
+
 def test_cli_errors():
     res = subprocess.run([EXE, "--pathRF", "/nonexistent.yaml.gz"], capture_output=True, text=True)
     assert res.returncode != 0 and "impossible to load random forest" in res.stderr
