@@ -34,6 +34,10 @@ sys.path.insert(0, ROOT)
 FOREST = os.path.join(ROOT, "data", "forests", "synth200k_a5b6_t10.yaml.gz")
 A, B = 5, 6
 HBM_PEAK = 8.0e12   # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
+try:                # the metric's name is BASELINE.json's, verbatim
+    METRIC = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+except (OSError, ValueError, KeyError):
+    METRIC = "Mpoints/sec scored (feature+forest+NMS), 200k-pt cloud, 1/2/4/8 MI355X"
 
 
 def usable_cores():
@@ -314,7 +318,7 @@ def main():
         ms = elapsed * 1e3 / args.steps
         kernel = "score_kernel"
         out = {
-            "metric": "Mpoints/sec scored (feature+forest+NMS), 200k-pt cloud",
+            "metric": METRIC,
             "value": round(n * nb * world * args.steps / elapsed / 1e6, 3),
             "unit": "Mpoints/s",
             "n_gpus": world,
@@ -326,7 +330,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "configs[1]: %d-pt synthetic 2.5D views, 10-tree forest, annuli=5 bins=6 "
+            "config": {"workload": "configs[1] (single %d-pt synthetic 2.5D view, 10-tree forest), annuli=5 bins=6 "
                                    "r_feat=6*mr r_nms=4*mr thr=0.85; one step = a batch of %d independent views "
                                    "per GPU (scored in one launch); %d batches in flight on %d HIP streams"
                                    % (n, nb, ng, ng),
