@@ -436,6 +436,16 @@ int upload_view(kpl_detector *h, const void *xyz, size_t xs, const void *nrm, si
     return KPL_OK;
 }
 
+// a view staged WITHOUT normals (resolution, normal estimation) must never be mistaken for a bound
+// view afterwards, whichever way the entry point returns
+struct UnbindOnExit {
+    kpl_detector *h;
+    ~UnbindOnExit() {
+        h->bound = false;
+        h->index_valid = false;
+    }
+};
+
 }  // namespace
 
 // =============================================================================================
@@ -849,6 +859,7 @@ int kpl_estimate_normals(kpl_detector *h, const void *xyz, size_t xyz_stride, in
     // staged without normals: the index build copies whatever sits at the normal pointer
     int rc = upload_view(h, xyz, xyz_stride, xyz, xyz_stride, n);
     if (rc) return rc;
+    UnbindOnExit unbind{h};
     h->d_nrm = h->d_xyz;
     const size_t nn = (size_t)(n > 0 ? n : 1);
     KPL_HIP(h, h->stage_feat.ensure(sizeof(float) * 4 * nn));       // (nx, ny, nz, curvature) per point
@@ -862,7 +873,6 @@ int kpl_estimate_normals(kpl_detector *h, const void *xyz, size_t xyz_stride, in
         if (rc) return rc;
         break;
     }
-    h->bound = false;              // the staged view has no normals: not usable for detection
     std::vector<float> tmp(4 * nn);
     KPL_HIP(h, hipMemcpy(tmp.data(), h->stage_feat.p, sizeof(float) * 4 * (size_t)n, hipMemcpyDeviceToHost));
     for (int i = 0; i < n; ++i) {
@@ -879,6 +889,7 @@ int kpl_cloud_resolution(kpl_detector *h, const void *xyz, size_t xyz_stride, in
     // pointer, which this entry point never looks at
     int rc = upload_view(h, xyz, xyz_stride, xyz, xyz_stride, n);
     if (rc) return rc;
+    UnbindOnExit unbind{h};
     h->d_nrm = h->d_xyz;
     const size_t nn = (size_t)(n > 0 ? n : 1);
     KPL_HIP(h, h->stage_feat.ensure(sizeof(float) * nn));
@@ -898,8 +909,6 @@ int kpl_cloud_resolution(kpl_detector *h, const void *xyz, size_t xyz_stride, in
     }
     double out[2];
     KPL_HIP(h, hipMemcpy(out, h->out_scores.p, sizeof(out), hipMemcpyDeviceToHost));
-    h->bound = false;              // the staged view has no normals: not usable for detection
-    h->index_valid = false;
     if (out[1] > 0.0) *resolution = out[0] / out[1];                          // hpp:145-148
     return KPL_OK;
 }
