@@ -168,12 +168,17 @@ def main():
     # ---- parity gate (rank 0): every view's keypoint list + scores must equal the oracle's --------
     for g in range(ng):
         run_group(g)
-    if any(d.syncStatus(None) == kpl.ERR_RETRY for d in dets):   # first view of this size: tables grown
+    # first view of this size: cell tables may have to grow.  EVERY detector is synced (no short
+    # circuit: a detector that is not synced keeps its small tables) until all of them report OK
+    for attempt in range(4):
+        rcs = [d.syncStatus(None) for d in dets]
+        if kpl.ERR_RETRY not in rcs:
+            break
         torch.cuda.synchronize()
         for g in range(ng):
             run_group(g)
-        for d in dets:
-            d.syncStatus(None)
+    else:
+        raise SystemExit("cell tables still growing after 4 attempts")
     torch.cuda.synchronize()
     parity = None
     cpu = None

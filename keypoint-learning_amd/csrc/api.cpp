@@ -182,10 +182,23 @@ int install_forest(kpl_detector *h, ForestModel &&m) {
     if (!flatten_forest(m, flat, err)) return fail(h, KPL_ERR_FOREST_PARSE, "forest: %s", err.c_str());
     int rc = use_device(h);
     if (rc) return rc;
-    KPL_HIP(h, h->d_nodes.ensure(sizeof(FlatNode) * flat.nodes.size()));
-    KPL_HIP(h, h->d_roots.ensure(sizeof(uint32_t) * flat.roots.size()));
-    KPL_HIP(h, hipMemcpy(h->d_nodes.p, flat.nodes.data(), sizeof(FlatNode) * flat.nodes.size(), hipMemcpyHostToDevice));
-    KPL_HIP(h, hipMemcpy(h->d_roots.p, flat.roots.data(), sizeof(uint32_t) * flat.roots.size(), hipMemcpyHostToDevice));
+    // the new device copy is complete before the handle sees any of it: a failure on the way
+    // leaves the previous forest (host and device side) in place
+    DevBuf nodes, roots;
+    hipError_t e = nodes.ensure(sizeof(FlatNode) * flat.nodes.size());
+    if (e == hipSuccess) e = roots.ensure(sizeof(uint32_t) * flat.roots.size());
+    if (e == hipSuccess) e = hipMemcpy(nodes.p, flat.nodes.data(), sizeof(FlatNode) * flat.nodes.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(roots.p, flat.roots.data(), sizeof(uint32_t) * flat.roots.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        nodes.release();
+        roots.release();
+        return fail(h, KPL_ERR_DEVICE, "forest upload failed: %s", hipGetErrorString(e));
+    }
+    KPL_HIP(h, hipDeviceSynchronize());     // no kernel of an earlier call still walks the old nodes
+    h->d_nodes.release();
+    h->d_roots.release();
+    h->d_nodes = nodes;
+    h->d_roots = roots;
     h->model = std::move(m);
     h->flat = std::move(flat);
     h->has_forest = true;
@@ -227,7 +240,7 @@ int prepare_index(kpl_detector *h, bool auto_cell, ViewDev &v, double cell = 0.0
     KPL_HIP(h, h->tmp_idx.ensure(sizeof(int2) * nn));
     const size_t scan_len = (size_t)(h->cells_cap > n ? h->cells_cap : n) + 1;
     KPL_HIP(h, h->scan_tmp.ensure(sizeof(int) * (scan_len / 4096 + 4)));
-    KPL_HIP(h, h->pts.ensure(sizeof(float4) * nn));
+    KPL_HIP(h, h->pts.ensure(pts_bytes(n)));            // incl. the tail the search steps read past the last point
     KPL_HIP(h, h->nrm.ensure(sizeof(float4) * nn));
     KPL_HIP(h, h->pos_of.ensure(sizeof(int) * nn));
     v.xyz = h->d_xyz;

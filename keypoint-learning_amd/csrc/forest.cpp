@@ -404,7 +404,11 @@ bool flatten_forest(const ForestModel &m, FlatForest &out, std::string &err) {
             FlatNode fn;
             if (m.var[it.src] < 0) {
                 const float v = (float)m.value[it.src];
-                if ((double)v != m.value[it.src]) { err = "leaf value is not exactly a float"; return false; }
+                // (double)v != value also rejects NaN; +-Inf leaves would make the tree sum Inf - Inf = NaN
+                if (!std::isfinite(m.value[it.src]) || (double)v != m.value[it.src]) {
+                    err = "leaf value is not a finite float";
+                    return false;
+                }
                 memcpy(&fn.x, &v, 4);
                 fn.y = kLeafVar << 24;
             } else {

@@ -134,9 +134,11 @@ void launch_score(const Batch &b, hipStream_t st);
 // all zero on entry to a detect call; the compaction leaves them zeroed again
 void launch_post(const Batch &b, hipStream_t st);
 
+// bytes of pts[] for a view of n points: a search step of the feature code loads a fixed number of
+// consecutive candidates from one address, so the array carries that many elements of tail
+size_t pts_bytes(int n);
 // bytes of row-table scratch the feature code needs for `nqueries` query slots
 size_t rowtab_bytes(int nqueries);
-int score_block_size(int F);
 // features of listed points -> out[m*F]
 void launch_features(const float4 *pts, const float4 *nrm, const int *cell_start,
                      const int *pos_of, const DevState *ds, FeatDesc f, const int *query, int m, int n,

@@ -8,6 +8,10 @@
 // /root/reference/src/KeypointLearning.cpp:41-92; per-kernel citations below.
 #include "kernels.h"
 
+#ifdef KPL_ABLATE
+#error "KPL_ABLATE timing experiments are not part of libkpl: build them from a scratch copy of this file"
+#endif
+
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -430,10 +434,6 @@ __device__ __forceinline__ float dist2(float px, float py, float pz, const float
 // walks its own non-empty rows of cells back to back with the next search step's 16-B loads
 // always in flight; the expensive part (sqrt, two soft assignments, 4 histogram adds) only ever
 // runs on accepted neighbors -- see point_features.
-// The 4 adds of one neighbor may hit the same cell (pair == index at the range ends -- the common
-// case for bin 0); the cells are read once, the adds are forwarded through registers in the
-// reference's order (hpp:350-355) and written back in order, so the float result is exactly the
-// one the sequential "+=" chain gives while only one LDS round trip sits on the critical path.
 constexpr int kLanes = 64;   // one wave per workgroup: waves never synchronise with each other
 constexpr int kMaxRows = 16; // a search box spans at most 4 x 4 rows of cells (cell edge = radius)
 
@@ -472,11 +472,14 @@ __device__ __forceinline__ float &hist_at(float *H, int byte_offset) {
     return *reinterpret_cast<float *>(reinterpret_cast<char *>(H) + byte_offset);
 }
 
+// The 4 adds of one neighbor may hit the same cell (pair == index at the range ends -- the common
+// case for bin 0); the cells are read once, the adds are forwarded through registers in the
+// reference's order (hpp:350-355) and written back in order, so the float result is exactly the
+// one the sequential "+=" chain gives while only one LDS round trip sits on the critical path.
+// (Four ds_add_f32 give the same bits -- the LDS adder rounds like v_add_f32 and one wave's DS
+// instructions execute in order -- but LDS float atomics run at a fraction of the plain read /
+// write rate: the score kernel took 2.3x as long with them, profiles/r02_notes.md.)
 __device__ __forceinline__ void apply_contribution(float *H, const Contribution &c) {
-#if defined(KPL_ABLATE) && (KPL_ABLATE & 8)
-    hist_at(H, c.c0) += (c.w00 + c.w01 + c.w10 + c.w11) * (float)(c.c0 + c.c1 + c.c2 + c.c3);   // timing experiment
-    return;
-#endif
     const float v0 = hist_at(H, c.c0), v1 = hist_at(H, c.c1), v2 = hist_at(H, c.c2), v3 = hist_at(H, c.c3);
     const float x0 = v0 + c.w00;                                                                   // hpp:350
     const float x1 = ((c.c1 == c.c0) ? x0 : v1) + c.w01;                                           // hpp:351
@@ -587,9 +590,6 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
     Taken pa, pb;
     pa.valid = pb.valid = false;
     pa.q = pa.n = pb.q = pb.n = make_float4(0.f, 0.f, 0.f, 0.f);
-#if defined(KPL_ABLATE) && (KPL_ABLATE & 64)
-    int dbg_iters = 0;
-#endif
     // One iteration: C (take the next neighbor into `nxt`), A (accumulate `now`), B (search).
     // Every global load is issued unconditionally with a clamped address and its result selected
     // afterwards: a load behind a branch makes the compiler wait for it at the join.
@@ -639,9 +639,6 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
         }                                                                                          \
     }
     do {
-#if defined(KPL_ABLATE) && (KPL_ABLATE & 64)
-        dbg_iters += 2;
-#endif
         KPL_FEATURE_ITERATION(pa, pb, prea, preb)
         KPL_FEATURE_ITERATION(pb, pa, preb, prea)
     } while (__any((ri < nrows) | (t < t1) | (f0 != 0u) | pa.valid | pb.valid));
@@ -657,9 +654,6 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
         if (nr > 0)
             for (int k = 0; k < f.B; ++k) h[k * kLanes] = h[k * kLanes] / nr;
     }
-#if defined(KPL_ABLATE) && (KPL_ABLATE & 64)
-    return dbg_iters;   // diagnostic build only
-#endif
     return kf;
 }
 
@@ -727,9 +721,6 @@ __device__ __forceinline__ void score_wave(const ViewDev &a, int chunk, float *H
         const int i = chunk * kLanes + threadIdx.x;
         if (i < a.n && a.scores && a.cid[i] < 0) a.scores[i] = NAN;
     }
-#if defined(KPL_ABLATE) && (KPL_ABLATE & 16)
-    const unsigned long long stamp0 = __builtin_amdgcn_s_memtime();   // diagnostic build only
-#endif
     const int s = chunk * kLanes + threadIdx.x;
     const int nfinite = cell_start[g.ncells];
     const bool in_range = s < nfinite;
@@ -743,11 +734,7 @@ __device__ __forceinline__ void score_wave(const ViewDev &a, int chunk, float *H
     float score = NAN;
     if (scoreable) {
         int depth = 0;
-#if defined(KPL_ABLATE) && (KPL_ABLATE & 1)
-        const float fsum = 0.0f;   // timing experiment only: no forest walk
-#else
         const float fsum = forest_sum<STATS>(a.forest, H, depth);
-#endif
         score = 1 - (fsum / (a.forest.ntrees * 1.0f));                             // hpp:287
         if (STATS) {
             atomicAdd(&a.stats->sum_kf, (unsigned long long)kf);
@@ -755,19 +742,14 @@ __device__ __forceinline__ void score_wave(const ViewDev &a, int chunk, float *H
             atomicAdd(&a.stats->n_scored, 1ull);
         }
     }
-#if defined(KPL_ABLATE) && (KPL_ABLATE & 16)
-    score = (float)(__builtin_amdgcn_s_memtime() - stamp0);   // diagnostic build only
-#endif
-#if defined(KPL_ABLATE) && (KPL_ABLATE & 64)
-    score = (float)kf;   // diagnostic build only: loop iterations / stage cycles of the wave
-#endif
     a.score_sorted[s] = score;
     if (a.scores) a.scores[__float_as_int(p.w)] = score;
     // hand the point to the NMS stage (detectKeypoints, hpp:203-208): only scoreable points whose
     // score, promoted to double, is not below the threshold are ever searched
     if (scoreable) {
         if (!a.nd.non_maxima) a.flags[__float_as_int(p.w)] = 1;                     // hpp:189-196
-        else if (!((double)score < a.nd.thr)) a.cand.list[atomicAdd(a.cand.count, 1)] = s;
+        // hpp:205-207: a non-finite response is never a candidate (!pcl_isfinite(intensity))
+        else if (isfinite(score) && !((double)score < a.nd.thr)) a.cand.list[atomicAdd(a.cand.count, 1)] = s;
     }
 }
 
@@ -1391,7 +1373,7 @@ void launch_index(const Batch &b, hipStream_t st) {
     }
 }
 
-int score_block_size(int F) { (void)F; return kLanes; }
+size_t pts_bytes(int n) { return sizeof(float4) * ((size_t)(n > 0 ? n : 1) + kStepW); }
 
 size_t rowtab_bytes(int nqueries) {
     return sizeof(uint2) * (size_t)div_up(nqueries > 0 ? nqueries : 1, kLanes) * kMaxRows * kLanes;

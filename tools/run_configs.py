@@ -50,9 +50,8 @@ def time_gpu(det, xyz, nrm, reps=30, batch=10):
     def step():
         det.computeDevice(ds.data_ptr(), dk[1:].data_ptr(), n, dk[0:1].data_ptr(), st)
     step()
-    if det.syncStatus(st) == kpl.ERR_RETRY:
+    while det.syncStatus(st) == kpl.ERR_RETRY:
         step()
-        det.syncStatus(st)
     t_end = time.perf_counter() + 0.3
     while time.perf_counter() < t_end:
         step()
@@ -175,8 +174,9 @@ def cfg3():
                                      streams[g].cuda_stream)
     sweep()
     torch.cuda.synchronize()
-    for det in dets:
-        det.syncStatus(None)
+    while kpl.ERR_RETRY in [det.syncStatus(None) for det in dets]:   # every detector, no short circuit
+        sweep()
+        torch.cuda.synchronize()
     sweep(); torch.cuda.synchronize()
     ok = True
     for (xyz, nrm), det, (dx, dn, ds, dk) in zip(views, dets, bufs):
