@@ -70,7 +70,7 @@ struct kpl_detector {
     DevBuf stage_xyz, stage_nrm, stage_idx, stage_feat;
     DevBuf dstate, cid, cnt, cell_start, tmp_idx, scan_tmp, pts, nrm, pos_of;
     DevBuf score_sorted, flags, prefix, stats, out_scores, out_kp, out_count, cand_list, cand_count;
-    DevBuf draw_list, draw_count, skip, rowtab;
+    DevBuf draw_list, draw_count, skip;
     int cells_cap = 0;            // capacity (cells) of cnt / cell_start
     DevState *h_state = nullptr;  // pinned copy of the device state (status read-back)
     int *h_count = nullptr;       // pinned
@@ -329,7 +329,6 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
         KPL_HIP(h, hipMemset(h->cand_count.p, 0, sizeof(int)));
     }
     KPL_HIP(h, h->cand_list.ensure(sizeof(int) * nn));
-    KPL_HIP(h, h->rowtab.ensure(rowtab_bytes(n)));
     KPL_HIP(h, h->prefix.ensure(sizeof(int) * (nn + 2)));
     const NmsDesc nd = make_nms(h->prm);
     if (nd.draws_remove) {
@@ -349,7 +348,6 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
     v.flags = h->flags.as<int>();
     v.prefix = h->prefix.as<int>();
     v.cand = NmsList{h->cand_list.as<int>(), h->cand_count.as<int>()};
-    v.rowtab = h->rowtab.as<uint2>();
     v.draw_list = h->draw_list.as<int>();
     v.draw_count = h->draw_count.as<int>();
     v.skip = h->skip.as<int>();
@@ -529,7 +527,7 @@ void kpl_destroy(kpl_detector *h) {
                       &h->dstate, &h->cid, &h->cnt, &h->cell_start, &h->tmp_idx, &h->scan_tmp,
                       &h->pts, &h->nrm, &h->pos_of, &h->score_sorted, &h->flags, &h->prefix, &h->stats,
                       &h->out_scores, &h->out_kp, &h->out_count, &h->cand_list, &h->cand_count,
-                      &h->draw_list, &h->draw_count, &h->skip, &h->rowtab};
+                      &h->draw_list, &h->draw_count, &h->skip};
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->h_state) (void)hipHostFree(h->h_state);
@@ -723,9 +721,8 @@ int kpl_compute_features_device(kpl_detector *h, const int *d_indices, int m, fl
     hipStream_t st = (hipStream_t)stream;
     rc = ensure_index(h, st);
     if (rc) return rc;
-    KPL_HIP(h, h->rowtab.ensure(rowtab_bytes(m > h->n ? m : h->n)));
     launch_features(h->pts.as<float4>(), h->nrm.as<float4>(), h->cell_start.as<int>(), h->pos_of.as<int>(),
-                    h->dstate.as<DevState>(), make_feat(h->prm), d_indices, m, h->n, h->rowtab.as<uint2>(), d_features, st);
+                    h->dstate.as<DevState>(), make_feat(h->prm), d_indices, m, h->n, d_features, st);
     KPL_HIP(h, hipGetLastError());
     return KPL_OK;
 }

@@ -7,8 +7,6 @@
 //   cell_start[c]    first storage position of grid cell c, c = (cz*ny + cy)*nx + cx; a run of
 //                    cells along x is therefore ONE contiguous range of pts/nrm
 //   pos_of[i]        storage position of original point i, -1 if its xyz is not finite
-//   rowtab           per query lane: its (<= 16) non-empty rows of cells [first, end) -- scratch the
-//                    feature code writes once per point and re-reads one row ahead
 //   score_sorted[s]  forest response in storage order (what the NMS kernel gathers)
 //   flags[i]         1 if original point i is a keypoint (compacted in ascending i)
 // Canonical storage order = ascending (cell id, original index); it is what makes the float
@@ -95,7 +93,6 @@ struct ViewDev {
     float *scores;               // [n] out, original order (may be null)
     int *flags, *prefix;         // [n+1] keypoint flags in original order and their scan
     NmsList cand;                // points that passed the threshold
-    uint2 *rowtab;               // scratch, rowtab_bytes(n)
     // draws pass + compaction ("detectKeypoints")
     int *draw_list, *draw_count, *skip;
     int *kp_idx;
@@ -137,12 +134,10 @@ void launch_post(const Batch &b, hipStream_t st);
 // bytes of pts[] for a view of n points: a search step of the feature code loads a fixed number of
 // consecutive candidates from one address, so the array carries that many elements of tail
 size_t pts_bytes(int n);
-// bytes of row-table scratch the feature code needs for `nqueries` query slots
-size_t rowtab_bytes(int nqueries);
 // features of listed points -> out[m*F]
 void launch_features(const float4 *pts, const float4 *nrm, const int *cell_start,
                      const int *pos_of, const DevState *ds, FeatDesc f, const int *query, int m, int n,
-                     uint2 *rowtab, float *out, hipStream_t st);
+                     float *out, hipStream_t st);
 
 // cloud resolution: val[n] scratch, out[0] = ordered double sum of the 2nd-NN distances, out[1] = count
 // (out holds 3 doubles; scratch holds resolution_scratch_bytes())

@@ -435,7 +435,6 @@ __device__ __forceinline__ float dist2(float px, float py, float pz, const float
 // always in flight; the expensive part (sqrt, two soft assignments, 4 histogram adds) only ever
 // runs on accepted neighbors -- see point_features.
 constexpr int kLanes = 64;   // one wave per workgroup: waves never synchronise with each other
-constexpr int kMaxRows = 16; // a search box spans at most 4 x 4 rows of cells (cell edge = radius)
 
 // what one accepted neighbor adds to the histogram: 4 cells and 4 weights (hpp:342-355).  The
 // cells are byte offsets of the lane's entries from H (cell c of lane l lives at (c * 64 + l) * 4)
@@ -503,15 +502,20 @@ __device__ __forceinline__ uint2 ld8(const uint2 *base, int idx) {
     return *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(base) + ((unsigned)idx << 3));
 }
 
-constexpr int kStepW = 4;   // candidates tested per search step (4 and 8 measure the same; 4 keeps fewer loads in flight)
+// a wave-uniform value as a scalar-register VALUE (v_readfirstlane), not a reloadable kernel argument
+__device__ __forceinline__ int pin_i(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ float pin_f(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
+
+constexpr int kStepW = 4;      // candidates per search step: one address, kStepW 16-byte loads
+constexpr int kWordSteps = 8;  // search steps per accept word (32 candidates)
 
 struct Cand {
     float4 q[kStepW];
 };
 
 // the kStepW candidates starting at storage position t: ONE address, constant offsets.  Positions
-// past the end of the row hold other cells' points (or, past the last point, the kStepW - 1 padding
-// elements of the array); their accept bits are masked by the row end
+// past the end of the row hold other cells' points (or, past the last point, the kStepW padding
+// elements of the array, pts_bytes()); their accept bits are masked by the row end
 __device__ __forceinline__ Cand load_cand(const float4 *__restrict__ pts, int t) {
     Cand c;
 #pragma unroll
@@ -519,130 +523,180 @@ __device__ __forceinline__ Cand load_cand(const float4 *__restrict__ pts, int t)
     return c;
 }
 
+// One search step: the accept bits of kStepW candidates are shifted into w from the right, so the
+// first candidate of a word ends up in its highest bit.  Strict d2 < r2 (KdTreeFLANN::radiusSearch)
+// as the sign of RN(d2 - r2): the difference of two floats is zero only if they are equal
+// (denormals are kept), so the sign bit is set exactly when d2 < r2.
+__device__ __forceinline__ unsigned search_step(unsigned w, const float4 &p, const Cand &c, float r2) {
+#pragma unroll
+    for (int j = 0; j < kStepW; ++j) {
+        const float s = dist2(p.x, p.y, p.z, c.q[j]) - r2;
+        w = __builtin_amdgcn_alignbit(w, __float_as_uint(s), 31);   // (w << 1) | sign(s)
+    }
+    return w;
+}
+
+// LDS of one wave of the feature code: the histograms, then the accept words
+//   H[c * 64 + lane]            float  the lane's A x B histogram      (bank = lane mod 32: no conflicts)
+//   ent[e * 64 + lane]          uint2  the lane's e-th non-empty accept word: x = storage position of
+//                                      the word's first candidate, y = accept bits (first candidate
+//                                      = highest bit); `ecap` words per lane
+__host__ __device__ inline size_t feature_lds_bytes(int F, int ecap) {
+    return sizeof(float) * (size_t)F * kLanes + sizeof(uint2) * (size_t)ecap * kLanes;
+}
+
 // Returns K_f.
 //
-// One loop, three stages per iteration, each lane taking part in the stages it has work for:
-//   C  take the next accepted candidate from the lane's queue of search steps and request its
-//      point and normal -- it is accumulated NEXT iteration;
-//   A  accumulate the neighbor taken one iteration ago (its data has had a whole iteration to
-//      arrive);
-//   B  while the queue has room: one search step (kStepW distance tests on the candidates
-//      requested one iteration ago, the next kStepW requested), or a move to the lane's next
-//      non-empty row of cells (row table built once per point, next entry requested ahead).
-// A lane needs about max(K_f, search steps + non-empty rows) iterations and the wave as many as
-// its busiest lane; neighbors never go through memory.  The kernel is VALU-issue bound, so the
-// code below is written for instruction count: selects instead of branches around loads, one
-// address per search step, LDS byte offsets instead of cell indices, two register sets used
-// alternately instead of copies.
+// Two alternating phases per wave, each a loop in which every lane works on ITS OWN query:
+//   search  the lane walks the rows of cells of its search box in canonical order ((cz, cy)
+//           ascending, storage positions ascending), kStepW distance tests per step on candidates
+//           requested one step earlier, and collects the accept bits of 32 consecutive candidates
+//           in one word; non-empty words go to the lane's list in LDS.  The first accepted
+//           neighbor of the query is dropped here (hpp:336 starts at neigh_indx = 1).
+//   drain   the lane takes its accepted neighbors one per iteration, in order, from its list of
+//           words (find-first-bit), requests point and normal one iteration ahead of their use,
+//           and accumulates (exact sqrt, two soft assignments, 4 histogram adds).
+// The search runs until a lane's list is full (ecap words) or the rows are used up; the lists are
+// then drained and the search resumes.  A wave spends about max-over-lanes(candidates) / 4 cheap
+// search iterations plus max-over-lanes(K_f) accumulate iterations; neighbors never go through
+// global memory, and nothing but the histogram and the accept words lives in LDS.
 __device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
                                               const float4 *__restrict__ nrm,
                                               const int *__restrict__ cell_start,
-                                              const GridDesc &g, const FeatDesc &f, float4 p,
-                                              float4 np, float *H, uint2 *rows, bool active) {
+                                              const GridDesc &g, const FeatDesc &fin, float4 p,
+                                              float4 np, float *H, uint2 *ent, int ecap, bool active) {
     const int tid = threadIdx.x;
+    // the per-launch constants of the loops below, pinned in scalar registers: left as kernel
+    // arguments the compiler re-reads them from memory inside the accumulate loop (scalar loads whose
+    // s_waitcnt lgkmcnt(0) also waits for the LDS reads in flight)
+    FeatDesc f;
+    f.A = pin_i(fin.A);
+    f.B = pin_i(fin.B);
+    f.F = pin_i(fin.F);
+    f.support = fin.support;
+    f.ann_dim = pin_f(fin.ann_dim);
+    f.ann_half = pin_f(fin.ann_half);
+    f.ann_rdim = pin_f(fin.ann_rdim);
+    f.bin_dim = pin_f(fin.bin_dim);
+    f.bin_half = pin_f(fin.bin_half);
+    f.bin_rdim = pin_f(fin.bin_rdim);
+    f.r2 = pin_f(fin.r2);
+    f.rr = fin.rr;
     for (int c = 0; c < f.F; ++c) H[c * kLanes + tid] = 0.0f;                    // hpp:325
-    // ---- row table: the ranges of all (<= 16) rows of cells of the search box are requested at
-    // once; the non-empty ones go, in canonical (cz, cy) order, to the lane's table in scratch
-    uint2 *rw = rows + tid;
-    int nrows = 0;
-    {
-        CellBox b = make_box(g, p.x, p.y, p.z, f.rr);
-        b.hi[1] = min(b.hi[1], b.lo[1] + 3);               // cell edge = radius: never more than 4 x 4 rows
-        b.hi[2] = min(b.hi[2], b.lo[2] + 3);
-        int2 rg[kMaxRows];
-#pragma unroll
-        for (int k = 0; k < kMaxRows; ++k) {
-            const int cz = b.lo[2] + (k >> 2), cy = b.lo[1] + (k & 3);
-            const bool valid = active & (cz <= b.hi[2]) & (cy <= b.hi[1]);
-            const int row = valid ? (cz * g.dims[1] + cy) * g.dims[0] : 0;
-            const int x = ld4(cell_start, row + (valid ? b.lo[0] : 0));
-            const int y = ld4(cell_start, row + (valid ? b.hi[0] + 1 : 0));
-            rg[k] = valid ? make_int2(x, y) : make_int2(0, 0);
-        }
-#pragma unroll
-        for (int k = 0; k < kMaxRows; ++k) {
-            if (rg[k].y > rg[k].x) {
-                rw[nrows * kLanes] = make_uint2((unsigned)rg[k].x, (unsigned)rg[k].y);
-                ++nrows;
-            }
-        }
-    }
+    // ---- the lane's search box; cell edge = radius: never more than 4 x 4 rows of cells
+    CellBox b = make_box(g, p.x, p.y, p.z, f.rr);
+    b.hi[1] = min(b.hi[1], b.lo[1] + 3);
+    b.hi[2] = min(b.hi[2], b.lo[2] + 3);
+    const int ny = active ? b.hi[1] - b.lo[1] + 1 : 0, nz = active ? b.hi[2] - b.lo[2] + 1 : 0;
+    // wave-uniform extent of the row walk
+    const int wny = __any(ny > 3) ? 4 : __any(ny > 2) ? 3 : __any(ny > 1) ? 2 : __any(ny > 0) ? 1 : 0;
+    const int wnz = __any(nz > 3) ? 4 : __any(nz > 2) ? 3 : __any(nz > 1) ? 2 : __any(nz > 0) ? 1 : 0;
     const int t_max = max(cell_start[g.ncells] - 1, 0);   // last valid storage position
-    int ri = 0;                       // rows taken from the table so far
-    int t = 0, t1 = 0;                // current row: next candidate, end
-    uint2 nr = rw[0];                 // next row of the table, requested ahead of its use
-    // candidates of the next search step, requested one iteration ahead; two sets used alternately
-    // like the neighbor registers below
-    Cand prea = load_cand(pts, 0), preb = prea;
-    int kf = 0;
-    bool first_pending = true;   // the first accepted neighbor has not been dropped yet (hpp:336)
-    // search steps with accepted candidates not taken yet, oldest first: (position of the step's
-    // first candidate << 4 | accept bits); 0 = empty.  The search runs up to three steps ahead of
-    // the accumulation, so a step without a hit or a row change does not cost the lane an iteration
-    unsigned f0 = 0u, f1 = 0u, f2 = 0u;
-    // two sets of neighbor registers used alternately: while one set is accumulated, the other
-    // set's points and normals are on their way (no register copy between iterations, so nothing
-    // waits on a load in flight)
-    struct Taken {
-        bool valid;
-        float4 q, n;
+    // row slot (ky, kz) of the lane = its row of cells (lo_y + ky, lo_z + kz), x range [lo_x, hi_x]
+    auto row_range = [&](int ky, int kz, int &r0, int &r1) {
+        const bool valid = (ky < ny) & (kz < nz);
+        const int row = valid ? ((b.lo[2] + kz) * g.dims[1] + b.lo[1] + ky) * g.dims[0] : 0;
+        const int x = ld4(cell_start, row + (valid ? b.lo[0] : 0));
+        const int y = ld4(cell_start, row + (valid ? b.hi[0] + 1 : 0));
+        r0 = valid ? x : 0;
+        r1 = valid ? y : 0;
     };
-    Taken pa, pb;
-    pa.valid = pb.valid = false;
-    pa.q = pa.n = pb.q = pb.n = make_float4(0.f, 0.f, 0.f, 0.f);
-    // One iteration: C (take the next neighbor into `nxt`), A (accumulate `now`), B (search).
-    // Every global load is issued unconditionally with a clamped address and its result selected
-    // afterwards: a load behind a branch makes the compiler wait for it at the join.
-#define KPL_FEATURE_ITERATION(now, nxt, pre, pren)                                                 \
+    int ky = 0, kz = 0;                      // next row slot (wave-uniform)
+    bool slots_left = wny > 0 && wnz > 0;
+    int n0 = 0, n1 = 0;                      // its range, requested ahead
+    if (slots_left) row_range(0, 0, n0, n1);
+    int t = 0, t1 = 0;                       // current row of the lane: next candidate, end
+    Cand pre = load_cand(pts, 0);            // candidates at t, requested one step ahead
+    bool first_pending = true;               // the first accepted neighbor has not been dropped yet (hpp:336)
+    int kf = 0;
+    const int ent_last = (ecap - 1) * kLanes + tid;
+    for (;;) {
+        // ================= search: fill the lanes' word lists =================
+        int ecnt = 0;                        // words in the lane's list
+        bool full = false;
+        while (!full) {
+            if (!__any(t < t1)) {            // every lane is through with its current row
+                if (!slots_left) break;
+                t = n0;
+                t1 = n1;
+                pre = load_cand(pts, min(t, t_max));
+                if (++ky == wny) {
+                    ky = 0;
+                    ++kz;
+                }
+                slots_left = kz < wnz;
+                if (slots_left) row_range(ky, kz, n0, n1);
+                continue;
+            }
+            // one word: up to kWordSteps steps, two per round so that the two candidate sets swap roles
+            const int wbase = t;
+            unsigned w = 0u;
+            int rounds = 0;
+            do {
+                Cand nxt = load_cand(pts, min(t + kStepW, t_max));
+                w = search_step(w, p, pre, f.r2);
+                pre = load_cand(pts, min(t + 2 * kStepW, t_max));
+                w = search_step(w, p, nxt, f.r2);
+                t += 2 * kStepW;
+                ++rounds;
+            } while (rounds < kWordSteps / 2 && __any(t < t1));
+            w <<= (32 - 2 * kStepW * rounds) & 31;                       // first candidate -> bit 31
+            const int nv = min(max(t1 - wbase, 0), 32);                  // candidates of this word inside the row
+            w = nv > 0 ? (w & (0xffffffffu << ((32 - nv) & 31))) : 0u;
+            kf += __popc(w);
+            if (first_pending & (w != 0u)) {                             // hpp:336
+                w &= 0x7fffffffu >> (__clz((int)w) & 31);
+                first_pending = false;
+            }
+            if (w != 0u) {
+                ent[ecnt * kLanes + tid] = make_uint2((unsigned)wbase, w);
+                ++ecnt;
+            }
+            full = __any(ecnt == ecap);
+        }
+        // ================= drain: accumulate the listed neighbors =================
+        if (__any(ecnt > 0)) {
+            struct Taken {
+                bool valid;
+                float4 q, n;
+            };
+            Taken pa, pb;
+            pa.valid = pb.valid = false;
+            pa.q = pa.n = pb.q = pb.n = make_float4(0.f, 0.f, 0.f, 0.f);
+            int e = tid;                               // list position (in uint2 units) of the next word
+            const int e_end = ecnt * kLanes + tid;
+            unsigned w = 0u;
+            int wbase = 0;
+            uint2 nw = ent[tid];                       // next word, requested one iteration ahead
+            // One iteration: take the next neighbor into `nxt` and request its point and normal,
+            // accumulate `now` (taken one iteration ago).  Loads are issued unconditionally with a
+            // clamped address: a load behind a branch makes the compiler wait for it at the join.
+#define KPL_DRAIN_ITERATION(now, nxt)                                                              \
     {                                                                                              \
-        /* ---- C: take the lowest accepted candidate, request its point and normal ---- */        \
-        nxt.valid = f0 != 0u;                                                                      \
-        const int t_ = nxt.valid ? (int)(f0 >> 4) + __ffs((int)f0) - 1 : 0;                        \
-        f0 &= f0 - (nxt.valid ? 1u : 0u);                                                          \
-        const bool pop_ = (f0 & 15u) == 0u; /* step used up: the queue moves up */                 \
-        f0 = pop_ ? f1 : f0;                                                                       \
-        f1 = pop_ ? f2 : f1;                                                                       \
-        f2 = pop_ ? 0u : f2;                                                                       \
+        const bool refill_ = (w == 0u) & (e < e_end);                                              \
+        w = refill_ ? nw.y : w;                                                                    \
+        wbase = refill_ ? (int)nw.x : wbase;                                                       \
+        e += refill_ ? kLanes : 0;                                                                 \
+        nw = ent[min(e, ent_last)];                                                                \
+        nxt.valid = w != 0u;                                                                       \
+        const int j_ = __clz((int)w) & 31;                                                         \
+        const int t_ = nxt.valid ? wbase + j_ : 0;                                                 \
+        w &= 0x7fffffffu >> j_;                                                                    \
         nxt.q = ld16(pts, t_);                                                                     \
         nxt.n = ld16(nrm, t_);                                                                     \
-        /* ---- A: accumulate the neighbor taken last iteration (hpp:338: a neighbor with a      \
-         * non-finite normal is skipped) ---- */                                                   \
+        /* hpp:338: a neighbor with a non-finite normal is skipped */                              \
         if (now.valid & (now.n.w != 0.0f))                                                         \
             apply_contribution(H, neighbor_contribution(f, dist2(p.x, p.y, p.z, now.q), np, now.n)); \
         now.valid = false;                                                                         \
-        { /* ---- B ---- */                                                                        \
-            const bool adv = (t >= t1) & (ri < nrows);                /* move to the next row */      \
-            const bool stp = (f2 == 0u) & (t < t1);                   /* one search step */           \
-            /* search step on the candidates requested last iteration; strict d2 < r2 */           \
-            unsigned m = 0u;                                                                       \
-            _Pragma("unroll") for (int j_ = 0; j_ < kStepW; ++j_)                                  \
-                m |= (unsigned)(dist2(p.x, p.y, p.z, pre.q[j_]) < f.r2) << j_;                     \
-            m &= (1u << (min(t1 - t, kStepW) & 31)) - 1u;             /* the row ends here */         \
-            m = stp ? m : 0u;                                                                      \
-            kf += __popc(m);                                                                       \
-            const bool drop = first_pending & (m != 0u); /* hpp:336 */                             \
-            m &= m - (drop ? 1u : 0u);                                                             \
-            first_pending = first_pending & !drop;                                                 \
-            { /* a step with accepted candidates joins the queue as (position << 4 | accept bits) */ \
-                const unsigned e_ = ((unsigned)t << 4) | m;                                        \
-                const bool push_ = m != 0u, h0_ = f0 == 0u, h1_ = f1 == 0u;                        \
-                f2 = (push_ & !h0_ & !h1_) ? e_ : f2;                                              \
-                f1 = (push_ & !h0_ & h1_) ? e_ : f1;                                               \
-                f0 = (push_ & h0_) ? e_ : f0;                                                      \
-            }                                                                                      \
-            /* row change: nr was requested at least one iteration ago */                          \
-            t = adv ? (int)nr.x : (stp ? t + kStepW : t);                                          \
-            t1 = adv ? (int)nr.y : t1;                                                             \
-            ri += adv ? 1 : 0;                                                                     \
-            nr = ld8(rows, min(ri, kMaxRows - 1) * kLanes + tid);                                  \
-            pren = load_cand(pts, min(t, t_max));                                                  \
-        }                                                                                          \
     }
-    do {
-        KPL_FEATURE_ITERATION(pa, pb, prea, preb)
-        KPL_FEATURE_ITERATION(pb, pa, preb, prea)
-    } while (__any((ri < nrows) | (t < t1) | (f0 != 0u) | pa.valid | pb.valid));
-#undef KPL_FEATURE_ITERATION
+            do {
+                KPL_DRAIN_ITERATION(pa, pb)
+                KPL_DRAIN_ITERATION(pb, pa)
+            } while (__any((w != 0u) | (e < e_end) | pa.valid | pb.valid));
+#undef KPL_DRAIN_ITERATION
+        }
+        if (!slots_left && !__any(t < t1)) break;
+    }
     for (int a = 0; a < f.A; ++a) {                                                // hpp:360-370
         float *h = H + (a * f.B) * kLanes + tid;
         float s = 0.0f;
@@ -711,11 +765,10 @@ __device__ __forceinline__ float forest_sum(const ForestDev &forest, const float
 
 // One wave of the scoring stage: 64 consecutive storage positions of the view described by `a`.
 template <bool STATS>
-__device__ __forceinline__ void score_wave(const ViewDev &a, int chunk, float *H) {
+__device__ __forceinline__ void score_wave(const ViewDev &a, int chunk, float *H, uint2 *ent, int ecap) {
     const float4 *__restrict__ pts = a.pts;
     const float4 *__restrict__ nrm = a.nrm;
     const int *__restrict__ cell_start = a.cell_start;
-    uint2 *rows = a.rowtab + (size_t)chunk * kMaxRows * kLanes;
     const GridDesc g = a.ds->grid;
     {   // per ORIGINAL point: NaN for points that are not in the grid
         const int i = chunk * kLanes + threadIdx.x;
@@ -729,7 +782,7 @@ __device__ __forceinline__ void score_wave(const ViewDev &a, int chunk, float *H
     const bool scoreable = in_range && np.w != 0.0f;                               // hpp:277
     // every lane of the wave runs the feature code (wave-level votes inside); lanes without a
     // scoreable point simply have no rows
-    const int kf = point_features(pts, nrm, cell_start, g, a.f, p, np, H, rows, scoreable);
+    const int kf = point_features(pts, nrm, cell_start, g, a.f, p, np, H, ent, ecap, scoreable);
     if (!in_range) return;
     float score = NAN;
     if (scoreable) {
@@ -756,11 +809,11 @@ __device__ __forceinline__ void score_wave(const ViewDev &a, int chunk, float *H
 // Several independent views per launch (blockIdx.y = view): 200 k points are only ~3 waves per
 // SIMD, too few to hide the latencies of this kernel; a batch of views fills the chip.
 template <bool STATS>
-__global__ __launch_bounds__(kLanes) void score_kernel(Batch b) {
+__global__ __launch_bounds__(kLanes) void score_kernel(Batch b, int maxF, int ecap) {
     extern __shared__ float H[];
     const ViewDev &v = b.view[blockIdx.y];
     if ((int)blockIdx.x * kLanes >= v.n) return;
-    score_wave<STATS>(v, blockIdx.x, H);
+    score_wave<STATS>(v, blockIdx.x, H, reinterpret_cast<uint2 *>(H + maxF * kLanes), ecap);
 }
 
 // computePointsForTrainingFeatures, hpp:299-318: same feature code, sparse query list.
@@ -770,10 +823,9 @@ __global__ __launch_bounds__(kLanes) void features_kernel(const float4 *__restri
                                                           const int *__restrict__ pos_of,
                                                           const DevState *__restrict__ ds, FeatDesc f,
                                                           const int *__restrict__ query, int m,
-                                                          int n, uint2 *__restrict__ rowtab,
-                                                          float *__restrict__ out) {
+                                                          int n, int ecap, float *__restrict__ out) {
     extern __shared__ float H[];
-    uint2 *rows = rowtab + (size_t)blockIdx.x * kMaxRows * kLanes;
+    uint2 *ent = reinterpret_cast<uint2 *>(H + f.F * kLanes);
     const GridDesc g = ds->grid;
     const int qi = blockIdx.x * kLanes + threadIdx.x;
     int s = -1;
@@ -783,7 +835,7 @@ __global__ __launch_bounds__(kLanes) void features_kernel(const float4 *__restri
     }
     const float4 p = s >= 0 ? pts[s] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 np = s >= 0 ? nrm[s] : make_float4(0.f, 0.f, 0.f, 0.f);
-    point_features(pts, nrm, cell_start, g, f, p, np, H, rows, s >= 0);
+    point_features(pts, nrm, cell_start, g, f, p, np, H, ent, ecap, s >= 0);
     if (qi >= m) return;
     float *o = out + (size_t)qi * f.F;
     for (int c = 0; c < f.F; ++c) o[c] = s >= 0 ? H[c * kLanes + threadIdx.x] : NAN;
@@ -1375,8 +1427,16 @@ void launch_index(const Batch &b, hipStream_t st) {
 
 size_t pts_bytes(int n) { return sizeof(float4) * ((size_t)(n > 0 ? n : 1) + kStepW); }
 
-size_t rowtab_bytes(int nqueries) {
-    return sizeof(uint2) * (size_t)div_up(nqueries > 0 ? nqueries : 1, kLanes) * kMaxRows * kLanes;
+// Accept words per lane for a histogram of F floats per lane: as many as fit next to the histogram
+// while kMinWaves waves per CU stay resident (160 KB of LDS per CU), between 4 and 16.  A lane whose
+// neighborhood needs more words than that simply searches and drains in several rounds.
+constexpr int kLdsPerCu = 160 * 1024, kMinWavesPerCu = 12;
+static int accept_words(int F) {
+    const long long room = kLdsPerCu / kMinWavesPerCu - (long long)sizeof(float) * F * kLanes;
+    long long e = room / (long long)(sizeof(uint2) * kLanes);
+    if (e < 4) e = 4;
+    if (e > 16) e = 16;
+    return (int)e;
 }
 
 // scoring ("runForest") of every view of the batch in one launch
@@ -1389,18 +1449,19 @@ void launch_score(const Batch &b, hipStream_t st) {
         maxF = b.view[v].f.F > maxF ? b.view[v].f.F : maxF;
         stats |= b.view[v].stats != nullptr;
     }
-    const size_t lds = sizeof(float) * (size_t)maxF * kLanes;
-    if (stats) score_kernel<true><<<dim3(div_up(n, kLanes), b.nviews), kLanes, lds, st>>>(b);
-    else score_kernel<false><<<dim3(div_up(n, kLanes), b.nviews), kLanes, lds, st>>>(b);
+    const int ecap = accept_words(maxF);
+    const size_t lds = feature_lds_bytes(maxF, ecap);
+    if (stats) score_kernel<true><<<dim3(div_up(n, kLanes), b.nviews), kLanes, lds, st>>>(b, maxF, ecap);
+    else score_kernel<false><<<dim3(div_up(n, kLanes), b.nviews), kLanes, lds, st>>>(b, maxF, ecap);
 }
 
 void launch_features(const float4 *pts, const float4 *nrm, const int *cell_start,
                      const int *pos_of, const DevState *ds, FeatDesc f, const int *query, int m, int n,
-                     uint2 *rowtab, float *out, hipStream_t st) {
+                     float *out, hipStream_t st) {
     if (m <= 0) return;
-    const size_t lds = sizeof(float) * (size_t)f.F * kLanes;
-    features_kernel<<<div_up(m, kLanes), kLanes, lds, st>>>(pts, nrm, cell_start, pos_of, ds, f,
-                                                            query, m, n, rowtab, out);
+    const int ecap = accept_words(f.F);
+    features_kernel<<<div_up(m, kLanes), kLanes, feature_lds_bytes(f.F, ecap), st>>>(pts, nrm, cell_start, pos_of, ds, f,
+                                                                                    query, m, n, ecap, out);
 }
 
 // NMS, draws pass (if any view asks for it), flag scan and ordered compaction of every view
