@@ -70,7 +70,7 @@ struct kpl_detector {
     DevBuf stage_xyz, stage_nrm, stage_idx, stage_feat;
     DevBuf dstate, cid, cnt, cell_start, tmp_idx, scan_tmp, pts, nrm, pos_of;
     DevBuf score_sorted, flags, prefix, stats, out_scores, out_kp, out_count, cand_list, cand_count;
-    DevBuf draw_list, draw_count, skip;
+    DevBuf draw_list, draw_count, skip, feat;
     int cells_cap = 0;            // capacity (cells) of cnt / cell_start
     DevState *h_state = nullptr;  // pinned copy of the device state (status read-back)
     int *h_count = nullptr;       // pinned
@@ -321,6 +321,7 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
     const int n = h->n;
     const size_t nn = (size_t)(n > 0 ? n : 1);
     KPL_HIP(h, h->score_sorted.ensure(sizeof(float) * nn));
+    KPL_HIP(h, h->feat.ensure(feat_bytes(n, h->prm.n_annulus * h->prm.n_bins)));
     if (h->flags.cap < sizeof(int) * (nn + 1) || !h->cand_count.p) {
         KPL_HIP(h, hipDeviceSynchronize());
         KPL_HIP(h, h->flags.ensure(sizeof(int) * (nn + 1)));
@@ -341,8 +342,9 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
         KPL_HIP(h, h->draw_count.ensure(sizeof(int)));
     }
     v.f = make_feat(h->prm);
-    v.forest = ForestDev{h->d_nodes.as<uint2>(), h->d_roots.as<uint32_t>(), h->flat.ntrees};
+    v.forest = ForestDev{h->d_nodes.as<uint2>(), h->d_roots.as<uint32_t>(), h->flat.ntrees, (int)h->flat.nodes.size()};
     v.nd = nd;
+    v.feat = h->feat.as<float>();
     v.score_sorted = h->score_sorted.as<float>();
     v.scores = d_scores;
     v.flags = h->flags.as<int>();
@@ -527,7 +529,7 @@ void kpl_destroy(kpl_detector *h) {
                       &h->dstate, &h->cid, &h->cnt, &h->cell_start, &h->tmp_idx, &h->scan_tmp,
                       &h->pts, &h->nrm, &h->pos_of, &h->score_sorted, &h->flags, &h->prefix, &h->stats,
                       &h->out_scores, &h->out_kp, &h->out_count, &h->cand_list, &h->cand_count,
-                      &h->draw_list, &h->draw_count, &h->skip};
+                      &h->draw_list, &h->draw_count, &h->skip, &h->feat};
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->h_state) (void)hipHostFree(h->h_state);

@@ -385,48 +385,50 @@ bool flatten_forest(const ForestModel &m, FlatForest &out, std::string &err) {
     out.var_count = m.var_count;
     out.nodes.reserve((size_t)nn);
     std::vector<char> seen((size_t)nn, 0);
+    // ONE breadth-first pass over the whole forest: the roots of all trees first (root of tree t =
+    // node t), then the second level of all trees, and so on.  A node's record is emitted when it is
+    // dequeued; its two children get adjacent slots reserved at that moment.  The first k nodes are
+    // therefore the top levels of EVERY tree -- the part the forest kernel keeps in LDS.
+    struct Item { int src; uint32_t dst; int depth; };
+    std::deque<Item> q;
     for (int t = 0; t < m.ntrees(); ++t) {
         const int r = m.root[t];
         if (r < 0 || r >= nn) { err = "root index out of range"; return false; }
-        // breadth first; a node's record is emitted when it is dequeued, its two children get
-        // adjacent slots reserved at that moment
-        struct Item { int src; uint32_t dst; int depth; };
-        std::deque<Item> q;
         out.roots.push_back((uint32_t)out.nodes.size());
         out.nodes.push_back(FlatNode{0, 0});
         q.push_back(Item{r, out.roots.back(), 1});
-        while (!q.empty()) {
-            Item it = q.front();
-            q.pop_front();
-            if (seen[it.src]) { err = "node reachable twice (not a tree)"; return false; }
-            seen[it.src] = 1;
-            if (it.depth > out.max_depth) out.max_depth = it.depth;
-            FlatNode fn;
-            if (m.var[it.src] < 0) {
-                const float v = (float)m.value[it.src];
-                // (double)v != value also rejects NaN; +-Inf leaves would make the tree sum Inf - Inf = NaN
-                if (!std::isfinite(m.value[it.src]) || (double)v != m.value[it.src]) {
-                    err = "leaf value is not a finite float";
-                    return false;
-                }
-                memcpy(&fn.x, &v, 4);
-                fn.y = kLeafVar << 24;
-            } else {
-                const int l = m.left[it.src], rr = m.right[it.src];
-                if (m.var[it.src] >= m.var_count) { err = "split variable >= var_count"; return false; }
-                if (l < 0 || l >= nn || rr < 0 || rr >= nn) { err = "split node without two children"; return false; }
-                if (!std::isfinite(m.thr[it.src])) { err = "non-finite split threshold"; return false; }
-                const uint32_t lpos = (uint32_t)out.nodes.size();
-                if (lpos + 2 > kMaxFlatNodes) { err = "forest has more than 2^24 nodes"; return false; }
-                out.nodes.push_back(FlatNode{0, 0});
-                out.nodes.push_back(FlatNode{0, 0});
-                memcpy(&fn.x, &m.thr[it.src], 4);
-                fn.y = ((uint32_t)m.var[it.src] << 24) | lpos;
-                q.push_back(Item{l, lpos, it.depth + 1});
-                q.push_back(Item{rr, lpos + 1, it.depth + 1});
+    }
+    while (!q.empty()) {
+        Item it = q.front();
+        q.pop_front();
+        if (seen[it.src]) { err = "node reachable twice (not a tree)"; return false; }
+        seen[it.src] = 1;
+        if (it.depth > out.max_depth) out.max_depth = it.depth;
+        FlatNode fn;
+        if (m.var[it.src] < 0) {
+            const float v = (float)m.value[it.src];
+            // (double)v != value also rejects NaN; +-Inf leaves would make the tree sum Inf - Inf = NaN
+            if (!std::isfinite(m.value[it.src]) || (double)v != m.value[it.src]) {
+                err = "leaf value is not a finite float";
+                return false;
             }
-            out.nodes[it.dst] = fn;
+            memcpy(&fn.x, &v, 4);
+            fn.y = kLeafVar << 24;
+        } else {
+            const int l = m.left[it.src], rr = m.right[it.src];
+            if (m.var[it.src] >= m.var_count) { err = "split variable >= var_count"; return false; }
+            if (l < 0 || l >= nn || rr < 0 || rr >= nn) { err = "split node without two children"; return false; }
+            if (!std::isfinite(m.thr[it.src])) { err = "non-finite split threshold"; return false; }
+            const uint32_t lpos = (uint32_t)out.nodes.size();
+            if (lpos + 2 > kMaxFlatNodes) { err = "forest has more than 2^24 nodes"; return false; }
+            out.nodes.push_back(FlatNode{0, 0});
+            out.nodes.push_back(FlatNode{0, 0});
+            memcpy(&fn.x, &m.thr[it.src], 4);
+            fn.y = ((uint32_t)m.var[it.src] << 24) | lpos;
+            q.push_back(Item{l, lpos, it.depth + 1});
+            q.push_back(Item{rr, lpos + 1, it.depth + 1});
         }
+        out.nodes[it.dst] = fn;
     }
     return true;
 }

@@ -28,8 +28,9 @@ struct ForestModel {
 // Device layout: one 8-byte record per node.
 //   x = threshold bits (internal) or leaf value as float bits (leaf)
 //   y = [31:24] split variable (0..254; 255 = leaf)   [23:0] index of the LEFT child
-// Siblings are adjacent (right = left + 1); each tree is laid out breadth first so that the
-// levels every walk touches first are contiguous.
+// Siblings are adjacent (right = left + 1).  The whole forest is laid out breadth first, level by
+// level ACROSS the trees: node t is the root of tree t, then come the second levels of all trees,
+// and so on -- the first k nodes are the top of every tree (what the forest kernel stages in LDS).
 struct FlatNode {
     uint32_t x;
     uint32_t y;

@@ -55,9 +55,10 @@ struct NmsList {
 };
 
 struct ForestDev {
-    const uint2 *nodes;
+    const uint2 *nodes;      // level-major (forest.h): the first k nodes are the top of every tree
     const uint32_t *roots;
     int ntrees;
+    int nnodes;
 };
 
 struct StatsDev {
@@ -89,6 +90,7 @@ struct ViewDev {
     FeatDesc f;
     ForestDev forest;
     NmsDesc nd;
+    float *feat;                 // scratch, feat_bytes(n, F): the feature rows between the two scoring kernels
     float *score_sorted;         // [n] out, storage order
     float *scores;               // [n] out, original order (may be null)
     int *flags, *prefix;         // [n+1] keypoint flags in original order and their scan
@@ -131,6 +133,8 @@ void launch_score(const Batch &b, hipStream_t st);
 // all zero on entry to a detect call; the compaction leaves them zeroed again
 void launch_post(const Batch &b, hipStream_t st);
 
+// bytes of the feature scratch of a view: F floats per point, one F x 64 block per wave
+size_t feat_bytes(int n, int F);
 // bytes of pts[] for a view of n points: a search step of the feature code loads a fixed number of
 // consecutive candidates from one address, so the array carries that many elements of tail
 size_t pts_bytes(int n);

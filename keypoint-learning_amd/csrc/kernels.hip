@@ -498,9 +498,6 @@ __device__ __forceinline__ float4 ld16(const float4 *__restrict__ base, int idx)
 __device__ __forceinline__ int ld4(const int *__restrict__ base, int idx) {
     return *reinterpret_cast<const int *>(reinterpret_cast<const char *>(base) + ((unsigned)idx << 2));
 }
-__device__ __forceinline__ uint2 ld8(const uint2 *base, int idx) {
-    return *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(base) + ((unsigned)idx << 3));
-}
 
 // a wave-uniform value as a scalar-register VALUE (v_readfirstlane), not a reloadable kernel argument
 __device__ __forceinline__ int pin_i(int x) { return __builtin_amdgcn_readfirstlane(x); }
@@ -714,106 +711,163 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
 // runForest, hpp:267-296 + cv::ml::RTrees::predict(PREDICT_SUM) restated (hpp:281): per tree
 // walk "val <= thr ? left : right", double sum of leaf values in tree order, (float)sum,
 // score = 1 - sum / (T * 1.0f).  kTreeWays trees are walked at once per lane so that several
-// dependent node loads are in flight; a finished walk re-reads its leaf until the others end.
-#ifndef KPL_TREE_WAYS
-#define KPL_TREE_WAYS 5   /* 10 trees = 2 rounds; 4 and 10 ways measure 2 % slower */
-#endif
-constexpr int kTreeWays = KPL_TREE_WAYS;
+// dependent node reads are in flight; a finished walk re-reads its leaf until the others end.
+// The first `nlds` nodes of the (level-major) forest are read from LDS, deeper ones from global
+// memory: 64 lanes at 64 different nodes are 64 cache lines for one load instruction, and the
+// texture path takes about a cycle per line -- the LDS serves the same request in a few cycles.
+// The walk is written without data-dependent branches: a lane that has reached a leaf keeps
+// re-reading that leaf, the split variable of a leaf reads feature 0 and is ignored, and all node
+// reads of a level are issued before the first one is used, then all feature reads -- one LDS round
+// trip each per level for all ways together.
+constexpr int kTreeWays = 10;
 
 template <bool STATS>
-__device__ __forceinline__ float forest_sum(const ForestDev &forest, const float *H, int &depth) {
+__device__ __forceinline__ float forest_sum(const ForestDev &forest, const uint2 *lnodes, int nlds,
+                                            const float *x, int &depth) {
     double sum = 0.0;
-    const float *x = H + threadIdx.x;
+    const bool all_in_lds = nlds >= forest.nnodes;
+    const uint32_t last_lds = (uint32_t)(nlds - 1);
     for (int t0 = 0; t0 < forest.ntrees; t0 += kTreeWays) {
         uint32_t nd[kTreeWays];
-        float leaf[kTreeWays];
-        bool done[kTreeWays];
+        uint2 node[kTreeWays];
+        bool was_leaf[kTreeWays];      // STATS only: the way had reached its leaf before this read
 #pragma unroll
         for (int k = 0; k < kTreeWays; ++k) {
-            done[k] = t0 + k >= forest.ntrees;
-            nd[k] = forest.roots[done[k] ? t0 : t0 + k];
-            leaf[k] = 0.0f;
+            nd[k] = forest.roots[t0 + k < forest.ntrees ? t0 + k : t0];
+            was_leaf[k] = t0 + k >= forest.ntrees;
         }
         for (;;) {
-            uint2 node[kTreeWays];
 #pragma unroll
-            for (int k = 0; k < kTreeWays; ++k) node[k] = forest.nodes[nd[k]];
-            bool all_done = true;
+            for (int k = 0; k < kTreeWays; ++k) node[k] = lnodes[min(nd[k], last_lds)];
+            if (!all_in_lds) {      // deep nodes of a large forest: global memory, all ways issued before the first use
+                bool far_any = false;
+#pragma unroll
+                for (int k = 0; k < kTreeWays; ++k) far_any |= nd[k] > last_lds;
+                if (__any(far_any)) {
+                    uint2 far[kTreeWays];
+#pragma unroll
+                    for (int k = 0; k < kTreeWays; ++k) far[k] = forest.nodes[nd[k]];
+#pragma unroll
+                    for (int k = 0; k < kTreeWays; ++k) node[k] = nd[k] > last_lds ? far[k] : node[k];
+                }
+            }
+            float val[kTreeWays];
+            bool leaf[kTreeWays];
 #pragma unroll
             for (int k = 0; k < kTreeWays; ++k) {
                 const uint32_t var = node[k].y >> 24;
-                if (!done[k]) {
-                    if (STATS) ++depth;
-                    if (var == 255u) {
-                        leaf[k] = __uint_as_float(node[k].x);
-                        done[k] = true;
-                    } else {
-                        const float val = x[var * kLanes];
-                        nd[k] = (node[k].y & 0x00ffffffu) + (val <= __uint_as_float(node[k].x) ? 0u : 1u);
-                    }
-                }
-                all_done &= done[k];
+                leaf[k] = var == 255u;
+                val[k] = x[(leaf[k] ? 0u : var) * kLanes];
             }
-            if (all_done) break;
+            bool all_leaves = true;
+#pragma unroll
+            for (int k = 0; k < kTreeWays; ++k) {
+                const uint32_t next = (node[k].y & 0x00ffffffu) + (val[k] <= __uint_as_float(node[k].x) ? 0u : 1u);
+                if (STATS) {
+                    depth += was_leaf[k] ? 0 : 1;   // visited nodes: internal ones and the leaf, once
+                    was_leaf[k] = leaf[k];
+                }
+                nd[k] = leaf[k] ? nd[k] : next;
+                all_leaves &= leaf[k];
+            }
+            if (__all(all_leaves)) break;
         }
 #pragma unroll
         for (int k = 0; k < kTreeWays; ++k)
-            if (t0 + k < forest.ntrees) sum += (double)leaf[k];
+            if (t0 + k < forest.ntrees) sum += (double)__uint_as_float(node[k].x);
     }
     return (float)sum;
 }
 
-// One wave of the scoring stage: 64 consecutive storage positions of the view described by `a`.
-template <bool STATS>
-__device__ __forceinline__ void score_wave(const ViewDev &a, int chunk, float *H, uint2 *ent, int ecap) {
-    const float4 *__restrict__ pts = a.pts;
-    const float4 *__restrict__ nrm = a.nrm;
-    const int *__restrict__ cell_start = a.cell_start;
-    const GridDesc g = a.ds->grid;
-    {   // per ORIGINAL point: NaN for points that are not in the grid
-        const int i = chunk * kLanes + threadIdx.x;
-        if (i < a.n && a.scores && a.cid[i] < 0) a.scores[i] = NAN;
+// The scoring stage ("runForest", hpp:267-296) in two kernels, one wave = 64 consecutive storage
+// positions of a view:
+//   feature kernel -> feat[(chunk * F + c) * 64 + lane], one contiguous F x 64 block per wave
+//   forest kernel  <- the same block, staged in LDS again next to the top of the forest.
+// In one kernel the forest walk (dependent node reads, 64 different cache lines per load instruction)
+// was 26 % of the time and ran no faster on its own at 5 waves per SIMD: it is bound by the texture
+// path, not by occupancy (profiles/r02_notes.md).  On its own it can keep the forest in LDS.
+struct WavePoint {
+    int s;               // storage position
+    bool in_range, scoreable;
+    float4 p, np;
+};
+
+__device__ __forceinline__ WavePoint wave_point(const ViewDev &a, int chunk, int lane, bool want_xyz) {
+    WavePoint w;
+    w.s = chunk * kLanes + lane;
+    const int nfinite = a.cell_start[a.ds->grid.ncells];
+    w.in_range = w.s < nfinite;
+    w.np = w.in_range ? a.nrm[w.s] : make_float4(0.f, 0.f, 0.f, 0.f);
+    w.p = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (w.in_range) {
+        if (want_xyz) w.p = a.pts[w.s];
+        else w.p.w = a.pts[w.s].w;                                                  // original index only
     }
-    const int s = chunk * kLanes + threadIdx.x;
-    const int nfinite = cell_start[g.ncells];
-    const bool in_range = s < nfinite;
-    const float4 p = in_range ? pts[s] : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 np = in_range ? nrm[s] : make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool scoreable = in_range && np.w != 0.0f;                               // hpp:277
-    // every lane of the wave runs the feature code (wave-level votes inside); lanes without a
-    // scoreable point simply have no rows
-    const int kf = point_features(pts, nrm, cell_start, g, a.f, p, np, H, ent, ecap, scoreable);
-    if (!in_range) return;
-    float score = NAN;
-    if (scoreable) {
-        int depth = 0;
-        const float fsum = forest_sum<STATS>(a.forest, H, depth);
-        score = 1 - (fsum / (a.forest.ntrees * 1.0f));                             // hpp:287
-        if (STATS) {
-            atomicAdd(&a.stats->sum_kf, (unsigned long long)kf);
-            atomicAdd(&a.stats->sum_depth, (unsigned long long)depth);
-            atomicAdd(&a.stats->n_scored, 1ull);
-        }
-    }
-    a.score_sorted[s] = score;
-    if (a.scores) a.scores[__float_as_int(p.w)] = score;
-    // hand the point to the NMS stage (detectKeypoints, hpp:203-208): only scoreable points whose
-    // score, promoted to double, is not below the threshold are ever searched
-    if (scoreable) {
-        if (!a.nd.non_maxima) a.flags[__float_as_int(p.w)] = 1;                     // hpp:189-196
-        // hpp:205-207: a non-finite response is never a candidate (!pcl_isfinite(intensity))
-        else if (isfinite(score) && !((double)score < a.nd.thr)) a.cand.list[atomicAdd(a.cand.count, 1)] = s;
-    }
+    w.scoreable = w.in_range && w.np.w != 0.0f;                                    // hpp:277
+    return w;
 }
 
 // Several independent views per launch (blockIdx.y = view): 200 k points are only ~3 waves per
 // SIMD, too few to hide the latencies of this kernel; a batch of views fills the chip.
 template <bool STATS>
-__global__ __launch_bounds__(kLanes) void score_kernel(Batch b, int maxF, int ecap) {
+__global__ __launch_bounds__(kLanes) void feature_kernel(Batch b, int maxF, int ecap) {
     extern __shared__ float H[];
     const ViewDev &v = b.view[blockIdx.y];
-    if ((int)blockIdx.x * kLanes >= v.n) return;
-    score_wave<STATS>(v, blockIdx.x, H, reinterpret_cast<uint2 *>(H + maxF * kLanes), ecap);
+    const int chunk = blockIdx.x;
+    if (chunk * kLanes >= v.n) return;
+    const WavePoint w = wave_point(v, chunk, threadIdx.x, true);
+    // every lane of the wave runs the feature code (wave-level votes inside); lanes without a
+    // scoreable point simply have no rows
+    const int kf = point_features(v.pts, v.nrm, v.cell_start, v.ds->grid, v.f, w.p, w.np, H,
+                                  reinterpret_cast<uint2 *>(H + maxF * kLanes), ecap, w.scoreable);
+    if (STATS && w.scoreable) atomicAdd(&v.stats->sum_kf, (unsigned long long)kf);
+    float *o = v.feat + (size_t)chunk * v.f.F * kLanes + threadIdx.x;
+    for (int c = 0; c < v.f.F; ++c) o[c * kLanes] = H[c * kLanes + threadIdx.x];
+}
+
+// Persistent workgroups of several waves: the workgroup stages the first nlds nodes of its view's
+// forest once, then every wave takes chunks of 64 points: features -> its LDS slice, tree walks,
+// score_sorted / scores / NMS candidates out.
+//   LDS: [nlds_cap nodes, 8 B each][waves x F x 64 floats]
+template <bool STATS>
+__global__ __launch_bounds__(1024) void forest_kernel(Batch b, int maxF, int nlds_cap) {
+    extern __shared__ uint2 lnodes[];
+    const ViewDev &a = b.view[blockIdx.y];
+    const int lane = threadIdx.x & (kLanes - 1), wid = threadIdx.x / kLanes, nwaves = blockDim.x / kLanes;
+    const int nlds = min(nlds_cap, a.forest.nnodes);
+    for (int i = threadIdx.x; i < nlds; i += blockDim.x) lnodes[i] = a.forest.nodes[i];
+    __syncthreads();
+    float *H = reinterpret_cast<float *>(lnodes + nlds_cap) + (size_t)wid * maxF * kLanes;
+    const int nchunks = (a.n + kLanes - 1) / kLanes;
+    for (int chunk = blockIdx.x * nwaves + wid; chunk < nchunks; chunk += gridDim.x * nwaves) {
+        {   // per ORIGINAL point: NaN for points that are not in the grid
+            const int i = chunk * kLanes + lane;
+            if (i < a.n && a.scores && a.cid[i] < 0) a.scores[i] = NAN;
+        }
+        const WavePoint w = wave_point(a, chunk, lane, false);
+        if (!w.in_range) continue;
+        float score = NAN;
+        if (w.scoreable) {
+            const float *o = a.feat + (size_t)chunk * a.f.F * kLanes + lane;
+            for (int c = 0; c < a.f.F; ++c) H[c * kLanes + lane] = o[c * kLanes];
+            int depth = 0;
+            const float fsum = forest_sum<STATS>(a.forest, lnodes, nlds, H + lane, depth);
+            score = 1 - (fsum / (a.forest.ntrees * 1.0f));                         // hpp:287
+            if (STATS) {
+                atomicAdd(&a.stats->sum_depth, (unsigned long long)depth);
+                atomicAdd(&a.stats->n_scored, 1ull);
+            }
+        }
+        a.score_sorted[w.s] = score;
+        if (a.scores) a.scores[__float_as_int(w.p.w)] = score;
+        // hand the point to the NMS stage (detectKeypoints, hpp:203-208): only scoreable points whose
+        // score, promoted to double, is not below the threshold are ever searched
+        if (w.scoreable) {
+            if (!a.nd.non_maxima) a.flags[__float_as_int(w.p.w)] = 1;               // hpp:189-196
+            // hpp:205-207: a non-finite response is never a candidate (!pcl_isfinite(intensity))
+            else if (isfinite(score) && !((double)score < a.nd.thr)) a.cand.list[atomicAdd(a.cand.count, 1)] = w.s;
+        }
+    }
 }
 
 // computePointsForTrainingFeatures, hpp:299-318: same feature code, sparse query list.
@@ -1425,6 +1479,8 @@ void launch_index(const Batch &b, hipStream_t st) {
     }
 }
 
+size_t feat_bytes(int n, int F) { return sizeof(float) * (size_t)div_up(n > 0 ? n : 1, kLanes) * kLanes * (size_t)(F > 0 ? F : 1); }
+
 size_t pts_bytes(int n) { return sizeof(float4) * ((size_t)(n > 0 ? n : 1) + kStepW); }
 
 // Accept words per lane for a histogram of F floats per lane: as many as fit next to the histogram
@@ -1439,20 +1495,69 @@ static int accept_words(int F) {
     return (int)e;
 }
 
-// scoring ("runForest") of every view of the batch in one launch
+// Geometry of the forest kernel: one workgroup per CU; LDS = the top of the forest (at most
+// kForestNodeBytes) + one F x 64 float slice per wave, as many waves as then fit (2..16).
+constexpr size_t kForestLds = 156 * 1024, kForestNodeBytes = 64 * 1024;
+struct ForestLaunch {
+    int waves, nlds_cap;
+    size_t lds;
+};
+static ForestLaunch forest_launch(int maxF, int max_nodes) {
+    ForestLaunch fl;
+    const size_t slice = sizeof(float) * (size_t)maxF * kLanes;
+    size_t node_bytes = sizeof(uint2) * (size_t)(max_nodes > 0 ? max_nodes : 1);
+    if (node_bytes > kForestNodeBytes) node_bytes = kForestNodeBytes;
+    long long w = ((long long)kForestLds - (long long)node_bytes) / (long long)slice;
+    if (w < 2) {                                   // huge histograms: two waves, the nodes get what is left
+        w = 2;
+        node_bytes = kForestLds - 2 * slice;       // F <= 255: 2 slices are at most 130 KB
+    }
+    if (w > 16) w = 16;
+    fl.waves = (int)w;
+    fl.nlds_cap = (int)(node_bytes / sizeof(uint2));
+    fl.lds = sizeof(uint2) * (size_t)fl.nlds_cap + slice * (size_t)fl.waves;
+    return fl;
+}
+
+static int cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            n = v;
+        else
+            n = 256;
+    }
+    return n;
+}
+
+// scoring ("runForest") of every view of the batch: the feature kernel, then the forest kernel
 void launch_score(const Batch &b, hipStream_t st) {
     const int n = max_n(b);
     if (b.nviews <= 0 || n <= 0) return;
-    int maxF = 1;
+    int maxF = 1, max_nodes = 1;
     bool stats = false;
     for (int v = 0; v < b.nviews; ++v) {
         maxF = b.view[v].f.F > maxF ? b.view[v].f.F : maxF;
+        max_nodes = b.view[v].forest.nnodes > max_nodes ? b.view[v].forest.nnodes : max_nodes;
         stats |= b.view[v].stats != nullptr;
     }
     const int ecap = accept_words(maxF);
     const size_t lds = feature_lds_bytes(maxF, ecap);
-    if (stats) score_kernel<true><<<dim3(div_up(n, kLanes), b.nviews), kLanes, lds, st>>>(b, maxF, ecap);
-    else score_kernel<false><<<dim3(div_up(n, kLanes), b.nviews), kLanes, lds, st>>>(b, maxF, ecap);
+    const dim3 grid(div_up(n, kLanes), b.nviews);
+    const ForestLaunch fl = forest_launch(maxF, max_nodes);
+    int wgs = div_up(cu_count(), b.nviews);                   // persistent: about one workgroup per CU
+    const int wgs_max = div_up(div_up(n, kLanes), fl.waves);
+    if (wgs > wgs_max) wgs = wgs_max;
+    const dim3 fgrid(wgs, b.nviews);
+    if (stats) {
+        feature_kernel<true><<<grid, kLanes, lds, st>>>(b, maxF, ecap);
+        forest_kernel<true><<<fgrid, fl.waves * kLanes, fl.lds, st>>>(b, maxF, fl.nlds_cap);
+    } else {
+        feature_kernel<false><<<grid, kLanes, lds, st>>>(b, maxF, ecap);
+        forest_kernel<false><<<fgrid, fl.waves * kLanes, fl.lds, st>>>(b, maxF, fl.nlds_cap);
+    }
 }
 
 void launch_features(const float4 *pts, const float4 *nrm, const int *cell_start,
