@@ -439,8 +439,9 @@ constexpr int kLanes = 64;   // one wave per workgroup: waves never synchronise 
 // what one accepted neighbor adds to the histogram: 4 cells and 4 weights (hpp:342-355).  The
 // cells are byte offsets of the lane's entries from H (cell c of lane l lives at (c * 64 + l) * 4)
 struct Contribution {
-    int c0, c1, c2, c3;
+    int c0, c1, c2, c3;      // (a,b) (a,b') (a',b) (a',b')
     float w00, w01, w10, w11;
+    bool same_a, same_b;     // a' == a / b' == b: the pair index was clamped onto the index (range ends)
 };
 
 __device__ __forceinline__ Contribution neighbor_contribution(const FeatDesc &f, float d2,
@@ -457,6 +458,8 @@ __device__ __forceinline__ Contribution neighbor_contribution(const FeatDesc &f,
     c.w01 = bw * (1 - aw);
     c.w10 = (1 - bw) * aw;
     c.w11 = bw * aw;
+    c.same_a = ap == a;
+    c.same_b = bp == bi;
     const int row_bytes = f.B * (kLanes * 4), lane_bytes = (int)threadIdx.x * 4;
     const int ra = __mul24(a, row_bytes) + lane_bytes, rap = __mul24(ap, row_bytes) + lane_bytes;
     const int cb = bi * (kLanes * 4), cbp = bp * (kLanes * 4);
@@ -471,19 +474,35 @@ __device__ __forceinline__ float &hist_at(float *H, int byte_offset) {
     return *reinterpret_cast<float *>(reinterpret_cast<char *>(H) + byte_offset);
 }
 
-// The 4 adds of one neighbor may hit the same cell (pair == index at the range ends -- the common
-// case for bin 0); the cells are read once, the adds are forwarded through registers in the
-// reference's order (hpp:350-355) and written back in order, so the float result is exactly the
-// one the sequential "+=" chain gives while only one LDS round trip sits on the critical path.
+// The 4 "+=" of one neighbor (hpp:350-355) may hit the same cell -- the pair index is clamped onto
+// the index at the range ends, the common case for bin 0.  The 4 cells are read once
+// (request_cells), the adds are forwarded through registers in the reference's order and written
+// back in order (apply_contribution), so the float result is exactly the one the sequential chain
+// gives and only one LDS round trip sits on the critical path.
+// Which cells coincide follows from the two clamp flags: c1 == c0 and c3 == c2 iff same_b,
+// c2 == c0 and c3 == c1 iff same_a.
 // (Four ds_add_f32 give the same bits -- the LDS adder rounds like v_add_f32 and one wave's DS
 // instructions execute in order -- but LDS float atomics run at a fraction of the plain read /
-// write rate: the score kernel took 2.3x as long with them, profiles/r02_notes.md.)
-__device__ __forceinline__ void apply_contribution(float *H, const Contribution &c) {
-    const float v0 = hist_at(H, c.c0), v1 = hist_at(H, c.c1), v2 = hist_at(H, c.c2), v3 = hist_at(H, c.c3);
-    const float x0 = v0 + c.w00;                                                                   // hpp:350
-    const float x1 = ((c.c1 == c.c0) ? x0 : v1) + c.w01;                                           // hpp:351
-    const float x2 = ((c.c2 == c.c1) ? x1 : (c.c2 == c.c0) ? x0 : v2) + c.w10;                     // hpp:354
-    const float x3 = ((c.c3 == c.c2) ? x2 : (c.c3 == c.c1) ? x1 : (c.c3 == c.c0) ? x0 : v3) + c.w11;  // hpp:355
+// write rate: the kernel took 2.3x as long with them, profiles/r02_notes.md.)
+struct Cells {
+    float v0, v1, v2, v3;
+};
+
+__device__ __forceinline__ Cells request_cells(float *H, const Contribution &c) {
+    Cells v;
+    v.v0 = hist_at(H, c.c0);
+    v.v1 = hist_at(H, c.c1);
+    v.v2 = hist_at(H, c.c2);
+    v.v3 = hist_at(H, c.c3);
+    return v;
+}
+
+__device__ __forceinline__ void apply_contribution(float *H, const Contribution &c, const Cells &v) {
+    const bool both = c.same_a & c.same_b;
+    const float x0 = v.v0 + c.w00;                                                 // hpp:350
+    const float x1 = (c.same_b ? x0 : v.v1) + c.w01;                               // hpp:351
+    const float x2 = (both ? x1 : c.same_a ? x0 : v.v2) + c.w10;                   // hpp:354
+    const float x3 = (c.same_b ? x2 : c.same_a ? x1 : v.v3) + c.w11;               // hpp:355
     hist_at(H, c.c0) = x0;
     hist_at(H, c.c1) = x1;
     hist_at(H, c.c2) = x2;
@@ -668,6 +687,9 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
             // One iteration: take the next neighbor into `nxt` and request its point and normal,
             // accumulate `now` (taken one iteration ago).  Loads are issued unconditionally with a
             // clamped address: a load behind a branch makes the compiler wait for it at the join.
+            // (A deeper pipeline -- neighbors taken two iterations ahead, the cells of one
+            // contribution requested under the arithmetic of the next -- measured 8 % slower: the
+            // loop is bound by VALU issue, not by its latencies, profiles/r02_notes.md.)
 #define KPL_DRAIN_ITERATION(now, nxt)                                                              \
     {                                                                                              \
         const bool refill_ = (w == 0u) & (e < e_end);                                              \
@@ -682,8 +704,10 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
         nxt.q = ld16(pts, t_);                                                                     \
         nxt.n = ld16(nrm, t_);                                                                     \
         /* hpp:338: a neighbor with a non-finite normal is skipped */                              \
-        if (now.valid & (now.n.w != 0.0f))                                                         \
-            apply_contribution(H, neighbor_contribution(f, dist2(p.x, p.y, p.z, now.q), np, now.n)); \
+        if (now.valid & (now.n.w != 0.0f)) {                                                       \
+            const Contribution c_ = neighbor_contribution(f, dist2(p.x, p.y, p.z, now.q), np, now.n); \
+            apply_contribution(H, c_, request_cells(H, c_));                                       \
+        }                                                                                          \
         now.valid = false;                                                                         \
     }
             do {
