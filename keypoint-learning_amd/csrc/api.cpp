@@ -63,15 +63,16 @@ struct kpl_detector {
     int n = 0;
     bool bound = false;
     bool index_valid = false;
+    bool pos_of_valid = false;    // the index was built with pos_of[]
     double index_radius = 0.0;
     bool has_origin = false;      // kpl_set_grid_origin
     float origin[3] = {0.0f, 0.0f, 0.0f};
 
     DevBuf stage_xyz, stage_nrm, stage_idx, stage_feat;
-    DevBuf dstate, cid, cnt, cell_start, tmp_idx, scan_tmp, pts, nrm, pos_of;
+    DevBuf dstate, cid, btable, cell_start, tmp_idx, scan_tmp, pts, nrm, pos_of;
     DevBuf score_sorted, flags, prefix, stats, out_scores, out_kp, out_count, cand_list, cand_count;
     DevBuf draw_list, draw_count, skip, feat;
-    int cells_cap = 0;            // capacity (cells) of cnt / cell_start
+    int cells_cap = 0;            // capacity (cells) of cell_start
     DevState *h_state = nullptr;  // pinned copy of the device state (status read-back)
     int *h_count = nullptr;       // pinned
 
@@ -205,15 +206,12 @@ int install_forest(kpl_detector *h, ForestModel &&m) {
     return KPL_OK;
 }
 
-// (re)allocates the cell tables for `cap` cells; the population counters start zeroed and are
-// kept zeroed by the scan that consumes them, so this is the only memset they ever see
+// (re)allocates the cell table for `cap` cells
 int ensure_cells(kpl_detector *h, int64_t cap) {
     if (cap <= h->cells_cap) return KPL_OK;
     if (cap > kMaxGridCells) cap = kMaxGridCells;
     KPL_HIP(h, hipDeviceSynchronize());
-    KPL_HIP(h, h->cnt.ensure(sizeof(int) * ((size_t)cap + 2)));
     KPL_HIP(h, h->cell_start.ensure(sizeof(int) * ((size_t)cap + 2)));
-    KPL_HIP(h, hipMemset(h->cnt.p, 0, sizeof(int) * ((size_t)cap + 2)));
     KPL_HIP(h, hipMemset(h->cell_start.p, 0, sizeof(int) * ((size_t)cap + 2)));
     h->cells_cap = (int)cap;
     return KPL_OK;
@@ -237,7 +235,8 @@ int prepare_index(kpl_detector *h, bool auto_cell, ViewDev &v, double cell = 0.0
         if (rc) return rc;
     }
     KPL_HIP(h, h->cid.ensure(sizeof(int) * nn));
-    KPL_HIP(h, h->tmp_idx.ensure(sizeof(int2) * nn));
+    KPL_HIP(h, h->tmp_idx.ensure(2 * sizeof(float4) * nn));
+    KPL_HIP(h, h->btable.ensure(sizeof(int) * btable_ints(n)));
     const size_t scan_len = (size_t)(h->cells_cap > n ? h->cells_cap : n) + 1;
     KPL_HIP(h, h->scan_tmp.ensure(sizeof(int) * (scan_len / 4096 + 4)));
     KPL_HIP(h, h->pts.ensure(pts_bytes(n)));            // incl. the tail the search steps read past the last point
@@ -254,9 +253,12 @@ int prepare_index(kpl_detector *h, bool auto_cell, ViewDev &v, double cell = 0.0
     v.has_origin = (h->has_origin && !auto_cell) ? 1 : 0;
     for (int k = 0; k < 3; ++k) v.origin[k] = h->origin[k];
     v.cid = h->cid.as<int>();
-    v.cnt = h->cnt.as<int>();
+    v.btable = h->btable.as<int>();
+    v.btotal = h->btable.as<int>() + (btable_ints(n) - 2 * (kBuckets + 1));
+    v.bstart = v.btotal + (kBuckets + 1);
     v.cell_start = h->cell_start.as<int>();
-    v.tmp_idx = h->tmp_idx.as<int2>();
+    v.rec = h->tmp_idx.as<float4>();
+    v.want_pos_of = 1;
     v.scan_tmp = h->scan_tmp.as<int>();
     v.pts = h->pts.as<float4>();
     v.nrm = h->nrm.as<float4>();
@@ -266,9 +268,10 @@ int prepare_index(kpl_detector *h, bool auto_cell, ViewDev &v, double cell = 0.0
 
 bool index_is_current(const kpl_detector *h) { return h->index_valid && h->index_radius == h->prm.radius_search; }
 
-void index_was_built(kpl_detector *h, bool auto_cell) {
+void index_was_built(kpl_detector *h, bool auto_cell, bool with_pos_of = true) {
     h->index_valid = !auto_cell;
     h->index_radius = h->prm.radius_search;
+    h->pos_of_valid = with_pos_of;
 }
 
 int build_index(kpl_detector *h, hipStream_t st, bool auto_cell = false) {
@@ -284,9 +287,19 @@ int build_index(kpl_detector *h, hipStream_t st, bool auto_cell = false) {
     return KPL_OK;
 }
 
+// the index AND pos_of[]: compute() builds the index without the map when nothing of the call reads it
 int ensure_index(kpl_detector *h, hipStream_t st) {
-    if (index_is_current(h)) return KPL_OK;
-    return build_index(h, st);
+    if (!index_is_current(h)) return build_index(h, st);
+    if (!h->pos_of_valid) {
+        Batch b{};
+        b.nviews = 1;
+        int rc = prepare_index(h, false, b.view[0]);
+        if (rc) return rc;
+        launch_pos_of(b, st);
+        KPL_HIP(h, hipGetLastError());
+        h->pos_of_valid = true;
+    }
+    return KPL_OK;
 }
 
 // waits for `st`, reads the device status of the last index build and turns it into a status
@@ -365,7 +378,8 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
 int run_batch(kpl_detector *const *handles, int count, float *const *d_scores, int *const *d_kp_idx,
               const int *kp_caps, int *const *d_kp_counts, StatsDev *d_stats, bool rebuild, hipStream_t st) {
     kpl_detector *h0 = handles[0];
-    Batch all{}, idx{};
+    Batch all{}, idx{}, fix{};
+    bool rebuilt[kMaxBatch] = {};
     for (int k = 0; k < count; ++k) {
         kpl_detector *h = handles[k];
         int rc = check_params_for_compute(h, true);
@@ -376,11 +390,17 @@ int run_batch(kpl_detector *const *handles, int count, float *const *d_scores, i
             if (h != h0) fail(h0, rc, "view %d: %s", k, kpl_last_error(h));
             return rc;
         }
-        if (rebuild || !index_is_current(h)) idx.view[idx.nviews++] = all.view[k];
+        // pos_of[] is read by the draws pass only; a view whose index is kept needs it completed if missing
+        const bool rebuild_k = rebuild || !index_is_current(h);
+        all.view[k].want_pos_of = all.view[k].nd.draws_remove ? 1 : 0;
+        if (rebuild_k) idx.view[idx.nviews++] = all.view[k];
+        else if (all.view[k].want_pos_of && !h->pos_of_valid) fix.view[fix.nviews++] = all.view[k];
+        rebuilt[k] = rebuild_k;
     }
     all.nviews = count;
     const size_t ev0 = mark(h0, st);
     if (idx.nviews) launch_index(idx, st);
+    if (fix.nviews) launch_pos_of(fix, st);
     const size_t ev1 = mark(h0, st);
     launch_score(all, st);
     const size_t ev2 = mark(h0, st);
@@ -390,7 +410,11 @@ int run_batch(kpl_detector *const *handles, int count, float *const *d_scores, i
     span(h0, 1, ev1, ev2);
     span(h0, 2, ev2, ev3);
     KPL_HIP(h0, hipGetLastError());
-    for (int k = 0; k < count; ++k) index_was_built(handles[k], false);
+    for (int k = 0; k < count; ++k) {
+        const bool with_map = all.view[k].want_pos_of != 0;
+        if (rebuilt[k]) index_was_built(handles[k], false, with_map);
+        else if (with_map) handles[k]->pos_of_valid = true;
+    }
     return KPL_OK;
 }
 
@@ -526,7 +550,7 @@ void kpl_destroy(kpl_detector *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     DevBuf *bufs[] = {&h->d_nodes, &h->d_roots, &h->stage_xyz, &h->stage_nrm, &h->stage_idx, &h->stage_feat,
-                      &h->dstate, &h->cid, &h->cnt, &h->cell_start, &h->tmp_idx, &h->scan_tmp,
+                      &h->dstate, &h->cid, &h->btable, &h->cell_start, &h->tmp_idx, &h->scan_tmp,
                       &h->pts, &h->nrm, &h->pos_of, &h->score_sorted, &h->flags, &h->prefix, &h->stats,
                       &h->out_scores, &h->out_kp, &h->out_count, &h->cand_list, &h->cand_count,
                       &h->draw_list, &h->draw_count, &h->skip, &h->feat};

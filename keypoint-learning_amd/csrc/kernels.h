@@ -6,7 +6,7 @@
 //   nrm[s]   float4  its normal, w = 1.0f if the normal is finite else 0.0f
 //   cell_start[c]    first storage position of grid cell c, c = (cz*ny + cy)*nx + cx; a run of
 //                    cells along x is therefore ONE contiguous range of pts/nrm
-//   pos_of[i]        storage position of original point i, -1 if its xyz is not finite
+//   pos_of[i]        storage position of original point i, -1 if its xyz is not finite (built on demand)
 //   score_sorted[s]  forest response in storage order (what the NMS kernel gathers)
 //   flags[i]         1 if original point i is a keypoint (compacted in ascending i)
 // Canonical storage order = ascending (cell id, original index); it is what makes the float
@@ -77,15 +77,17 @@ struct ViewDev {
     int n;
     // index ("initCompute")
     DevState *ds;
-    int cells_cap;               // capacity of cnt / cell_start
+    int cells_cap;               // capacity of cell_start
     float cell;                  // cell edge; <= 0: derived from the bounding box (cloud resolution)
     float origin[3];             // grid origin when has_origin, else the minimum of the finite points
     int has_origin;
     int *cid;                    // [n] cell of original point i, -1 if not finite
-    int *cnt, *cell_start, *scan_tmp;
-    int2 *tmp_idx;               // [n] (original index, cell) in arrival order inside each cell
+    int *cell_start, *scan_tmp;
+    int *btable, *btotal, *bstart;   // index sort, level 1: (chunk, bin) counts -> offsets; points / first position of each bin
+    float4 *rec;                 // [2 n] records (x, y, z, index)(nx, ny, nz, cell), bucket by bucket, index order inside
     float4 *pts, *nrm;           // canonical storage order
-    int *pos_of;
+    int *pos_of;                 // [n] original index -> storage position (-1: no cell); complete only if want_pos_of
+    int want_pos_of;
     // scoring ("runForest")
     FeatDesc f;
     ForestDev forest;
@@ -114,10 +116,12 @@ static_assert(sizeof(Batch) <= 4096, "a Batch travels as kernel arguments: 4 KB 
 // bounding box, so the host never waits between the kernels of a call.
 constexpr int kStatusOk = 0, kStatusGridTooLarge = 1, kStatusCellCapacity = 2, kStatusBadOrigin = 3;
 constexpr long long kMaxGridCells = 1ll << 28;
+constexpr int kBuckets = 1024;   // buckets of the index sort (kernels.hip "Index build")
 struct DevState {
     GridDesc grid;        // written by grid_setup_kernel, read by every later kernel
     int status;           // kStatus*: on failure the grid is empty and kp_count becomes -1
     int ncells_needed;    // what this view needs (to grow the cell tables before a retry)
+    int bshift, nbuckets; // index sort: nbuckets buckets of 2^bshift consecutive cells
     uint32_t bbox[6];     // order-preserving encoded min / max accumulators (self re-arming)
 };
 void init_dev_state(DevState *host_copy);
@@ -125,6 +129,8 @@ void init_dev_state(DevState *host_copy);
 // ---- the three stages of compute(), each over every view of the batch ------------------------
 // index build ("initCompute"): needs the input + index fields of ViewDev
 void launch_index(const Batch &b, hipStream_t st);
+// pos_of[] of views indexed without it (want_pos_of must be set)
+void launch_pos_of(const Batch &b, hipStream_t st);
 // scoring ("runForest"): scores[i] (original order, may be null) and score_sorted[s]; NaN where not
 // scoreable; appends the points that pass the threshold to `cand` (or, without NMS, flags every
 // scoreable point)
@@ -133,6 +139,9 @@ void launch_score(const Batch &b, hipStream_t st);
 // all zero on entry to a detect call; the compaction leaves them zeroed again
 void launch_post(const Batch &b, hipStream_t st);
 
+// ints of the (chunk, bin) table + bin totals + bin starts of the index sort of a view of n points (the two
+// arrays of kBuckets + 1 ints each sit at the end)
+size_t btable_ints(int n);
 // bytes of the feature scratch of a view: F floats per point, one F x 64 block per wave
 size_t feat_bytes(int n, int F);
 // bytes of pts[] for a view of n points: a search step of the feature code loads a fixed number of

@@ -163,40 +163,15 @@ __global__ void grid_setup_kernel(Batch b) {
     g.ncells = (int)nc;
     ds->grid = g;
     ds->status = status;
+    // buckets of the index sort: 2^bshift consecutive cells each, at most kBuckets of them
+    int bshift = 0;
+    while (nc > 0 && ((nc - 1) >> bshift) >= kBuckets) ++bshift;
+    ds->bshift = bshift;
+    ds->nbuckets = nc > 0 ? (int)((nc - 1) >> bshift) + 1 : 0;
     for (int k = 0; k < 3; ++k) {
         ds->bbox[k] = 0xffffffffu;
         ds->bbox[3 + k] = 0u;
     }
-}
-
-// ---------------------------------------------------------------------------------------------
-// cell id per point + population count per cell
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void cell_count_kernel(Batch b) {
-    const ViewDev &v = b.view[blockIdx.y];
-    const char *xyz = v.xyz;
-    const size_t stride = v.xs;
-    const int n = v.n;
-    const DevState *ds = v.ds;
-    int *cid = v.cid, *cnt = v.cnt, *arrival = v.pos_of;
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const GridDesc g = ds->grid;
-    if (g.ncells == 0) {           // empty view, or the grid could not be set up (ds->status)
-        cid[i] = -1;
-        return;
-    }
-    const float *p = point_at(xyz, stride, i);
-    float x = p[0], y = p[1], z = p[2];
-    int c = -1;
-    if (finite3(x, y, z)) {
-        int cx = cell_coord(x, g.mn[0], g.h, g.dims[0]);
-        int cy = cell_coord(y, g.mn[1], g.h, g.dims[1]);
-        int cz = cell_coord(z, g.mn[2], g.h, g.dims[2]);
-        c = (cz * g.dims[1] + cy) * g.dims[0] + cx;
-        arrival[i] = atomicAdd(&cnt[c], 1);   // the ONE atomic per point of the index build
-    }
-    cid[i] = c;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -319,47 +294,359 @@ __global__ __launch_bounds__(kScanBlock) void scan_apply_kernel(ScanJobs jobs) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// counting sort, made deterministic: scatter in arrival order, then rank inside the cell by
-// original index (ascending), and store the point + normal at its canonical position
+// Index build ("initCompute"): a STABLE two-level counting sort of the points by cell id, so that
+// the storage order is the canonical one (cell id ascending, original index ascending inside a
+// cell) by construction -- no global atomics, no ranking pass.
+//   level 1  the cell id space is cut into nbuckets <= 1024 buckets of 2^bshift consecutive cells
+//            (DevState, computed on the device with the grid).  Chunks of kSortChunk consecutive
+//            points (one wave each) count their points per bucket (bucket_hist_kernel), the
+//            (chunk, bucket) table is turned into offsets column by column (bucket_total_kernel,
+//            bucket_offsets_kernel), and the chunks move their (index, cell) pairs to the bucket's range, in index order
+//            (bucket_scatter_kernel).  Points that are not finite go to an extra bin at the end.
+//   level 2  one wave per bucket (cell_sort_store_kernel): per-cell counts of the bucket in LDS,
+//            scan -> cell_start[], then the bucket's pairs once more in index order: storage
+//            position = start of the cell + points of that cell seen so far; the point and its
+//            normal are gathered and stored there, pos_of[index] = position.
+// "In index order" inside a wave: the 64 pairs of a round are ranked among the lanes with the same
+// key by lane number (match_rank) and the running count of the key is advanced once per round.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void scatter_kernel(Batch b) {
-    const ViewDev &v = b.view[blockIdx.y];
-    const int *cid = v.cid, *cell_start = v.cell_start, *arrival = v.pos_of;
-    const int n = v.n;
-    int2 *tmp = v.tmp_idx;
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int c = cid[i];
-    if (c < 0) return;
-    tmp[cell_start[c] + arrival[i]] = make_int2(i, c);   // the cell travels along: no random read of cid later
+constexpr int kSortChunk = 1024;         // points per chunk of level 1 (16 rounds of one wave)
+constexpr int kInvalidBin = kBuckets;    // bin of the points without a cell
+constexpr int kTagSlots = 256;
+
+// Orders this wave's LDS accesses for the compiler (no forwarding of a store into a later load that
+// another lane may have overwritten, no reordering across it).  The hardware needs nothing: a wave's
+// DS instructions execute in order.  NOT __syncthreads(): that also waits for every global load and
+// store in flight (s_waitcnt vmcnt(0)), which would serialise the rounds of the sort on HBM latency.
+__device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+
+// rank = lanes below this one with the same key among the participating lanes, cnt = their number.
+// Fast path: every lane writes its number into a small hashed tag table and reads it back; if every
+// participating lane reads its own number no two of them share a hash slot, let alone a key.
+// Otherwise one ballot per key bit narrows each lane's set of equals.
+__device__ __forceinline__ void match_rank(int key, bool in, int nbits, int *tag, int lane, int &rank, int &cnt) {
+    const int hslot = key & (kTagSlots - 1);
+    if (in) tag[hslot] = lane;
+    wave_lds_fence();
+    const bool lost = in && tag[hslot] != lane;
+    wave_lds_fence();
+    rank = 0;
+    cnt = 1;
+    if (__any(lost)) {
+        unsigned long long m = __ballot(in);
+        for (int bit = 0; bit < nbits; ++bit) {
+            const bool one = (key >> bit) & 1;
+            const unsigned long long bb = __ballot(in && one);
+            m &= one ? bb : ~bb;
+        }
+        rank = __popcll(m & ((1ull << lane) - 1ull));
+        cnt = __popcll(m);
+    }
 }
 
-__global__ __launch_bounds__(256) void rank_store_kernel(Batch b) {
+__device__ __forceinline__ int point_cell(const GridDesc &g, const char *xyz, size_t stride, int i) {
+    const float *p = point_at(xyz, stride, i);
+    const float x = p[0], y = p[1], z = p[2];
+    if (g.ncells == 0 || !finite3(x, y, z)) return -1;
+    const int cx = cell_coord(x, g.mn[0], g.h, g.dims[0]);
+    const int cy = cell_coord(y, g.mn[1], g.h, g.dims[1]);
+    const int cz = cell_coord(z, g.mn[2], g.h, g.dims[2]);
+    return (cz * g.dims[1] + cy) * g.dims[0] + cx;
+}
+
+__host__ __device__ inline int sort_chunks(int n) { return (n + kSortChunk - 1) / kSortChunk; }
+
+constexpr int kBins = kBuckets + 1;      // buckets + the bin of the points without a cell
+constexpr int kRoundsAhead = 8;          // rounds of a chunk whose loads are issued together
+
+// btable[bin * nchunks + chunk] = points of the chunk in the bin (a bin's chunks are contiguous: the
+// two kernels that turn counts into offsets give each bin to one wave); cid[i] = cell of point i (-1: none)
+__global__ __launch_bounds__(kWave) void bucket_hist_kernel(Batch b) {
     const ViewDev &v = b.view[blockIdx.y];
-    const char *xyz = v.xyz, *nrm = v.nrmsrc;
-    const size_t xs = v.xs, ns = v.ns;
-    const int n = v.n;
-    const int *cid = v.cid, *cell_start = v.cell_start;
-    const int2 *tmp = v.tmp_idx;
-    float4 *pts = v.pts, *nrmo = v.nrm;
-    int *pos_of = v.pos_of;
-    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = v.n, chunk = blockIdx.x, i0 = chunk * kSortChunk, lane = threadIdx.x;
+    if (i0 >= n) return;
+    __shared__ int hist[kBins];
+    for (int k = lane; k < kBins; k += kWave) hist[k] = 0;
+    __syncthreads();
     const GridDesc g = v.ds->grid;
-    if (s < n && cid[s] < 0) pos_of[s] = -1;   // non-finite original point s
-    const int nfinite = cell_start[g.ncells];
-    if (s >= nfinite) return;
-    const int2 ic = tmp[s];
-    const int i = ic.x;
-    const int s0 = cell_start[ic.y], s1 = cell_start[ic.y + 1];
-    int rank = 0;
-    for (int t = s0; t < s1; ++t) rank += (tmp[t].x < i);
-    const int pos = s0 + rank;
-    const float *p = point_at(xyz, xs, i);
-    const float *q = point_at(nrm, ns, i);
-    pts[pos] = make_float4(p[0], p[1], p[2], __int_as_float(i));
-    float nx = q[0], ny = q[1], nz = q[2];
-    nrmo[pos] = make_float4(nx, ny, nz, finite3(nx, ny, nz) ? 1.0f : 0.0f);
-    pos_of[i] = pos;
+    const int bshift = v.ds->bshift;
+    for (int r0 = 0; r0 < kSortChunk / kWave; r0 += kRoundsAhead) {
+        int c[kRoundsAhead];
+#pragma unroll
+        for (int k = 0; k < kRoundsAhead; ++k) {
+            const int i = i0 + (r0 + k) * kWave + lane;
+            c[k] = i < n ? point_cell(g, v.xyz, v.xs, i) : -2;
+        }
+#pragma unroll
+        for (int k = 0; k < kRoundsAhead; ++k) {
+            const int i = i0 + (r0 + k) * kWave + lane;
+            if (c[k] != -2) {
+                v.cid[i] = c[k];
+                atomicAdd(&hist[c[k] < 0 ? kInvalidBin : (c[k] >> bshift)], 1);
+            }
+        }
+    }
+    __syncthreads();
+    const int nchunks = sort_chunks(n);
+    for (int k = lane; k < kBins; k += kWave) v.btable[(size_t)k * nchunks + chunk] = hist[k];
+}
+
+// points per bin over all chunks: one wave per bin
+__global__ __launch_bounds__(256) void bucket_total_kernel(Batch b) {
+    const ViewDev &v = b.view[blockIdx.y];
+    const int bin = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+    if (bin >= kBins) return;
+    const int nchunks = sort_chunks(v.n);
+    const int *t = v.btable + (size_t)bin * nchunks;
+    int sum = 0;
+    for (int c = lane; c < nchunks; c += kWave) sum += t[c];
+    for (int off = kWave / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    if (lane == 0) v.btotal[bin] = sum;
+}
+
+// btotal[bin] -> bstart[bin] = first position of the bin; btable[bin][chunk] -> first position of the
+// chunk's points inside the bin.  bstart[kBuckets] = number of points with a cell.  Every block
+// scans the kBins totals for itself (they are few); then one wave per bin scans the bin's chunks.
+// (Totals and starts are separate arrays: the blocks of this launch read ALL totals and finish at
+// different times.)
+__global__ __launch_bounds__(256) void bucket_offsets_kernel(Batch b) {
+    const ViewDev &v = b.view[blockIdx.y];
+    __shared__ int tot[kBins];
+    __shared__ int wsum[256 / kWave];
+    for (int k = threadIdx.x; k < kBins; k += blockDim.x) tot[k] = v.btotal[k];
+    __syncthreads();
+    // exclusive scan of tot[] by the block: 256 threads x ceil(kBins / 256) consecutive bins each
+    constexpr int kPer = (kBins + 255) / 256;
+    const int first = threadIdx.x * kPer;
+    int mine = 0;
+    for (int k = 0; k < kPer; ++k) mine += first + k < kBins ? tot[first + k] : 0;
+    const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+    int incl = mine;
+    for (int off = 1; off < kWave; off <<= 1) {
+        const int o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+    }
+    if (lane == kWave - 1) wsum[wid] = incl;
+    __syncthreads();
+    int run = incl - mine;
+    for (int w = 0; w < wid; ++w) run += wsum[w];
+    __syncthreads();
+    for (int k = 0; k < kPer; ++k)
+        if (first + k < kBins) {
+            const int x = tot[first + k];
+            tot[first + k] = run;
+            run += x;
+        }
+    __syncthreads();
+    const int bin = blockIdx.x * (blockDim.x / kWave) + wid;
+    if (bin >= kBins) return;
+    const int nchunks = sort_chunks(v.n);
+    int *t = v.btable + (size_t)bin * nchunks;
+    int pos = tot[bin];
+    for (int c0 = 0; c0 < nchunks; c0 += kWave) {
+        const int c = c0 + lane;
+        const int x = c < nchunks ? t[c] : 0;
+        int inc = x;
+        for (int off = 1; off < kWave; off <<= 1) {
+            const int o = __shfl_up(inc, off);
+            if (lane >= off) inc += o;
+        }
+        if (c < nchunks) t[c] = pos + inc - x;
+        pos += __shfl(inc, kWave - 1);
+    }
+    if (lane == 0) v.bstart[bin] = tot[bin];
+}
+
+// rec[2 * position] = (x, y, z, index), rec[2 * position + 1] = (nx, ny, nz, cell): positions inside a bin in index order
+__global__ __launch_bounds__(kWave) void bucket_scatter_kernel(Batch b) {
+    const ViewDev &v = b.view[blockIdx.y];
+    const int n = v.n, chunk = blockIdx.x, i0 = chunk * kSortChunk, lane = threadIdx.x;
+    if (i0 >= n) return;
+    __shared__ int run[kBins];
+    __shared__ int tag[kTagSlots];
+    const int bshift = v.ds->bshift;
+    const int nchunks = sort_chunks(n);
+    for (int k = lane; k < kBins; k += kWave) run[k] = v.btable[(size_t)k * nchunks + chunk];
+    __syncthreads();
+    for (int r0 = 0; r0 < kSortChunk / kWave; r0 += kRoundsAhead) {
+        int c[kRoundsAhead];
+        float px[kRoundsAhead], py[kRoundsAhead], pz[kRoundsAhead], nx[kRoundsAhead], ny[kRoundsAhead], nz[kRoundsAhead];
+#pragma unroll
+        for (int k = 0; k < kRoundsAhead; ++k) {            // unconditional, clamped loads: all in flight together
+            const int i = i0 + (r0 + k) * kWave + lane, ic = min(i, n - 1);
+            const int cell = v.cid[ic];
+            c[k] = i < n ? cell : -2;
+            const float *p = point_at(v.xyz, v.xs, ic);
+            const float *q = point_at(v.nrmsrc, v.ns, ic);
+            px[k] = p[0]; py[k] = p[1]; pz[k] = p[2];
+            nx[k] = q[0]; ny[k] = q[1]; nz[k] = q[2];
+        }
+#pragma unroll
+        for (int k = 0; k < kRoundsAhead; ++k) {
+            const int i = i0 + (r0 + k) * kWave + lane;
+            const bool in = c[k] != -2;
+            const int key = c[k] < 0 ? kInvalidBin : (c[k] >> bshift);
+            int rank, cnt;
+            match_rank(key, in, 11, tag, lane, rank, cnt);
+            if (in) {
+                const int pos = run[key] + rank;
+                v.rec[2 * pos] = make_float4(px[k], py[k], pz[k], __int_as_float(i));       // one 32-byte sector
+                v.rec[2 * pos + 1] = make_float4(nx[k], ny[k], nz[k], __int_as_float(c[k]));
+                if (c[k] < 0) v.pos_of[i] = -1;
+            }
+            if (in && rank == cnt - 1) run[key] += cnt;      // after every lane's read above (one wave: in order)
+            wave_lds_fence();
+        }
+    }
+}
+
+// level 2, one workgroup of kSortWaves waves per bucket.  The bucket's records are cut into
+// kSortWaves consecutive pieces (index order), one per wave; every wave counts its piece per cell
+// (cnt[wave][cell] in LDS), the workgroup turns the counts into first positions per (cell, wave)
+// and writes cell_start[], then every wave walks its piece once more in index order: position =
+// its first position of the cell + points of that cell it has seen so far.  A bucket in a dense
+// part of the cloud holds thousands of points: with one wave per bucket the longest bucket set the
+// time of the whole kernel.
+//   LDS: cnt[kSortWaves][lds_cells] + tag[kSortWaves][kTagSlots]; a bucket of more than lds_cells
+//   cells (huge grids) is swept in slices of lds_cells cells.
+constexpr int kSortWaves = 4;
+constexpr int kCellsPerThread = 4;   // of the workgroup's scan: kSortWaves * 64 * kCellsPerThread >= lds_cells (<= 1024)
+
+__global__ __launch_bounds__(kSortWaves *kWave) void cell_sort_store_kernel(Batch b, int lds_cells, int nbits) {
+    extern __shared__ int lds[];
+    __shared__ int wsum[kSortWaves];
+    const ViewDev &v = b.view[blockIdx.y];
+    const DevState *ds = v.ds;
+    const GridDesc g = ds->grid;
+    const int bk = blockIdx.x, lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+    const int nb = ds->nbuckets, bshift = ds->bshift;
+    int *cell_start = v.cell_start;
+    if (g.ncells == 0) {
+        if (bk == 0 && threadIdx.x == 0) cell_start[0] = 0;
+        return;
+    }
+    if (bk >= nb) return;
+    int *cnt = lds + wid * lds_cells;                               // this wave's counters
+    int *tag = lds + kSortWaves * lds_cells + wid * kTagSlots;
+    const int nfinite = v.bstart[kBuckets];
+    const int s0 = v.bstart[bk], s1 = v.bstart[bk + 1];
+    if (bk == nb - 1 && threadIdx.x == 0) cell_start[g.ncells] = nfinite;
+    if (s0 == s1) {            // empty bucket (most of a sparse grid): every cell of it starts where the bucket does
+        const int c0 = bk << bshift, c1 = min(c0 + (1 << bshift), g.ncells);
+        for (int c = c0 + (int)threadIdx.x; c < c1; c += blockDim.x) cell_start[c] = s0;
+        return;
+    }
+    // this wave's piece [w0, w1): whole rounds of 64 records
+    const int piece = ((s1 - s0 + kSortWaves * kWave - 1) / (kSortWaves * kWave)) * kWave;
+    const int w0 = min(s0 + wid * piece, s1), w1 = min(w0 + piece, s1);
+    const int c_lo = bk << bshift;
+    const int c_hi = min(c_lo + (1 << bshift), g.ncells);
+    const float4 *rec = v.rec;
+    float4 *pts_out = v.pts, *nrm_out = v.nrm;
+    int sbase = s0;
+    for (int sub = c_lo; sub < c_hi; sub += lds_cells) {
+        const int m = min(lds_cells, c_hi - sub);
+        for (int k = lane; k < m; k += kWave) cnt[k] = 0;
+        wave_lds_fence();
+        for (int tb = w0; tb < w1; tb += kRoundsAhead * kWave) {
+            int cc[kRoundsAhead];
+#pragma unroll
+            for (int k = 0; k < kRoundsAhead; ++k) {        // unconditional loads, clamped: all in flight together
+                const int t = tb + k * kWave + lane;
+                const int y = __float_as_int(rec[2 * min(t, w1 - 1) + 1].w);
+                cc[k] = t < w1 ? y - sub : -1;
+            }
+#pragma unroll
+            for (int k = 0; k < kRoundsAhead; ++k)
+                if (cc[k] >= 0 && cc[k] < m) atomicAdd(&cnt[cc[k]], 1);
+        }
+        __syncthreads();
+        // per cell: counts of the waves -> exclusive prefix over the waves; total per cell
+        int tot[kCellsPerThread];
+        int mine = 0;
+#pragma unroll
+        for (int j = 0; j < kCellsPerThread; ++j) {
+            const int k = threadIdx.x * kCellsPerThread + j;
+            tot[j] = 0;
+            if (k < m) {
+                int run = 0;
+#pragma unroll
+                for (int w = 0; w < kSortWaves; ++w) {
+                    const int x = lds[w * lds_cells + k];
+                    lds[w * lds_cells + k] = run;
+                    run += x;
+                }
+                tot[j] = run;
+            }
+            mine += tot[j];
+        }
+        // exclusive scan of the cell totals over the workgroup (kCellsPerThread consecutive cells per thread)
+        int incl = mine;
+        for (int off = 1; off < kWave; off <<= 1) {
+            const int o = __shfl_up(incl, off);
+            if (lane >= off) incl += o;
+        }
+        if (lane == kWave - 1) wsum[wid] = incl;
+        __syncthreads();
+        int first = incl - mine, slice_total = 0;
+#pragma unroll
+        for (int w = 0; w < kSortWaves; ++w) {
+            first += w < wid ? wsum[w] : 0;
+            slice_total += wsum[w];
+        }
+#pragma unroll
+        for (int j = 0; j < kCellsPerThread; ++j) {
+            const int k = threadIdx.x * kCellsPerThread + j;
+            if (k < m) {
+                cell_start[sub + k] = sbase + first;                // first position of cell k
+#pragma unroll
+                for (int w = 0; w < kSortWaves; ++w) lds[w * lds_cells + k] += first;
+            }
+            first += tot[j];
+        }
+        __syncthreads();
+        // kRoundsAhead rounds at a time: all their records are requested together, then the rounds are
+        // ranked and stored one after the other (a wave's loads and stores retire in order: a round
+        // that waits for its own loads also waits for the stores of the round before)
+        for (int tb = w0; tb < w1; tb += kRoundsAhead * kWave) {
+            // (scalar arrays: an array of float4 indexed in an unrolled loop is left in scratch memory)
+            float ax[kRoundsAhead], ay[kRoundsAhead], az[kRoundsAhead], aw[kRoundsAhead];
+            float bx[kRoundsAhead], by[kRoundsAhead], bz[kRoundsAhead];
+            int bc[kRoundsAhead];
+#pragma unroll
+            for (int k = 0; k < kRoundsAhead; ++k) {
+                const int t = min(tb + k * kWave + lane, w1 - 1);
+                const float4 a4 = rec[2 * t], b4 = rec[2 * t + 1];
+                ax[k] = a4.x; ay[k] = a4.y; az[k] = a4.z; aw[k] = a4.w;
+                bx[k] = b4.x; by[k] = b4.y; bz[k] = b4.z; bc[k] = __float_as_int(b4.w);
+            }
+#pragma unroll
+            for (int k = 0; k < kRoundsAhead; ++k) {
+                const int cc = bc[k] - sub;
+                const bool in = tb + k * kWave + lane < w1 && cc >= 0 && cc < m;
+                int rank, same;
+                match_rank(cc, in, nbits, tag, lane, rank, same);
+                if (in) {
+                    const int pos = sbase + cnt[cc] + rank;
+                    pts_out[pos] = make_float4(ax[k], ay[k], az[k], aw[k]);
+                    nrm_out[pos] = make_float4(bx[k], by[k], bz[k], finite3(bx[k], by[k], bz[k]) ? 1.0f : 0.0f);
+                }
+                if (in && rank == same - 1) cnt[cc] += same;   // after every lane's read above (one wave: in order)
+                wave_lds_fence();
+            }
+        }
+        sbase += slice_total;
+        __syncthreads();
+    }
+}
+
+// pos_of[original index] = storage position (the points without a cell got -1 from the scatter)
+__global__ __launch_bounds__(256) void pos_of_kernel(Batch b) {
+    const ViewDev &v = b.view[blockIdx.y];
+    if (!v.want_pos_of) return;
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= v.n || s >= v.cell_start[v.ds->grid.ncells]) return;
+    v.pos_of[__float_as_int(v.pts[s].w)] = s;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1478,7 +1765,9 @@ static void run_scan(const ScanJobs &jobs, int nviews, hipStream_t st) {
 }
 
 // Index build ("initCompute") of every view of the batch: bounding box -> grid descriptor (on the
-// device) -> cell ids + counts -> scan -> scatter -> rank/store.  7 launches whatever the batch size.
+// device) -> two-level stable counting sort.  7 launches whatever the batch size (8 with pos_of[]).
+size_t btable_ints(int n) { return (size_t)kBins * (size_t)sort_chunks(n > 0 ? n : 1) + 2 * kBins; }
+
 void launch_index(const Batch &b, hipStream_t st) {
     const int nv = b.nviews, n = max_n(b);
     if (nv <= 0) return;
@@ -1488,19 +1777,29 @@ void launch_index(const Batch &b, hipStream_t st) {
         bbox_kernel<<<dim3(blocks, nv), 256, 0, st>>>(b);
     }
     grid_setup_kernel<<<dim3(1, nv), 64, 0, st>>>(b);
-    if (n > 0) cell_count_kernel<<<dim3(div_up(n, 256), nv), 256, 0, st>>>(b);
-    ScanJobs jobs;
-    jobs.zero_in = 1;
-    jobs.match = -1;
-    for (int v = 0; v < nv; ++v) {
-        const ViewDev &w = b.view[v];
-        jobs.job[v] = ScanJob{w.cnt, w.cell_start, nullptr, &w.ds->grid.ncells, w.cells_cap, w.scan_tmp};
+    if (n > 0) bucket_hist_kernel<<<dim3(sort_chunks(n), nv), kWave, 0, st>>>(b);
+    bucket_total_kernel<<<dim3(div_up(kBins, 256 / kWave), nv), 256, 0, st>>>(b);
+    bucket_offsets_kernel<<<dim3(div_up(kBins, 256 / kWave), nv), 256, 0, st>>>(b);
+    if (n > 0) bucket_scatter_kernel<<<dim3(sort_chunks(n), nv), kWave, 0, st>>>(b);
+    // cells of a bucket held in LDS at a time: what the largest cell table of the batch can need, at most
+    // 1024 (two cells per thread in the workgroup's scan; kSortWaves counters per cell)
+    int cap = 0;
+    for (int v = 0; v < nv; ++v) cap = b.view[v].cells_cap > cap ? b.view[v].cells_cap : cap;
+    int lds_cells = 64, nbits = 6;
+    while (lds_cells < 1024 && (long long)lds_cells * kBuckets < (long long)cap) {
+        lds_cells <<= 1;
+        ++nbits;
     }
-    run_scan(jobs, nv, st);
-    if (n > 0) {
-        scatter_kernel<<<dim3(div_up(n, 256), nv), 256, 0, st>>>(b);
-        rank_store_kernel<<<dim3(div_up(n, 256), nv), 256, 0, st>>>(b);
-    }
+    cell_sort_store_kernel<<<dim3(kBuckets, nv), kSortWaves * kWave,
+                             sizeof(int) * (size_t)kSortWaves * (size_t)(lds_cells + kTagSlots), st>>>(b, lds_cells, nbits);
+    bool want = false;
+    for (int v = 0; v < nv; ++v) want |= b.view[v].want_pos_of != 0;
+    if (want && n > 0) pos_of_kernel<<<dim3(div_up(n, 256), nv), 256, 0, st>>>(b);
+}
+
+void launch_pos_of(const Batch &b, hipStream_t st) {
+    const int n = max_n(b);
+    if (b.nviews > 0 && n > 0) pos_of_kernel<<<dim3(div_up(n, 256), b.nviews), 256, 0, st>>>(b);
 }
 
 size_t feat_bytes(int n, int F) { return sizeof(float) * (size_t)div_up(n > 0 ? n : 1, kLanes) * kLanes * (size_t)(F > 0 ? F : 1); }
