@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define KPL_VERSION 100
+#define KPL_VERSION 110
 
 typedef enum kpl_status {
     KPL_OK = 0,
@@ -171,9 +171,11 @@ int kpl_sync_status(kpl_detector *h, void *stream);
  * the recorded events, adds them up and clears the record. */
 typedef struct kpl_timing {
     int calls;            /* detect calls summed                                              */
-    float index_ms;       /* bbox + cell count + scan + scatter + rank/store                  */
-    float score_ms;       /* the feature + forest kernel (the dominant kernel)                */
+    float index_ms;       /* bounding box + the two-level counting sort of the index build    */
+    float score_ms;       /* feature_ms + forest_ms                                           */
     float nms_ms;         /* NMS + flag scan + compaction                                     */
+    float feature_ms;     /* the histogram feature kernel (the dominant kernel)               */
+    float forest_ms;      /* the forest kernel                                                */
 } kpl_timing;
 int kpl_enable_timing(kpl_detector *h, int enable);
 int kpl_get_timing(kpl_detector *h, kpl_timing *out);

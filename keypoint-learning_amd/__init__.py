@@ -39,7 +39,7 @@ class ForestSummary(C.Structure):
 
 class Timing(C.Structure):
     _fields_ = [("calls", C.c_int), ("index_ms", C.c_float), ("score_ms", C.c_float),
-                ("nms_ms", C.c_float)]
+                ("nms_ms", C.c_float), ("feature_ms", C.c_float), ("forest_ms", C.c_float)]
 
 
 class Stats(C.Structure):
@@ -387,7 +387,8 @@ class KeypointLearningDetector:
     def getTiming(self):
         t = Timing()
         self._check(self._lib.kpl_get_timing(self._h, C.byref(t)))
-        return {"calls": t.calls, "index_ms": t.index_ms, "score_ms": t.score_ms, "nms_ms": t.nms_ms}
+        return {"calls": t.calls, "index_ms": t.index_ms, "score_ms": t.score_ms, "nms_ms": t.nms_ms,
+                "feature_ms": t.feature_ms, "forest_ms": t.forest_ms}
 
     def collectStats(self, stream=None):
         self._push()

@@ -105,7 +105,7 @@ int fail(kpl_detector *h, int code, const char *fmt, ...) {
             return fail(h, KPL_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(e_));     \
     } while (0)
 
-constexpr size_t kMaxSpans = 3 * 4096;
+constexpr size_t kMaxSpans = 4 * 4096;
 
 // records an event on `st`; returns its pool slot or SIZE_MAX when timing is off / full
 size_t mark(kpl_detector *h, hipStream_t st) {
@@ -402,12 +402,15 @@ int run_batch(kpl_detector *const *handles, int count, float *const *d_scores, i
     if (idx.nviews) launch_index(idx, st);
     if (fix.nviews) launch_pos_of(fix, st);
     const size_t ev1 = mark(h0, st);
-    launch_score(all, st);
+    launch_feature_stage(all, st);
+    const size_t ev1b = mark(h0, st);
+    launch_forest_stage(all, st);
     const size_t ev2 = mark(h0, st);
     launch_post(all, st);
     const size_t ev3 = mark(h0, st);
     if (idx.nviews) span(h0, 0, ev0, ev1);
-    span(h0, 1, ev1, ev2);
+    span(h0, 1, ev1, ev1b);
+    span(h0, 3, ev1b, ev2);
     span(h0, 2, ev2, ev3);
     KPL_HIP(h0, hipGetLastError());
     for (int k = 0; k < count; ++k) {
@@ -838,7 +841,8 @@ int kpl_get_timing(kpl_detector *h, kpl_timing *out) {
         float ms = 0.0f;
         KPL_HIP(h, hipEventElapsedTime(&ms, h->ev_pool[sp.a], h->ev_pool[sp.b]));
         if (sp.phase == 0) out->index_ms += ms;
-        else if (sp.phase == 1) { out->score_ms += ms; out->calls++; }
+        else if (sp.phase == 1) { out->score_ms += ms; out->feature_ms += ms; out->calls++; }
+        else if (sp.phase == 3) { out->score_ms += ms; out->forest_ms += ms; }
         else out->nms_ms += ms;
     }
     h->spans.clear();

@@ -131,10 +131,11 @@ void init_dev_state(DevState *host_copy);
 void launch_index(const Batch &b, hipStream_t st);
 // pos_of[] of views indexed without it (want_pos_of must be set)
 void launch_pos_of(const Batch &b, hipStream_t st);
-// scoring ("runForest"): scores[i] (original order, may be null) and score_sorted[s]; NaN where not
-// scoreable; appends the points that pass the threshold to `cand` (or, without NMS, flags every
-// scoreable point)
-void launch_score(const Batch &b, hipStream_t st);
+// scoring ("runForest") in two kernels: features of every point -> feat (F x 64 blocks), then the
+// forest: scores[i] (original order, may be null) and score_sorted[s]; NaN where not scoreable;
+// appends the points that pass the threshold to `cand` (or, without NMS, flags every scoreable point)
+void launch_feature_stage(const Batch &b, hipStream_t st);
+void launch_forest_stage(const Batch &b, hipStream_t st);
 // NMS, draws pass, ordered compaction ("detectKeypoints").  flags[] / cand.count / skip[] must be
 // all zero on entry to a detect call; the compaction leaves them zeroed again
 void launch_post(const Batch &b, hipStream_t st);

@@ -1855,8 +1855,25 @@ static int cu_count() {
     return n;
 }
 
-// scoring ("runForest") of every view of the batch: the feature kernel, then the forest kernel
-void launch_score(const Batch &b, hipStream_t st) {
+// scoring ("runForest") of every view of the batch, first kernel: histogram features -> feat
+void launch_feature_stage(const Batch &b, hipStream_t st) {
+    const int n = max_n(b);
+    if (b.nviews <= 0 || n <= 0) return;
+    int maxF = 1;
+    bool stats = false;
+    for (int v = 0; v < b.nviews; ++v) {
+        maxF = b.view[v].f.F > maxF ? b.view[v].f.F : maxF;
+        stats |= b.view[v].stats != nullptr;
+    }
+    const int ecap = accept_words(maxF);
+    const size_t lds = feature_lds_bytes(maxF, ecap);
+    const dim3 grid(div_up(n, kLanes), b.nviews);
+    if (stats) feature_kernel<true><<<grid, kLanes, lds, st>>>(b, maxF, ecap);
+    else feature_kernel<false><<<grid, kLanes, lds, st>>>(b, maxF, ecap);
+}
+
+// second kernel: feat -> forest response (score_sorted, scores) and the NMS candidates
+void launch_forest_stage(const Batch &b, hipStream_t st) {
     const int n = max_n(b);
     if (b.nviews <= 0 || n <= 0) return;
     int maxF = 1, max_nodes = 1;
@@ -1866,21 +1883,13 @@ void launch_score(const Batch &b, hipStream_t st) {
         max_nodes = b.view[v].forest.nnodes > max_nodes ? b.view[v].forest.nnodes : max_nodes;
         stats |= b.view[v].stats != nullptr;
     }
-    const int ecap = accept_words(maxF);
-    const size_t lds = feature_lds_bytes(maxF, ecap);
-    const dim3 grid(div_up(n, kLanes), b.nviews);
     const ForestLaunch fl = forest_launch(maxF, max_nodes);
     int wgs = div_up(cu_count(), b.nviews);                   // persistent: about one workgroup per CU
     const int wgs_max = div_up(div_up(n, kLanes), fl.waves);
     if (wgs > wgs_max) wgs = wgs_max;
     const dim3 fgrid(wgs, b.nviews);
-    if (stats) {
-        feature_kernel<true><<<grid, kLanes, lds, st>>>(b, maxF, ecap);
-        forest_kernel<true><<<fgrid, fl.waves * kLanes, fl.lds, st>>>(b, maxF, fl.nlds_cap);
-    } else {
-        feature_kernel<false><<<grid, kLanes, lds, st>>>(b, maxF, ecap);
-        forest_kernel<false><<<fgrid, fl.waves * kLanes, fl.lds, st>>>(b, maxF, fl.nlds_cap);
-    }
+    if (stats) forest_kernel<true><<<fgrid, fl.waves * kLanes, fl.lds, st>>>(b, maxF, fl.nlds_cap);
+    else forest_kernel<false><<<fgrid, fl.waves * kLanes, fl.lds, st>>>(b, maxF, fl.nlds_cap);
 }
 
 void launch_features(const float4 *pts, const float4 *nrm, const int *cell_start,

@@ -1,18 +1,23 @@
 #!/bin/bash
 # usage (on the GPU box, via gpurun): tools/prof.sh <tag> [bench args]
-# 1. bench.py under rocprofv3 --kernel-trace --stats (csv)   -> gpurun_out/<tag>_trace/
-# 2. own passes for --pmc FETCH_SIZE and --pmc WRITE_SIZE     -> gpurun_out/pmc_<tag>_fetch|write/
-# every step has its own timeout; nothing here reads stdin
+# 1. bench.py under rocprofv3 --kernel-trace --stats (csv)                      -> gpurun_out/<tag>_trace/
+# 2. own passes for --pmc FETCH_SIZE, --pmc WRITE_SIZE and one SQ counter set   -> gpurun_out/pmc_<tag>_{fetch,write,sq}/
+# 3. the hash of the kernel sources the counters were taken on                  -> gpurun_out/<tag>_sha256.txt
+# Back in the build container: python tools/save_profile.py <tag>  (copies the summaries to profiles/ and
+# refreshes profiles/counters.json, which bench.py quotes only while that hash matches its own kernels).
+# Every step has its own timeout; nothing here reads stdin.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
+python3 -c "import sys; sys.path.insert(0, '$R'); import bench; print(bench.kernel_source_sha256())" > $R/gpurun_out/${tag}_sha256.txt
 rm -rf $R/gpurun_out/${tag}_trace
-timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_trace -- python3 $R/bench.py --lean --steps 100 --warmup 10 "$@" > $R/gpurun_out/${tag}_trace.log 2>&1 < /dev/null
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_trace -- python3 $R/bench.py --lean --steps 40 --warmup 10 --repeats 2 "$@" > $R/gpurun_out/${tag}_trace.log 2>&1 < /dev/null
 echo "trace rc=$?"
 grep '^{"metric' $R/gpurun_out/${tag}_trace.log | tail -1 > $R/gpurun_out/${tag}_bench.json
 f=$(find $R/gpurun_out/${tag}_trace -name "*kernel_stats.csv" | head -1)
-[ -n "$f" ] && cut -c1-160 "$f"
-for c in FETCH_SIZE WRITE_SIZE; do
-  l=$(echo $c | cut -d_ -f1 | tr A-Z a-z)
-  bash $R/tools/pmc.sh ${tag}_$l $c "$@" < /dev/null | cut -c1-300
-done
+[ -n "$f" ] && cut -c1-160 "$f" | head -14
+# keep what travels back small: the per-dispatch trace is not needed, the stats are
+find $R/gpurun_out/${tag}_trace -name "*kernel_trace.csv" -delete
+bash $R/tools/pmc.sh ${tag}_fetch FETCH_SIZE "$@" < /dev/null | cut -c1-200 | grep -A2 "feature_kernel<false>\|forest_kernel<false>"
+bash $R/tools/pmc.sh ${tag}_write WRITE_SIZE "$@" < /dev/null | cut -c1-200 | grep -A2 "feature_kernel<false>\|forest_kernel<false>"
+bash $R/tools/pmc.sh ${tag}_sq "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE" "$@" < /dev/null | cut -c1-200 | grep -A9 "feature_kernel<false>\|forest_kernel<false>"

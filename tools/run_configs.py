@@ -68,7 +68,8 @@ def time_gpu(det, xyz, nrm, reps=30, batch=10):
     det.enableTiming(False)
     cnt = int(dk[0].item())
     return (float(np.median(times)), ds.cpu().numpy(), dk[1:1 + cnt].cpu().numpy(),
-            {k: tm[k] / max(tm["calls"], 1) for k in ("index_ms", "score_ms", "nms_ms")}, det.collectStats(st))
+            {k: tm[k] / max(tm["calls"], 1) for k in ("index_ms", "score_ms", "feature_ms", "forest_ms", "nms_ms")},
+            det.collectStats(st))
 
 
 def time_cpu(xyz, nrm, A, B, r, rn, thr, of, budget=12.0):
@@ -113,14 +114,16 @@ def report(name, xyz, nrm, A, B, rmul_f, rmul_n, thr, forest, fa, extra=None):
     ok = bool(np.array_equal(np.asarray(sc).view(np.uint32), o_sc.view(np.uint32)) and np.array_equal(kp, o_kp))
     n = len(xyz)
     b_alg = 24 * (st["n_scored"] + st["sum_kf"]) + 16 * st["sum_kn"] + 8 * st["sum_depth"] + 8 * st["n_scored"]
-    b_score = 24 * (st["n_scored"] + st["sum_kf"]) + 8 * st["sum_depth"] + 4 * st["n_scored"]
+    b_feat = 24 * (st["n_scored"] + st["sum_kf"])            # gather model, feature kernel / forest kernel
+    b_forest = 8 * st["sum_depth"] + 4 * st["n_scored"]
     row = {"config": name, "N": n, "AxB": "%dx%d" % (A, B), "T": fa.ntrees, "nodes": int(fa.nnodes), "r_feat": "%g*mr" % rmul_f,
            "mr": round(mr, 5), "gpu_Mpts": round(n / t / 1e6, 2), "gpu_ms": round(t * 1e3, 4),
            "phases_ms": {k: round(v, 4) for k, v in phases.items()},
            "K_f": round(st["sum_kf"] / max(st["n_scored"], 1), 1), "depth_per_pt": round(st["sum_depth"] / max(st["n_scored"], 1), 1),
            "B_alg_per_pt": round(b_alg / max(st["n_scored"], 1), 1),
-           "score_kernel_alg_GBps": round(b_score / (phases["score_ms"] * 1e-3) / 1e9, 1),
-           "score_kernel_frac_of_8TBps": round(b_score / (phases["score_ms"] * 1e-3) / 8e12, 4),
+           "feature_kernel_alg_GBps": round(b_feat / (phases["feature_ms"] * 1e-3) / 1e9, 1),
+           "feature_kernel_frac_of_8TBps": round(b_feat / (phases["feature_ms"] * 1e-3) / 8e12, 4),
+           "forest_kernel_alg_GBps": round(b_forest / (phases["forest_ms"] * 1e-3) / 1e9, 1),
            "keypoints": int(len(kp)), "parity": ok}
     row.update(cpu)
     if extra:

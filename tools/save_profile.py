@@ -1,9 +1,15 @@
-"""Copies the judged summaries of a profiling run from gpurun_out/ (scratch) into profiles/ (tracked):
-   python tools/save_profile.py <tag> <trace_dir> <pmc_fetch_dir> <pmc_write_dir> [bench_json]
-Writes profiles/<tag>_kernel_stats.csv, profiles/<tag>_pmc.json and refreshes profiles/traffic.json
-(what bench.py reports as roofline.traffic): HBM bytes per launch of the score kernel =
-2 x FETCH_SIZE (gfx950 counts a 16-B-per-lane read at half its bytes, MI355X_MICROARCH.md "HBM")
-+ WRITE_SIZE, both in KiB from separate --pmc passes."""
+"""Copies the judged summaries of a profiling run (tools/prof.sh <tag>, merged back into gpurun_out/) into profiles/
+(tracked) and refreshes profiles/counters.json -- what bench.py quotes as roofline.traffic / valu_busy /
+hbm_counter_frac, and only while the recorded hash of the kernel sources equals that of the kernels it runs.
+
+    python tools/save_profile.py <tag>
+
+Writes profiles/<tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats), profiles/<tag>_pmc.json (per-kernel means of
+the --pmc passes), profiles/<tag>_bench.json (the bench line printed under the tracer) and profiles/counters.json.
+HBM bytes per launch = 2 x FETCH_SIZE (gfx950 counts a 16-B-per-lane read at half its bytes, MI355X_MICROARCH.md
+"HBM") + WRITE_SIZE, both in KiB from separate --pmc passes; VALU busy = SQ_ACTIVE_INST_VALU x 4 / (SIMDs x cycles),
+cycles = GRBM_GUI_ACTIVE / 8 XCDs; waves per SIMD = SQ_WAVE_CYCLES x 4 / (SIMDs x cycles)."""
+import csv
 import glob
 import json
 import os
@@ -14,40 +20,73 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from pmc_summary import summarize  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SIMDS = 256 * 4
+XCDS = 8
+
+
+def mean(v):
+    return sum(v) / len(v) if v else None
 
 
 def main():
-    tag, trace, fetch, write = sys.argv[1:5]
+    tag = sys.argv[1]
+    out_dir = os.path.join(ROOT, "gpurun_out")
     prof = os.path.join(ROOT, "profiles")
     os.makedirs(prof, exist_ok=True)
-    stats = sorted(glob.glob(os.path.join(trace, "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime)
+    sha = open(os.path.join(out_dir, tag + "_sha256.txt")).read().strip()
+    stats = sorted(glob.glob(os.path.join(out_dir, tag + "_trace", "**", "*_kernel_stats.csv"), recursive=True),
+                   key=os.path.getmtime)
+    avg_ns, calls = {}, {}
     if stats:
         shutil.copy(stats[-1], os.path.join(prof, tag + "_kernel_stats.csv"))
-    out = {}
-    for name, d in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write)):
-        agg, meta = summarize(d)
-        for k, v in agg.items():
-            vals = v.get(name, [])
-            if vals:
-                out.setdefault(k, {})[name + "_KiB_mean"] = sum(vals) / len(vals)
-                out[k]["launches_" + name] = len(vals)
-                out[k]["vgpr/agpr/sgpr/lds/scratch/wg/grid"] = meta[k]
-    json.dump(out, open(os.path.join(prof, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
-    sk = out.get("score_kernel<false>", {})
-    views = 1
-    if len(sys.argv) > 5 and os.path.exists(sys.argv[5]):
-        try:
-            views = int(json.load(open(sys.argv[5]))["config"].get("views_per_launch", 1))
-        except Exception:
-            pass
-    if "FETCH_SIZE_KiB_mean" in sk and "WRITE_SIZE_KiB_mean" in sk:
-        traffic = (2.0 * sk["FETCH_SIZE_KiB_mean"] + sk["WRITE_SIZE_KiB_mean"]) * 1024.0
-        json.dump({"score_kernel_hbm_bytes_per_launch": int(traffic), "views_per_launch": views, "source": tag + "_pmc.json",
-                   "formula": "(2*FETCH_SIZE + WRITE_SIZE) KiB, separate rocprofv3 --pmc passes"},
-                  open(os.path.join(prof, "traffic.json"), "w"), indent=1)
-    if len(sys.argv) > 5 and os.path.exists(sys.argv[5]):
-        shutil.copy(sys.argv[5], os.path.join(prof, tag + "_bench.json"))
-    print("saved", tag, "->", prof)
+        for r in csv.DictReader(open(stats[-1])):
+            name = r["Name"]
+            for k in ("feature_kernel<false>", "forest_kernel<false>", "nms_kernel<false>", "cell_sort_store_kernel",
+                      "bucket_scatter_kernel", "bucket_hist_kernel"):
+                if k in name:
+                    avg_ns[k] = float(r["AverageNs"])
+                    calls[k] = int(r["Calls"])
+    pmc = {}
+    for suffix in ("fetch", "write", "sq"):
+        agg, meta = summarize(os.path.join(out_dir, "pmc_%s_%s" % (tag, suffix)))
+        for k, counters in agg.items():
+            for c, vals in counters.items():
+                pmc.setdefault(k, {})[c] = mean(vals)
+                pmc[k]["launches_" + c] = len(vals)
+            pmc[k]["vgpr/agpr/sgpr/lds/scratch/wg/grid"] = meta[k]
+    json.dump(pmc, open(os.path.join(prof, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
+    bench_json = os.path.join(out_dir, tag + "_bench.json")
+    views = None
+    if os.path.exists(bench_json) and os.path.getsize(bench_json) > 0:
+        shutil.copy(bench_json, os.path.join(prof, tag + "_bench.json"))
+        views = json.load(open(bench_json))["config"].get("views_per_launch")
+    kernels = {}
+    for k in ("feature_kernel<false>", "forest_kernel<false>"):
+        c = pmc.get(k)
+        if not c:
+            continue
+        e = {"rocprof_avg_ns": avg_ns.get(k), "rocprof_calls": calls.get(k)}
+        if c.get("FETCH_SIZE") is not None and c.get("WRITE_SIZE") is not None:
+            e["fetch_KiB"], e["write_KiB"] = round(c["FETCH_SIZE"], 1), round(c["WRITE_SIZE"], 1)
+            e["hbm_bytes"] = int((2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0)
+        if c.get("GRBM_GUI_ACTIVE"):
+            cycles = c["GRBM_GUI_ACTIVE"] / XCDS
+            e["cycles_per_xcd"] = round(cycles, 1)
+            if c.get("SQ_ACTIVE_INST_VALU") is not None:
+                e["valu_busy"] = round(c["SQ_ACTIVE_INST_VALU"] * 4.0 / (SIMDS * cycles), 4)
+            if c.get("SQ_WAVE_CYCLES") is not None:
+                e["waves_per_simd"] = round(c["SQ_WAVE_CYCLES"] * 4.0 / (SIMDS * cycles), 3)
+            for name in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "SQ_INSTS_VMEM_RD"):
+                if c.get(name) is not None:
+                    e[name] = round(c[name], 1)
+        kernels[k.split("<")[0]] = e
+    json.dump({"tag": tag, "source_sha256": sha, "views_per_launch": views, "kernels": kernels,
+               "formulas": {"hbm_bytes": "(2*FETCH_SIZE + WRITE_SIZE) KiB * 1024, separate rocprofv3 --pmc passes",
+                            "valu_busy": "SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * GRBM_GUI_ACTIVE / 8)",
+                            "waves_per_simd": "SQ_WAVE_CYCLES * 4 / (1024 SIMDs * GRBM_GUI_ACTIVE / 8)"},
+               "files": [tag + "_kernel_stats.csv", tag + "_pmc.json", tag + "_bench.json"]},
+              open(os.path.join(prof, "counters.json"), "w"), indent=1)
+    print("saved", tag, "->", prof, "kernels:", sorted(kernels))
 
 
 if __name__ == "__main__":
