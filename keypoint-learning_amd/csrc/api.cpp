@@ -355,7 +355,7 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
         KPL_HIP(h, h->draw_count.ensure(sizeof(int)));
     }
     v.f = make_feat(h->prm);
-    v.forest = ForestDev{h->d_nodes.as<uint2>(), h->d_roots.as<uint32_t>(), h->flat.ntrees, (int)h->flat.nodes.size()};
+    v.forest = ForestDev{h->d_nodes.as<uint2>(), h->flat.ntrees, (int)h->flat.nodes.size(), h->flat.order_free ? 1 : 0};
     v.nd = nd;
     v.feat = h->feat.as<float>();
     v.score_sorted = h->score_sorted.as<float>();
@@ -624,7 +624,7 @@ int kpl_forest_info(const kpl_detector *h, int *ntrees, int *var_count, int64_t 
     if (!h->has_forest) return KPL_ERR_NO_FOREST;
     if (ntrees) *ntrees = h->flat.ntrees;
     if (var_count) *var_count = h->flat.var_count;
-    if (nnodes) *nnodes = (int64_t)h->flat.nodes.size();
+    if (nnodes) *nnodes = h->flat.nnodes;
     if (max_depth) *max_depth = h->flat.max_depth;
     return KPL_OK;
 }
@@ -655,7 +655,7 @@ int kpl_forest_inspect(const void *data, size_t len, kpl_forest_summary *out, ch
     }
     out->ntrees = flat.ntrees;
     out->var_count = flat.var_count;
-    out->nnodes = (int64_t)flat.nodes.size();
+    out->nnodes = flat.nnodes;
     out->max_depth = flat.max_depth;
     return KPL_OK;
 }

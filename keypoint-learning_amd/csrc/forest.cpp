@@ -384,51 +384,106 @@ bool flatten_forest(const ForestModel &m, FlatForest &out, std::string &err) {
     out.ntrees = m.ntrees();
     out.var_count = m.var_count;
     out.nodes.reserve((size_t)nn);
+    out.order_free = m.ntrees() <= (1 << 15);
     std::vector<char> seen((size_t)nn, 0);
-    // ONE breadth-first pass over the whole forest: the roots of all trees first (root of tree t =
-    // node t), then the second level of all trees, and so on.  A node's record is emitted when it is
-    // dequeued; its two children get adjacent slots reserved at that moment.  The first k nodes are
-    // therefore the top levels of EVERY tree -- the part the forest kernel keeps in LDS.
+    // Top part: ONE breadth-first pass over the whole forest, level by level: the roots of all trees
+    // first (root of tree t = node t), then the second level of all trees, and so on, while the whole
+    // next level still fits kTopNodes slots.  A node's record is written when it is visited; its two
+    // children get adjacent slots reserved at that moment.
     struct Item { int src; uint32_t dst; int depth; };
-    std::deque<Item> q;
-    for (int t = 0; t < m.ntrees(); ++t) {
-        const int r = m.root[t];
-        if (r < 0 || r >= nn) { err = "root index out of range"; return false; }
-        out.roots.push_back((uint32_t)out.nodes.size());
-        out.nodes.push_back(FlatNode{0, 0});
-        q.push_back(Item{r, out.roots.back(), 1});
-    }
-    while (!q.empty()) {
-        Item it = q.front();
-        q.pop_front();
-        if (seen[it.src]) { err = "node reachable twice (not a tree)"; return false; }
+    auto emit = [&](const Item &it, uint32_t lpos, std::string &e) -> int {   // 1 = internal, 0 = leaf, -1 = error
+        if (seen[it.src]) { e = "node reachable twice (not a tree)"; return -1; }
         seen[it.src] = 1;
         if (it.depth > out.max_depth) out.max_depth = it.depth;
         FlatNode fn;
         if (m.var[it.src] < 0) {
             const float v = (float)m.value[it.src];
             // (double)v != value also rejects NaN; +-Inf leaves would make the tree sum Inf - Inf = NaN
-            if (!std::isfinite(m.value[it.src]) || (double)v != m.value[it.src]) {
-                err = "leaf value is not a finite float";
-                return false;
-            }
+            if (!std::isfinite(m.value[it.src]) || (double)v != m.value[it.src]) { e = "leaf value is not a finite float"; return -1; }
+            if (!(std::fabs(v) <= 32768.0f) || v != std::floor(v)) out.order_free = false;
             memcpy(&fn.x, &v, 4);
             fn.y = kLeafVar << 24;
-        } else {
-            const int l = m.left[it.src], rr = m.right[it.src];
-            if (m.var[it.src] >= m.var_count) { err = "split variable >= var_count"; return false; }
-            if (l < 0 || l >= nn || rr < 0 || rr >= nn) { err = "split node without two children"; return false; }
-            if (!std::isfinite(m.thr[it.src])) { err = "non-finite split threshold"; return false; }
-            const uint32_t lpos = (uint32_t)out.nodes.size();
-            if (lpos + 2 > kMaxFlatNodes) { err = "forest has more than 2^24 nodes"; return false; }
-            out.nodes.push_back(FlatNode{0, 0});
-            out.nodes.push_back(FlatNode{0, 0});
-            memcpy(&fn.x, &m.thr[it.src], 4);
-            fn.y = ((uint32_t)m.var[it.src] << 24) | lpos;
-            q.push_back(Item{l, lpos, it.depth + 1});
-            q.push_back(Item{rr, lpos + 1, it.depth + 1});
+            out.nodes[it.dst] = fn;
+            return 0;
         }
+        const int l = m.left[it.src], rr = m.right[it.src];
+        if (m.var[it.src] >= m.var_count) { e = "split variable >= var_count"; return -1; }
+        if (l < 0 || l >= nn || rr < 0 || rr >= nn) { e = "split node without two children"; return -1; }
+        if (!std::isfinite(m.thr[it.src])) { e = "non-finite split threshold"; return -1; }
+        memcpy(&fn.x, &m.thr[it.src], 4);
+        fn.y = ((uint32_t)m.var[it.src] << 24) | lpos;
         out.nodes[it.dst] = fn;
+        return 1;
+    };
+    out.nnodes = nn;
+    std::vector<Item> level, next;
+    for (int t = 0; t < m.ntrees(); ++t) {
+        const int r = m.root[t];
+        if (r < 0 || r >= nn) { err = "root index out of range"; return false; }
+        out.roots.push_back((uint32_t)out.nodes.size());
+        out.nodes.push_back(FlatNode{0, 0});
+        level.push_back(Item{r, out.roots.back(), 1});
+    }
+    std::vector<Item> pairs;          // left members of the sibling pairs that start the blocked part
+    while (!level.empty()) {
+        size_t internal = 0;
+        for (const Item &it : level) internal += m.var[it.src] >= 0 ? 1 : 0;
+        const bool top = out.nodes.size() + 2 * internal <= (size_t)kTopNodes;
+        next.clear();
+        for (const Item &it : level) {
+            if (m.var[it.src] >= 0 && !top) {       // its children start a block: slot known only then
+                pairs.push_back(it);
+                continue;
+            }
+            const uint32_t lpos = (uint32_t)out.nodes.size();
+            const int kind = emit(it, lpos, err);
+            if (kind < 0) return false;
+            if (kind == 1) {
+                out.nodes.push_back(FlatNode{0, 0});
+                out.nodes.push_back(FlatNode{0, 0});
+                next.push_back(Item{m.left[it.src], lpos, it.depth + 1});
+                next.push_back(Item{m.right[it.src], lpos + 1, it.depth + 1});
+            }
+        }
+        if (!top) break;
+        level.swap(next);
+    }
+    // Blocked part: every pending internal node gets a 16-slot block for its descendants, three levels
+    // of them: slots [0,1] its children, [2,3] / [4,5] their children, [6..13] the grandchildren's
+    // level; the children of THAT level start blocks of their own.
+    while (!pairs.empty()) {
+        const Item parent = pairs.back();
+        pairs.pop_back();
+        size_t base = out.nodes.size();
+        base = (base + kBlockSlots - 1) / kBlockSlots * kBlockSlots;
+        if (base + kBlockSlots > (size_t)kMaxFlatNodes) { err = "forest needs more than 2^24 node slots"; return false; }
+        out.nodes.resize(base + kBlockSlots, FlatNode{0, 0});
+        if (emit(parent, (uint32_t)base, err) < 0) return false;                  // the parent's record points at slot 0
+        // slot s of the block holds the node src[s]; children of slot s (s < 6) live at slots 2 + 2s, 3 + 2s
+        int src[kBlockSlots];
+        int depth[kBlockSlots];
+        for (uint32_t k = 0; k < kBlockSlots; ++k) src[k] = -1;
+        src[0] = m.left[parent.src];
+        src[1] = m.right[parent.src];
+        depth[0] = depth[1] = parent.depth + 1;
+        for (uint32_t sl = 0; sl < 14; ++sl) {
+            if (src[sl] < 0) continue;
+            const Item it{src[sl], (uint32_t)(base + sl), depth[sl]};
+            if (sl < 6) {
+                const uint32_t c = 2 + 2 * sl;
+                const int kind = emit(it, (uint32_t)(base + c), err);
+                if (kind < 0) return false;
+                if (kind == 1) {
+                    src[c] = m.left[it.src];
+                    src[c + 1] = m.right[it.src];
+                    depth[c] = depth[c + 1] = it.depth + 1;
+                }
+            } else if (m.var[it.src] >= 0) {
+                pairs.push_back(it);                 // emitted when its own block is placed
+            } else if (emit(it, 0u, err) < 0) {
+                return false;
+            }
+        }
     }
     return true;
 }

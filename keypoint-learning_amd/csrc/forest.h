@@ -28,22 +28,32 @@ struct ForestModel {
 // Device layout: one 8-byte record per node.
 //   x = threshold bits (internal) or leaf value as float bits (leaf)
 //   y = [31:24] split variable (0..254; 255 = leaf)   [23:0] index of the LEFT child
-// Siblings are adjacent (right = left + 1).  The whole forest is laid out breadth first, level by
-// level ACROSS the trees: node t is the root of tree t, then come the second levels of all trees,
-// and so on -- the first k nodes are the top of every tree (what the forest kernel stages in LDS).
+// Siblings are adjacent (right = left + 1).  The forest is laid out breadth first, level by level
+// ACROSS the trees: node t is the root of tree t, then come the second levels of all trees, and so
+// on -- the first k nodes are the top of every tree (what the forest kernel stages in LDS) -- for
+// as many whole levels as fit kTopNodes slots.  What lies below is laid out for the cache line:
+// blocks of 16 slots (128 bytes) holding a sibling pair, its 4 children and its 8 grandchildren,
+// so that a walk through global memory touches one line per three levels instead of one per level
+// (a 100-tree forest of 2 M nodes is 16 MB: its deep nodes come from beyond the L2).  Slots that
+// hold no node are never referenced.
 struct FlatNode {
     uint32_t x;
     uint32_t y;
 };
 constexpr uint32_t kLeafVar = 255u;
-constexpr uint32_t kMaxFlatNodes = 1u << 24;
+constexpr uint32_t kMaxFlatNodes = 1u << 24;   // slots, padding of the blocked part included
+constexpr uint32_t kTopNodes = 8192;           // = the forest kernel's LDS node budget (64 KB)
+constexpr uint32_t kBlockSlots = 16;
 
 struct FlatForest {
     int ntrees = 0;
     int var_count = 0;
     int max_depth = 0;               // longest root->leaf path, counted in nodes
-    std::vector<uint32_t> roots;     // [ntrees] node index of each root
-    std::vector<FlatNode> nodes;
+    bool order_free = false;         // every leaf value is an integer of magnitude <= 2^15 and there are at most 2^15
+                                     // trees: the sum of leaf values is exact in any order (and fits an int32)
+    std::vector<uint32_t> roots;     // [ntrees] node index of each root (= the tree's number)
+    std::vector<FlatNode> nodes;     // slots
+    int64_t nnodes = 0;              // nodes of the model (nodes.size() counts padding slots too)
 };
 
 // Parses OpenCV FileStorage YAML text of a cv::ml::RTrees / DTrees / legacy CvRTrees model.

@@ -55,10 +55,10 @@ struct NmsList {
 };
 
 struct ForestDev {
-    const uint2 *nodes;      // level-major (forest.h): the first k nodes are the top of every tree
-    const uint32_t *roots;
+    const uint2 *nodes;      // level-major (forest.h): node t is the root of tree t, the first k nodes are the top of every tree
     int ntrees;
     int nnodes;
+    int order_free;          // FlatForest::order_free: the trees of a point may be summed in any order
 };
 
 struct StatsDev {

@@ -1026,42 +1026,56 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
 // The first `nlds` nodes of the (level-major) forest are read from LDS, deeper ones from global
 // memory: 64 lanes at 64 different nodes are 64 cache lines for one load instruction, and the
 // texture path takes about a cycle per line -- the LDS serves the same request in a few cycles.
-// The walk is written without data-dependent branches: a lane that has reached a leaf keeps
-// re-reading that leaf, the split variable of a leaf reads feature 0 and is ignored, and all node
-// reads of a level are issued before the first one is used, then all feature reads -- one LDS round
-// trip each per level for all ways together.
+// The walk is written without data-dependent branches: a walk that has reached its leaf is parked on
+// the root of its tree (a node in LDS) with its leaf value kept in a register, the split variable of
+// a leaf reads feature 0 and is ignored, and all node reads of a level are issued before the first
+// one is used, then all feature reads -- one LDS round trip each per level for all ways together.
+// Lanes whose node is in LDS send their global load to node 0: the requests of a wave are served
+// line by line, and one shared line costs one cycle however many lanes ask for it.
 constexpr int kTreeWays = 10;
 
-template <bool STATS>
+template <int WAYS>
+__device__ __forceinline__ void fetch_nodes(const ForestDev &forest, const uint2 *lnodes, uint32_t last_lds,
+                                            bool all_in_lds, const uint32_t (&nd)[WAYS], uint2 (&node)[WAYS]) {
+#pragma unroll
+    for (int k = 0; k < WAYS; ++k) node[k] = lnodes[min(nd[k], last_lds)];
+    if (!all_in_lds) {      // deep nodes of a large forest: global memory, all ways issued before the first use
+        bool far_any = false;
+#pragma unroll
+        for (int k = 0; k < WAYS; ++k) far_any |= nd[k] > last_lds;
+        if (__any(far_any)) {
+            uint2 far[WAYS];
+#pragma unroll
+            for (int k = 0; k < WAYS; ++k)      // 32-bit byte offset from the uniform base (< 2^24 slots of 8 bytes)
+                far[k] = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(forest.nodes) +
+                                                          ((nd[k] > last_lds ? nd[k] : 0u) << 3));
+#pragma unroll
+            for (int k = 0; k < WAYS; ++k) node[k] = nd[k] > last_lds ? far[k] : node[k];
+        }
+    }
+}
+
+// PARK = false: the whole forest is in LDS; a finished walk simply keeps re-reading its leaf (the
+// leanest loop).  PARK = true: part of the forest is in global memory; a finished walk is parked on the
+// root of its tree with its leaf value kept in a register, so that it costs no more global loads.
+template <bool STATS, bool PARK>
 __device__ __forceinline__ float forest_sum(const ForestDev &forest, const uint2 *lnodes, int nlds,
                                             const float *x, int &depth) {
     double sum = 0.0;
-    const bool all_in_lds = nlds >= forest.nnodes;
     const uint32_t last_lds = (uint32_t)(nlds - 1);
     for (int t0 = 0; t0 < forest.ntrees; t0 += kTreeWays) {
         uint32_t nd[kTreeWays];
         uint2 node[kTreeWays];
-        bool was_leaf[kTreeWays];      // STATS only: the way had reached its leaf before this read
+        float leafval[kTreeWays];
+        bool done[kTreeWays];          // PARK, or STATS: the walk had reached its leaf before this read
 #pragma unroll
         for (int k = 0; k < kTreeWays; ++k) {
-            nd[k] = forest.roots[t0 + k < forest.ntrees ? t0 + k : t0];
-            was_leaf[k] = t0 + k >= forest.ntrees;
+            nd[k] = t0 + k < forest.ntrees ? t0 + k : t0;       // level-major layout: the root of tree t is node t
+            done[k] = t0 + k >= forest.ntrees;
+            leafval[k] = 0.0f;
         }
         for (;;) {
-#pragma unroll
-            for (int k = 0; k < kTreeWays; ++k) node[k] = lnodes[min(nd[k], last_lds)];
-            if (!all_in_lds) {      // deep nodes of a large forest: global memory, all ways issued before the first use
-                bool far_any = false;
-#pragma unroll
-                for (int k = 0; k < kTreeWays; ++k) far_any |= nd[k] > last_lds;
-                if (__any(far_any)) {
-                    uint2 far[kTreeWays];
-#pragma unroll
-                    for (int k = 0; k < kTreeWays; ++k) far[k] = forest.nodes[nd[k]];
-#pragma unroll
-                    for (int k = 0; k < kTreeWays; ++k) node[k] = nd[k] > last_lds ? far[k] : node[k];
-                }
-            }
+            fetch_nodes<kTreeWays>(forest, lnodes, last_lds, !PARK, nd, node);
             float val[kTreeWays];
             bool leaf[kTreeWays];
 #pragma unroll
@@ -1070,24 +1084,82 @@ __device__ __forceinline__ float forest_sum(const ForestDev &forest, const uint2
                 leaf[k] = var == 255u;
                 val[k] = x[(leaf[k] ? 0u : var) * kLanes];
             }
-            bool all_leaves = true;
+            bool all_done = true;
 #pragma unroll
             for (int k = 0; k < kTreeWays; ++k) {
                 const uint32_t next = (node[k].y & 0x00ffffffu) + (val[k] <= __uint_as_float(node[k].x) ? 0u : 1u);
-                if (STATS) {
-                    depth += was_leaf[k] ? 0 : 1;   // visited nodes: internal ones and the leaf, once
-                    was_leaf[k] = leaf[k];
+                if (STATS) depth += done[k] ? 0 : 1;            // visited nodes: internal ones and the leaf, once
+                if (PARK) {
+                    const bool arrives = leaf[k] & !done[k];
+                    leafval[k] = arrives ? __uint_as_float(node[k].x) : leafval[k];
+                    done[k] |= leaf[k];
+                    nd[k] = done[k] ? (uint32_t)t0 : next;      // parked on a root: a node that is always in LDS
+                    all_done &= done[k];
+                } else {
+                    if (STATS) done[k] = leaf[k];
+                    nd[k] = leaf[k] ? nd[k] : next;
+                    all_done &= leaf[k];
                 }
-                nd[k] = leaf[k] ? nd[k] : next;
-                all_leaves &= leaf[k];
             }
-            if (__all(all_leaves)) break;
+            if (__all(all_done)) break;
         }
 #pragma unroll
         for (int k = 0; k < kTreeWays; ++k)
-            if (t0 + k < forest.ntrees) sum += (double)__uint_as_float(node[k].x);
+            if (t0 + k < forest.ntrees) sum += (double)(PARK ? leafval[k] : __uint_as_float(node[k].x));
     }
     return (float)sum;
+}
+
+// The same walk for a forest whose leaf values are small integers (class labels: every forest the
+// reference trains, src/main_train_detector.cpp:405-407): the double sum of hpp:281 is then exact in
+// any order and equals an int32 sum, so a lane need not keep its trees in step.  Each of its
+// walks takes the lane's next tree as soon as it reaches a leaf; the loop runs for about
+// sum-of-depths / ways steps instead of (trees / ways) x the depth of the deepest tree.
+// The lane walks the trees first, first + tstride, ...; its features are x[var * xstride].
+template <bool STATS, int kQueueWays>
+__device__ __forceinline__ int forest_sum_any_order(const ForestDev &forest, const uint2 *lnodes, int nlds,
+                                                    const float *x, int xstride, int first, int tstride, bool active,
+                                                    int &depth) {
+    const bool all_in_lds = nlds >= forest.nnodes;
+    const uint32_t last_lds = (uint32_t)(nlds - 1);
+    const int ntrees = active ? forest.ntrees : 0;
+    int sum = 0;
+    int next_tree = first + tstride * kQueueWays;      // per lane: its first kQueueWays trees are taken
+    uint32_t nd[kQueueWays];
+    bool live[kQueueWays];
+#pragma unroll
+    for (int k = 0; k < kQueueWays; ++k) {
+        live[k] = first + tstride * k < ntrees;
+        nd[k] = live[k] ? first + tstride * k : 0;     // level-major layout: the root of tree t is node t
+    }
+    for (;;) {
+        uint2 node[kQueueWays];
+        fetch_nodes<kQueueWays>(forest, lnodes, last_lds, all_in_lds, nd, node);
+        float val[kQueueWays];
+        bool leaf[kQueueWays];
+#pragma unroll
+        for (int k = 0; k < kQueueWays; ++k) {
+            const uint32_t var = node[k].y >> 24;
+            leaf[k] = var == 255u;
+            val[k] = x[(leaf[k] ? 0u : var) * xstride];
+        }
+        bool any_live = false;
+#pragma unroll
+        for (int k = 0; k < kQueueWays; ++k) {
+            const uint32_t next = (node[k].y & 0x00ffffffu) + (val[k] <= __uint_as_float(node[k].x) ? 0u : 1u);
+            if (STATS) depth += live[k] ? 1 : 0;
+            const bool done = live[k] & leaf[k];
+            sum += done ? (int)__uint_as_float(node[k].x) : 0;
+            const bool more = next_tree < ntrees;
+            // a finished walk takes the lane's next tree (its root is node next_tree) or parks on node 0
+            nd[k] = done ? (more ? (uint32_t)next_tree : 0u) : (live[k] ? next : 0u);
+            live[k] = done ? more : live[k];
+            next_tree += (done & more) ? tstride : 0;
+            any_live |= live[k];
+        }
+        if (!__any(any_live)) break;
+    }
+    return sum;
 }
 
 // The scoring stage ("runForest", hpp:267-296) in two kernels, one wave = 64 consecutive storage
@@ -1162,7 +1234,14 @@ __global__ __launch_bounds__(1024) void forest_kernel(Batch b, int maxF, int nld
             const float *o = a.feat + (size_t)chunk * a.f.F * kLanes + lane;
             for (int c = 0; c < a.f.F; ++c) H[c * kLanes + lane] = o[c * kLanes];
             int depth = 0;
-            const float fsum = forest_sum<STATS>(a.forest, lnodes, nlds, H + lane, depth);
+            // trees out of step only where it pays (more trees than ways) and is exact (integer leaves)
+            float fsum;
+            if (a.forest.order_free && a.forest.ntrees > kTreeWays)
+                fsum = (float)forest_sum_any_order<STATS, kTreeWays>(a.forest, lnodes, nlds, H + lane, kLanes, 0, 1, true, depth);
+            else if (nlds >= a.forest.nnodes)
+                fsum = forest_sum<STATS, false>(a.forest, lnodes, nlds, H + lane, depth);
+            else
+                fsum = forest_sum<STATS, true>(a.forest, lnodes, nlds, H + lane, depth);
             score = 1 - (fsum / (a.forest.ntrees * 1.0f));                         // hpp:287
             if (STATS) {
                 atomicAdd(&a.stats->sum_depth, (unsigned long long)depth);
@@ -1177,6 +1256,66 @@ __global__ __launch_bounds__(1024) void forest_kernel(Batch b, int maxF, int nld
             if (!a.nd.non_maxima) a.flags[__float_as_int(w.p.w)] = 1;               // hpp:189-196
             // hpp:205-207: a non-finite response is never a candidate (!pcl_isfinite(intensity))
             else if (isfinite(score) && !((double)score < a.nd.thr)) a.cand.list[atomicAdd(a.cand.count, 1)] = w.s;
+        }
+    }
+}
+
+// The forest kernel for a large histogram and many trees whose sum is exact in any order (config 5:
+// F = 80, 100 trees, 16 MB of nodes): 64 / G points per wave, G lanes per point, lane g of a point
+// walks the trees g, g + G, ... and the G partial sums are added at the end.  The F x 64 floats of a
+// whole wave of points (20 KB at F = 80) leave room for 4 waves per CU next to the node cache -- one
+// per SIMD, and every step of the walk waits for a node from beyond the L2; with G = 4 the slice of a
+// wave is 5 KB and 16 waves fit.
+// Few walks per lane there: the kernel is bound by VALU issue (0.85 busy at 10 walks per lane, of which
+// under half were on live trees: a lane has only trees / G trees to keep its walks busy).
+
+template <bool STATS, int kSplitWays>
+__global__ __launch_bounds__(1024) void forest_split_kernel(Batch b, int maxF, int nlds_cap, int G) {
+    extern __shared__ uint2 lnodes[];
+    const ViewDev &a = b.view[blockIdx.y];
+    const int lane = threadIdx.x & (kLanes - 1), wid = threadIdx.x / kLanes, nwaves = blockDim.x / kLanes;
+    const int ppw = kLanes / G, p = lane % ppw, g = lane / ppw;
+    const int nlds = min(nlds_cap, a.forest.nnodes);
+    for (int i = threadIdx.x; i < nlds; i += blockDim.x) lnodes[i] = a.forest.nodes[i];
+    __syncthreads();
+    float *H = reinterpret_cast<float *>(lnodes + nlds_cap) + (size_t)wid * maxF * ppw;
+    const int F = a.f.F;
+    const int nunits = (a.n + ppw - 1) / ppw;
+    const int nfinite = a.cell_start[a.ds->grid.ncells];
+    for (int unit = blockIdx.x * nwaves + wid; unit < nunits; unit += gridDim.x * nwaves) {
+        const int s = unit * ppw + p;                              // storage position of the lane's point
+        if (g == 0 && s < a.n && a.scores && a.cid[s] < 0) a.scores[s] = NAN;   // (s as an ORIGINAL index here)
+        const bool in_range = s < nfinite;
+        const float4 np = in_range ? a.nrm[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool scoreable = in_range && np.w != 0.0f;           // hpp:277
+        // the wave's ppw feature rows: element (c, point) of the F x 64 block the feature kernel wrote
+        wave_lds_fence();
+        for (int idx = lane; idx < F * ppw; idx += kLanes) {
+            const int c = idx / ppw, sp = unit * ppw + idx % ppw;
+            H[idx] = sp < nfinite ? a.feat[((size_t)(sp / kLanes) * F + c) * kLanes + sp % kLanes] : 0.0f;
+        }
+        wave_lds_fence();
+        int depth = 0;
+        int sum = forest_sum_any_order<STATS, kSplitWays>(a.forest, lnodes, nlds, H + p, ppw, g, G, scoreable, depth);
+        for (int off = ppw; off < kLanes; off <<= 1) {
+            sum += __shfl_xor(sum, off);
+            if (STATS) depth += __shfl_xor(depth, off);
+        }
+        if (g != 0 || !in_range) continue;
+        float score = NAN;
+        if (scoreable) {
+            score = 1 - ((float)sum / (a.forest.ntrees * 1.0f));                   // hpp:287
+            if (STATS) {
+                atomicAdd(&a.stats->sum_depth, (unsigned long long)depth);
+                atomicAdd(&a.stats->n_scored, 1ull);
+            }
+        }
+        const int orig = __float_as_int(a.pts[s].w);
+        a.score_sorted[s] = score;
+        if (a.scores) a.scores[orig] = score;
+        if (scoreable) {
+            if (!a.nd.non_maxima) a.flags[orig] = 1;                                // hpp:189-196
+            else if (isfinite(score) && !((double)score < a.nd.thr)) a.cand.list[atomicAdd(a.cand.count, 1)] = s;
         }
     }
 }
@@ -1876,12 +2015,35 @@ void launch_feature_stage(const Batch &b, hipStream_t st) {
 void launch_forest_stage(const Batch &b, hipStream_t st) {
     const int n = max_n(b);
     if (b.nviews <= 0 || n <= 0) return;
-    int maxF = 1, max_nodes = 1;
-    bool stats = false;
+    int maxF = 1, max_nodes = 1, min_trees = 1 << 30;
+    bool stats = false, any_order = true;
     for (int v = 0; v < b.nviews; ++v) {
         maxF = b.view[v].f.F > maxF ? b.view[v].f.F : maxF;
         max_nodes = b.view[v].forest.nnodes > max_nodes ? b.view[v].forest.nnodes : max_nodes;
+        min_trees = b.view[v].forest.ntrees < min_trees ? b.view[v].forest.ntrees : min_trees;
+        any_order &= b.view[v].forest.order_free != 0;
         stats |= b.view[v].stats != nullptr;
+    }
+    // several lanes per point (forest_split_kernel) when every forest of the batch may be summed in any
+    // order, has trees to share out, and a whole wave of histograms would crowd the waves out of LDS
+    // (lanes per point x walks per lane -> forest kernel ms on config 5, 1 M points, 100 trees: 4 x 3 1.57, 4 x 2
+    // 1.63, 4 x 5 1.78, 8 x 3 1.74, 8 x 5 2.07, 2 x 3 2.08, 2 x 5 2.13; one lane per point with 10 walks 2.15)
+    constexpr int G = 4, kSplitWays = 3;
+    if (any_order && min_trees >= 40 && sizeof(float) * (size_t)maxF * kLanes >= 8192) {
+        const size_t slice = sizeof(float) * (size_t)maxF * (kLanes / G);
+        size_t node_bytes = sizeof(uint2) * (size_t)max_nodes;
+        if (node_bytes > kForestNodeBytes) node_bytes = kForestNodeBytes;
+        long long w = ((long long)kForestLds - (long long)node_bytes) / (long long)slice;
+        if (w > 16) w = 16;
+        const int nlds_cap = (int)(node_bytes / sizeof(uint2));
+        const size_t lds = node_bytes + slice * (size_t)w;
+        int wgs = div_up(cu_count(), b.nviews);
+        const int wgs_max = div_up(div_up(n, kLanes / G), (int)w);
+        if (wgs > wgs_max) wgs = wgs_max;
+        const dim3 sgrid(wgs, b.nviews);
+        if (stats) forest_split_kernel<true, kSplitWays><<<sgrid, (int)w * kLanes, lds, st>>>(b, maxF, nlds_cap, G);
+        else forest_split_kernel<false, kSplitWays><<<sgrid, (int)w * kLanes, lds, st>>>(b, maxF, nlds_cap, G);
+        return;
     }
     const ForestLaunch fl = forest_launch(maxF, max_nodes);
     int wgs = div_up(cu_count(), b.nviews);                   // persistent: about one workgroup per CU

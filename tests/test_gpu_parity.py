@@ -353,3 +353,34 @@ def test_randomised_soak():
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "8", "5"], capture_output=True,
                          text=True, timeout=300, cwd=root)
     assert out.returncode == 0 and "all bit-exact" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("ntrees,nodes_per_tree", [(23, 60), (37, 900)])
+def test_fractional_leaf_values_are_summed_in_tree_order(kpl, oracle, cases, ntrees, nodes_per_tree):
+    """A forest whose leaf values are not small integers (a regression forest): the double sum of
+    cv::ml::RTrees::predict(PREDICT_SUM) depends on the order of the trees, so the device walks them
+    in step (kernels.hip forest_sum) instead of letting every lane run ahead (forest_sum_any_order);
+    the second shape is larger than the part of a forest that is staged in LDS."""
+    import copy
+    from tools import synth
+    A, B = 5, 6
+    xyz, nrm = cases.cloud()
+    mr = cases.resolution()
+    r, rn = float(np.float32(6 * mr)), float(np.float32(4 * mr))
+    feat = oracle.Grid(xyz, r).features(nrm, A, B, r, np.arange(0, len(xyz), 5, dtype=np.int32))
+    fa = copy.deepcopy(synth.random_forest(A * B, ntrees=ntrees, max_depth=14, seed=11,
+                                           target_nodes_per_tree=nodes_per_tree, feat=feat))
+    rng = np.random.default_rng(5)
+    value = np.asarray(fa.value, dtype=np.float64).copy()
+    leaves = np.asarray(fa.var) < 0
+    value[leaves] = rng.uniform(-3.0, 3.0, size=int(leaves.sum())).astype(np.float32).astype(np.float64)
+    fa.value = value
+    thr = float(np.float32(0.4))
+    det = make_det(kpl, A, B, r, rn, thr, fa)
+    det.setInputCloud(xyz)
+    det.setNormals(nrm)
+    _, scores = det.compute()
+    o_scores, o_kp = oracle.detect(xyz, nrm, A, B, r, rn, thr, cases.oracle_forest(fa))
+    assert cases.same_bits(scores, o_scores)
+    assert np.array_equal(det.getKeypointsIndices(), o_kp)
+    assert len(np.unique(o_scores[np.isfinite(o_scores)])) > 100
