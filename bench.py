@@ -321,6 +321,90 @@ def main():
         t_single = dets[0].getTiming()
         dets[0].enableTiming(False)
 
+    # ---- the drop-in class's own path: host buffers in PCL's layouts (PointXYZ 16 B, Normal 32 B), pageable,
+    # one kpl_detect_keypoints per compute().  PCIe inclusive; never part of `value`.
+    if not args.lean and rank == 0:
+        xyz0, nrm0, mr0 = views[0]
+        pcl_xyz = np.zeros((n, 4), dtype=np.float32)
+        pcl_nrm = np.zeros((n, 8), dtype=np.float32)
+        pcl_xyz[:, :3], pcl_nrm[:, :3] = xyz0, nrm0
+        dets[0].setInputCloud(pcl_xyz)
+        dets[0].setNormals(pcl_nrm)
+        import ctypes as C
+        host_ms = {}
+        h_kp, h_kps, h_sc = np.empty(n, np.int32), np.empty(n, np.float32), np.empty(n, np.float32)
+        h_cnt = C.c_int()
+        lib, hd = dets[0]._lib, dets[0]._h
+        dets[0]._push()
+        for name in ("keypoints_only", "with_all_scores"):      # the C-ABI calls themselves, as the C++ class makes them
+            ts = []
+            for k in range(14):
+                c0 = time.perf_counter()
+                if name == "keypoints_only":
+                    rc = lib.kpl_detect_keypoints(hd, pcl_xyz.ctypes.data, 16, pcl_nrm.ctypes.data, 32, n, h_kp.ctypes.data,
+                                                  h_kps.ctypes.data, n, C.byref(h_cnt))
+                else:
+                    rc = lib.kpl_detect(hd, pcl_xyz.ctypes.data, 16, pcl_nrm.ctypes.data, 32, n, h_sc.ctypes.data,
+                                        h_kp.ctypes.data, n, C.byref(h_cnt))
+                ts.append((time.perf_counter() - c0) * 1e3)
+                assert rc == 0, dets[0].lastError()
+            host_ms[name] = float(np.median(ts[3:]))
+        same = bool(np.array_equal(h_kp[:h_cnt.value], d_kp[0][:int(d_cnt[0].item())].cpu().numpy()))
+        # the same bytes as plain pageable copies, for scale
+        tx, tn = torch.from_numpy(pcl_xyz), torch.from_numpy(pcl_nrm)
+        dx0, dn0 = torch.empty_like(tx, device=dev), torch.empty_like(tn, device=dev)
+        ts = []
+        for k in range(8):
+            torch.cuda.synchronize()
+            c0 = time.perf_counter()
+            dx0.copy_(tx)
+            dn0.copy_(tn)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - c0) * 1e3)
+        h2d_ms = float(np.median(ts[2:]))
+        extras["host_buffer_path"] = {
+            "what": "KeypointLearningDetector.compute() on host arrays in PCL layouts (16-B points, 32-B normals, pageable), "
+                    "%d points: upload + index + detect + keypoint list back" % n,
+            "compute_ms": round(host_ms["keypoints_only"], 4), "Mpoints_per_s": round(n / host_ms["keypoints_only"] / 1e3, 1),
+            "compute_ms_with_all_scores_back": round(host_ms["with_all_scores"], 4),
+            "upload_bytes": int(pcl_xyz.nbytes + pcl_nrm.nbytes),
+            "same_bytes_as_plain_pageable_copies_ms": round(h2d_ms, 4),
+            "keypoints_identical_to_device_path": same}
+        dets[0].bindCloudDevice(d_in[0][0].data_ptr(), 12, d_in[0][1].data_ptr(), 12, n)   # back to the resident view
+
+        # ---- configs[0]: one small view alone on the GPU (the parity anchor of config 1, tests/golden/cheff000.npz)
+        gold = os.path.join(ROOT, "tests", "golden", "cheff000.npz")
+        if os.path.exists(gold):
+            z = np.load(gold)
+            cx, cn = np.ascontiguousarray(z["xyz"], dtype=np.float32), np.ascontiguousarray(z["nrm"], dtype=np.float32)
+            dsm = kpl.KeypointLearningDetector(device=local_rank)
+            cmr = dsm.cloudResolution(cx)
+            dsm.setNAnnulus(A); dsm.setNBins(B); dsm.setNonMaxima(True); dsm.setNonMaximaDrawsRemove(False)
+            dsm.setNonMaxRadius(float(np.float32(4.0 * cmr))); dsm.setPredictionThreshold(thr)
+            dsm.setRadiusSearch(float(np.float32(6.0 * cmr)))
+            dsm.loadForest(FOREST)
+            m = len(cx)
+            tcx, tcn = torch.from_numpy(cx).to(dev), torch.from_numpy(cn).to(dev)
+            sc1 = torch.empty(m, dtype=torch.float32, device=dev)
+            kp1 = torch.zeros(m + 1, dtype=torch.int32, device=dev)
+            dsm.bindCloudDevice(tcx.data_ptr(), 12, tcn.data_ptr(), 12, m)
+            dsm.computeDevice(sc1.data_ptr(), kp1[1:].data_ptr(), m, kp1[0:1].data_ptr(), stream)
+            while dsm.syncStatus(stream) == kpl.ERR_RETRY:
+                dsm.computeDevice(sc1.data_ptr(), kp1[1:].data_ptr(), m, kp1[0:1].data_ptr(), stream)
+            dsm.enableTiming(True)
+            reps1 = 200
+            torch.cuda.synchronize()
+            c0 = time.perf_counter()
+            for _ in range(reps1):
+                dsm.computeDevice(sc1.data_ptr(), kp1[1:].data_ptr(), m, kp1[0:1].data_ptr(), stream)
+            torch.cuda.synchronize()
+            ms1 = (time.perf_counter() - c0) * 1e3 / reps1
+            t1v = dsm.getTiming()
+            extras["single_view_cfg1"] = {"view": "tests/golden/cheff000.npz", "points": m, "compute_ms": round(ms1, 5),
+                                          "Mpoints_per_s": round(m / ms1 / 1e3, 2), "keypoints": int(kp1[0].item()),
+                                          "phases_ms": {k: round(t1v[k] / max(t1v["calls"], 1), 5)
+                                                        for k in ("index_ms", "feature_ms", "forest_ms", "nms_ms")}}
+
     # ---- algorithmic bytes from the engine's own counters -------------------------
     # B_alg(i) = 24 (1 + K_f) + 16 K_n [s >= thr] + 8 sum depth + 8.  The scoring stage is two kernels:
     # the feature kernel (the dominant one) gathers xyz + normal of the point and of each feature

@@ -152,7 +152,11 @@ public:
         return features;
     }
 
-    // forest responses of the last compute(), one per input point (NaN where not scoreable)
+    // forest responses of the last compute(), one per input point (NaN where not scoreable) -- only
+    // when asked for with setKeepScores(true) BEFORE compute(): by default the responses of the
+    // keypoints alone come back from the device (no reference counterpart: the reference keeps the
+    // responses in a temporary cloud, hpp:182-187)
+    void setKeepScores(bool keep) { keep_scores_ = keep; }
     const std::vector<float> &getScores() const { return scores_; }
     const char *lastError() const { return handle_ ? kpl_last_error(handle_) : kpl_status_string(create_status_); }
 
@@ -209,27 +213,41 @@ protected:
 
     virtual void detectKeypoints(PointCloudOut &output) {                   // hpp:179-263
         const int n = (int)this->input_->points.size();
-        scores_.assign((size_t)n, 0.0f);
-        std::vector<int> kp((size_t)(n > 0 ? n : 1));
+        // indices and responses of the keypoints only come back from the device; the buffers are members
+        // (grow-only), like the device scratch of the handle
+        if (kp_idx_.size() < (size_t)(n > 0 ? n : 1)) {
+            kp_idx_.resize((size_t)(n > 0 ? n : 1));
+            kp_score_.resize(kp_idx_.size());
+        }
         int count = 0;
-        int rc = kpl_detect(handle_, n ? &this->input_->points[0].x : nullptr, sizeof(PointInT),
-                            n ? &normals_->points[0].normal_x : nullptr, sizeof(NormalT), n,
-                            scores_.data(), kp.data(), n, &count);
+        int rc;
+        if (keep_scores_) {
+            scores_.assign((size_t)n, 0.0f);
+            rc = kpl_detect(handle_, n ? &this->input_->points[0].x : nullptr, sizeof(PointInT),
+                            n ? &normals_->points[0].normal_x : nullptr, sizeof(NormalT), n, scores_.data(),
+                            kp_idx_.data(), n, &count);
+            for (int k = 0; rc == KPL_OK && k < count; ++k) kp_score_[(size_t)k] = scores_[(size_t)kp_idx_[(size_t)k]];
+        } else {
+            scores_.clear();
+            rc = kpl_detect_keypoints(handle_, n ? &this->input_->points[0].x : nullptr, sizeof(PointInT),
+                                      n ? &normals_->points[0].normal_x : nullptr, sizeof(NormalT), n,
+                                      kp_idx_.data(), kp_score_.data(), n, &count);
+        }
         if (rc != KPL_OK) {
             report("detectKeypoints", rc);
             return;
         }
         output.points.clear();
-        output.points.reserve((size_t)count);
+        output.points.resize((size_t)count);
+        this->keypoints_indices_->indices.reserve(this->keypoints_indices_->indices.size() + (size_t)count);
         for (int k = 0; k < count; ++k) {
-            const PointInT &in = this->input_->points[kp[k]];
-            PointOutT out;
+            const PointInT &in = this->input_->points[kp_idx_[k]];
+            PointOutT &out = output.points[(size_t)k];
             out.x = in.x;
             out.y = in.y;
             out.z = in.z;
-            out.intensity = scores_[kp[k]];                                  // hpp:284-287
-            output.points.push_back(out);
-            this->keypoints_indices_->indices.push_back(kp[k]);
+            out.intensity = kp_score_[k];                                    // hpp:284-287
+            this->keypoints_indices_->indices.push_back(kp_idx_[k]);
         }
         output.height = 1;                                                   // hpp:258-260
         output.width = static_cast<uint32_t>(output.points.size());
@@ -308,6 +326,9 @@ protected:
     int n_bins_;
     PointCloudNConstPtr normals_;
     std::vector<float> scores_;
+    std::vector<int> kp_idx_;            // grow-only landing buffers of detectKeypoints
+    std::vector<float> kp_score_;
+    bool keep_scores_ = false;
     kpl_detector *handle_ = nullptr;
     int create_status_ = KPL_OK;
 };

@@ -126,6 +126,13 @@ int kpl_detect(kpl_detector *h, const void *xyz, size_t xyz_stride,
                const void *normals, size_t normals_stride, int n,
                float *scores_out, int *kp_idx_out, int kp_cap, int *kp_count);
 
+/* The same call for a caller that wants what detectKeypoints() leaves behind -- the keypoint indices
+ * and the forest response OF THE KEYPOINTS (the intensity of the output cloud, hpp:258-260) -- and not
+ * the response of every point: nothing of size n travels back over PCIe.  kp_scores_out may be NULL. */
+int kpl_detect_keypoints(kpl_detector *h, const void *xyz, size_t xyz_stride,
+                         const void *normals, size_t normals_stride, int n,
+                         int *kp_idx_out, float *kp_scores_out, int kp_cap, int *kp_count);
+
 /* computePointsForTrainingFeatures (hpp:299-318): features of the listed points, m x
  * (n_annulus*n_bins) floats, row major.  A row of a point with non-finite xyz is NaN. */
 int kpl_compute_features(kpl_detector *h, const void *xyz, size_t xyz_stride,

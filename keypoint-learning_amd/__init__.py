@@ -70,6 +70,7 @@ SYMBOLS = {
     "kpl_forest_export_arrays": (C.c_int, [_vp, C.c_size_t, C.c_int64, C.c_int, _vp, _vp, _vp, _vp, _vp,
                                            _vp, C.c_char_p, C.c_size_t]),
     "kpl_detect": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_int, _vp, _vp, C.c_int, _ip]),
+    "kpl_detect_keypoints": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_int, _vp, _vp, C.c_int, _ip]),
     "kpl_compute_features": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_int, _vp,
                                        C.c_int, _vp]),
     "kpl_bind_cloud_device": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_int]),
@@ -282,7 +283,8 @@ class KeypointLearningDetector:
         return a, a.shape[1] * 4
 
     def compute(self, with_scores=True):
-        """pcl::Keypoint::compute.  Returns (keypoints [k,4] = x,y,z,score, scores [n] or None);
+        """pcl::Keypoint::compute.  Returns (keypoints [k,4] = x,y,z,score, scores [n] or None: with_scores=False
+        is the drop-in class's own path, kpl_detect_keypoints, which brings back the keypoints only);
         the indices are left in `keypoints_indices` like getKeypointsIndices()."""
         if self._cloud is None:
             raise KplError(ERR_NO_CLOUD, "no input cloud")
@@ -296,20 +298,25 @@ class KeypointLearningDetector:
             raise KplError(ERR_INVALID_ARG, "the number of normals does not match the number of "
                            "input points")   # impl/KeypointLearning.hpp:149-153
         self._push()
-        scores = np.empty(max(n, 1), dtype=np.float32) if with_scores else None
         kp = np.empty(max(n, 1), dtype=np.int32)
         cnt = C.c_int()
-        rc = self._lib.kpl_detect(self._h, xyz.ctypes.data, xs, nrm.ctypes.data, ns, n,
-                                  scores.ctypes.data if with_scores else None,
-                                  kp.ctypes.data, n, C.byref(cnt))
-        self._check(rc)
-        self.keypoints_indices = kp[:cnt.value].copy()
         if with_scores:
+            scores = np.empty(max(n, 1), dtype=np.float32)
+            rc = self._lib.kpl_detect(self._h, xyz.ctypes.data, xs, nrm.ctypes.data, ns, n, scores.ctypes.data,
+                                      kp.ctypes.data, n, C.byref(cnt))
+            self._check(rc)
+            self.keypoints_indices = kp[:cnt.value].copy()
             scores = scores[:n]
             out = np.concatenate([xyz[self.keypoints_indices, :3],
                                   scores[self.keypoints_indices, None]], axis=1)
             return out, scores
-        return xyz[self.keypoints_indices, :3], None
+        # what detectKeypoints() leaves behind and nothing else: indices + the response of the keypoints
+        kps = np.empty(max(n, 1), dtype=np.float32)
+        rc = self._lib.kpl_detect_keypoints(self._h, xyz.ctypes.data, xs, nrm.ctypes.data, ns, n, kp.ctypes.data,
+                                            kps.ctypes.data, n, C.byref(cnt))
+        self._check(rc)
+        self.keypoints_indices = kp[:cnt.value].copy()
+        return np.concatenate([xyz[self.keypoints_indices, :3], kps[:cnt.value, None]], axis=1), None
 
     def cloudResolution(self, cloud):
         """kpl::computeCloudResolution of the reference: mean distance to the second nearest neighbor."""

@@ -75,6 +75,10 @@ struct kpl_detector {
     int cells_cap = 0;            // capacity (cells) of cell_start
     DevState *h_state = nullptr;  // pinned copy of the device state (status read-back)
     int *h_count = nullptr;       // pinned
+    hipStream_t stream = nullptr; // the host-buffer entry points enqueue here
+    DevBuf out_kp_score;
+    void *h_res = nullptr;        // pinned landing zone of the keypoint lists (host-buffer entry points)
+    size_t h_res_cap = 0;
 
     // optional per-phase event timing (kpl_enable_timing)
     bool timing = false;
@@ -367,6 +371,7 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
     v.draw_count = h->draw_count.as<int>();
     v.skip = h->skip.as<int>();
     v.kp_idx = d_kp_idx;
+    v.kp_score = nullptr;
     v.kp_cap = kp_cap;
     v.kp_count = d_kp_count;
     v.stats = d_stats;
@@ -376,7 +381,8 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
 // compute() / detectKeypoints of `count` views: one stream, three stages, every kernel launched
 // once for the whole batch.  rebuild = always rebuild the index (compute), else only if stale.
 int run_batch(kpl_detector *const *handles, int count, float *const *d_scores, int *const *d_kp_idx,
-              const int *kp_caps, int *const *d_kp_counts, StatsDev *d_stats, bool rebuild, hipStream_t st) {
+              const int *kp_caps, int *const *d_kp_counts, StatsDev *d_stats, bool rebuild, hipStream_t st,
+              float *const *d_kp_scores = nullptr) {
     kpl_detector *h0 = handles[0];
     Batch all{}, idx{}, fix{};
     bool rebuilt[kMaxBatch] = {};
@@ -390,6 +396,7 @@ int run_batch(kpl_detector *const *handles, int count, float *const *d_scores, i
             if (h != h0) fail(h0, rc, "view %d: %s", k, kpl_last_error(h));
             return rc;
         }
+        if (d_kp_scores && d_kp_scores[k] && all.view[k].scores) all.view[k].kp_score = d_kp_scores[k];
         // pos_of[] is read by the draws pass only; a view whose index is kept needs it completed if missing
         const bool rebuild_k = rebuild || !index_is_current(h);
         all.view[k].want_pos_of = all.view[k].nd.draws_remove ? 1 : 0;
@@ -462,9 +469,12 @@ int upload_view(kpl_detector *h, const void *xyz, size_t xs, const void *nrm, si
     KPL_HIP(h, h->stage_xyz.ensure(nn * xs));
     KPL_HIP(h, h->stage_nrm.ensure(nn * ns));
     if (n > 0) {
-        // the last element may be shorter than the stride in the caller's array
-        KPL_HIP(h, hipMemcpy(h->stage_xyz.p, xyz, (size_t)(n - 1) * xs + 12, hipMemcpyHostToDevice));
-        KPL_HIP(h, hipMemcpy(h->stage_nrm.p, nrm, (size_t)(n - 1) * ns + 12, hipMemcpyHostToDevice));
+        // the last element may be shorter than the stride in the caller's array.  Enqueued on the
+        // handle's stream (pageable memory: the runtime stages it, the call returns once it has);
+        // everything the host-buffer entry points launch afterwards goes to the same stream
+        KPL_HIP(h, hipMemcpyAsync(h->stage_xyz.p, xyz, (size_t)(n - 1) * xs + 12, hipMemcpyHostToDevice, h->stream));
+        if (nrm != xyz)
+            KPL_HIP(h, hipMemcpyAsync(h->stage_nrm.p, nrm, (size_t)(n - 1) * ns + 12, hipMemcpyHostToDevice, h->stream));
     }
     h->d_xyz = h->stage_xyz.as<char>();
     h->d_nrm = h->stage_nrm.as<char>();
@@ -473,6 +483,60 @@ int upload_view(kpl_detector *h, const void *xyz, size_t xs, const void *nrm, si
     h->n = n;
     h->bound = true;
     h->index_valid = false;
+    return KPL_OK;
+}
+
+// compute() on a staged view: index build + detect on the handle's stream, then the keypoint list (and,
+// if asked for, its scores and / or the scores of all points) into the caller's buffers.  Two waits:
+// one for the count, one for the lists of exactly that length.
+int detect_staged(kpl_detector *h, int n, float *scores_out, int *kp_idx_out, float *kp_scores_out, int kp_cap,
+                  int *kp_count) {
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    const bool want_scores = scores_out != nullptr || kp_scores_out != nullptr;
+    if (want_scores) KPL_HIP(h, h->out_scores.ensure(sizeof(float) * nn));
+    KPL_HIP(h, h->out_kp.ensure(sizeof(int) * nn));
+    if (kp_scores_out) KPL_HIP(h, h->out_kp_score.ensure(sizeof(float) * nn));
+    KPL_HIP(h, h->out_count.ensure(sizeof(int)));
+    hipStream_t st = h->stream;
+    float *d_scores = want_scores ? h->out_scores.as<float>() : nullptr;
+    int *d_kp = h->out_kp.as<int>(), *d_count = h->out_count.as<int>();
+    float *d_kps = kp_scores_out ? h->out_kp_score.as<float>() : nullptr;
+    int rc = KPL_OK;
+    for (int attempt = 0;; ++attempt) {
+        rc = run_batch(&h, 1, &d_scores, &d_kp, &n, &d_count, nullptr, true, st, &d_kps);
+        if (rc) return rc;
+        KPL_HIP(h, hipMemcpyAsync(h->h_count, h->out_count.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        rc = sync_status(h, st);
+        if (rc == KPL_ERR_RETRY && attempt == 0) continue;   // cell tables were grown: run again
+        if (rc) return rc;
+        break;
+    }
+    const int count = h->h_count[0];
+    *kp_count = count;
+    const int ncopy = count < kp_cap ? count : kp_cap;
+    // the lists land in one pinned buffer (true DMA, no staging by the runtime), then one memcpy each
+    const size_t need = (size_t)ncopy * (sizeof(int) + (kp_scores_out ? sizeof(float) : 0));
+    if (need > h->h_res_cap) {
+        if (h->h_res) (void)hipHostFree(h->h_res);
+        h->h_res = nullptr;
+        h->h_res_cap = 0;
+        KPL_HIP(h, hipHostMalloc(&h->h_res, need + need / 2 + 4096, hipHostMallocDefault));
+        h->h_res_cap = need + need / 2 + 4096;
+    }
+    if (ncopy > 0) {
+        KPL_HIP(h, hipMemcpyAsync(h->h_res, h->out_kp.p, sizeof(int) * (size_t)ncopy, hipMemcpyDeviceToHost, st));
+        if (kp_scores_out)
+            KPL_HIP(h, hipMemcpyAsync((char *)h->h_res + sizeof(int) * (size_t)ncopy, h->out_kp_score.p,
+                                      sizeof(float) * (size_t)ncopy, hipMemcpyDeviceToHost, st));
+    }
+    if (scores_out && n > 0)
+        KPL_HIP(h, hipMemcpyAsync(scores_out, h->out_scores.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, st));
+    KPL_HIP(h, hipStreamSynchronize(st));
+    if (ncopy > 0) {
+        memcpy(kp_idx_out, h->h_res, sizeof(int) * (size_t)ncopy);
+        if (kp_scores_out) memcpy(kp_scores_out, (char *)h->h_res + sizeof(int) * (size_t)ncopy, sizeof(float) * (size_t)ncopy);
+    }
+    if (count > kp_cap) return fail(h, KPL_ERR_CAPACITY, "%d keypoints but capacity %d", count, kp_cap);
     return KPL_OK;
 }
 
@@ -536,7 +600,8 @@ int kpl_create(kpl_detector **out, int device) {
     if (hipSetDevice(device) != hipSuccess ||
         hipHostMalloc((void **)&h->h_state, sizeof(DevState), hipHostMallocDefault) != hipSuccess ||
         h->dstate.ensure(sizeof(DevState)) != hipSuccess ||
-        hipHostMalloc((void **)&h->h_count, 16 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+        hipHostMalloc((void **)&h->h_count, 16 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         kpl_destroy(h);
         return KPL_ERR_DEVICE;
     }
@@ -561,6 +626,9 @@ void kpl_destroy(kpl_detector *h) {
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->h_state) (void)hipHostFree(h->h_state);
     if (h->h_count) (void)hipHostFree(h->h_count);
+    if (h->h_res) (void)hipHostFree(h->h_res);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    h->out_kp_score.release();
     delete h;
 }
 
@@ -765,30 +833,20 @@ int kpl_detect(kpl_detector *h, const void *xyz, size_t xyz_stride, const void *
     if (rc) return rc;
     rc = upload_view(h, xyz, xyz_stride, normals, normals_stride, n);
     if (rc) return rc;
-    const size_t nn = (size_t)(n > 0 ? n : 1);
-    KPL_HIP(h, h->out_scores.ensure(sizeof(float) * nn));
-    KPL_HIP(h, h->out_kp.ensure(sizeof(int) * nn));
-    KPL_HIP(h, h->out_count.ensure(sizeof(int)));
-    hipStream_t st = nullptr;
-    for (int attempt = 0;; ++attempt) {
-        rc = build_index(h, st);
-        if (rc) return rc;
-        rc = detect_on_device(h, scores_out ? h->out_scores.as<float>() : nullptr, h->out_kp.as<int>(), n,
-                              h->out_count.as<int>(), st, nullptr);
-        if (rc) return rc;
-        KPL_HIP(h, hipMemcpyAsync(h->h_count, h->out_count.p, sizeof(int), hipMemcpyDeviceToHost, st));
-        rc = sync_status(h, st);
-        if (rc == KPL_ERR_RETRY && attempt == 0) continue;   // cell tables were grown: run again
-        if (rc) return rc;
-        break;
-    }
-    const int count = h->h_count[0];
-    *kp_count = count;
-    const int ncopy = count < kp_cap ? count : kp_cap;
-    if (ncopy > 0) KPL_HIP(h, hipMemcpy(kp_idx_out, h->out_kp.p, sizeof(int) * (size_t)ncopy, hipMemcpyDeviceToHost));
-    if (scores_out && n > 0) KPL_HIP(h, hipMemcpy(scores_out, h->out_scores.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
-    if (count > kp_cap) return fail(h, KPL_ERR_CAPACITY, "%d keypoints but capacity %d", count, kp_cap);
-    return KPL_OK;
+    return detect_staged(h, n, scores_out, kp_idx_out, nullptr, kp_cap, kp_count);
+}
+
+int kpl_detect_keypoints(kpl_detector *h, const void *xyz, size_t xyz_stride, const void *normals,
+                         size_t normals_stride, int n, int *kp_idx_out, float *kp_scores_out, int kp_cap,
+                         int *kp_count) {
+    if (!h) return KPL_ERR_INVALID_ARG;
+    if (!kp_count || kp_cap < 0 || (kp_cap > 0 && !kp_idx_out)) return fail(h, KPL_ERR_INVALID_ARG, "bad keypoint output buffers");
+    *kp_count = 0;
+    int rc = check_params_for_compute(h, true);
+    if (rc) return rc;
+    rc = upload_view(h, xyz, xyz_stride, normals, normals_stride, n);
+    if (rc) return rc;
+    return detect_staged(h, n, nullptr, kp_idx_out, kp_scores_out, kp_cap, kp_count);
 }
 
 int kpl_sync_status(kpl_detector *h, void *stream) {
@@ -810,11 +868,11 @@ int kpl_compute_features(kpl_detector *h, const void *xyz, size_t xyz_stride, co
     const size_t F = (size_t)h->prm.n_annulus * h->prm.n_bins;
     KPL_HIP(h, h->stage_idx.ensure(sizeof(int) * (size_t)m));
     KPL_HIP(h, h->stage_feat.ensure(sizeof(float) * (size_t)m * F));
-    KPL_HIP(h, hipMemcpy(h->stage_idx.p, indices, sizeof(int) * (size_t)m, hipMemcpyHostToDevice));
+    KPL_HIP(h, hipMemcpyAsync(h->stage_idx.p, indices, sizeof(int) * (size_t)m, hipMemcpyHostToDevice, h->stream));
     for (int attempt = 0;; ++attempt) {
-        rc = kpl_compute_features_device(h, h->stage_idx.as<int>(), m, h->stage_feat.as<float>(), nullptr);
+        rc = kpl_compute_features_device(h, h->stage_idx.as<int>(), m, h->stage_feat.as<float>(), h->stream);
         if (rc) return rc;
-        rc = sync_status(h, nullptr);
+        rc = sync_status(h, h->stream);
         if (rc == KPL_ERR_RETRY && attempt == 0) continue;
         if (rc) return rc;
         break;
@@ -903,7 +961,7 @@ int kpl_estimate_normals(kpl_detector *h, const void *xyz, size_t xyz_stride, in
     h->d_nrm = h->d_xyz;
     const size_t nn = (size_t)(n > 0 ? n : 1);
     KPL_HIP(h, h->stage_feat.ensure(sizeof(float) * 4 * nn));       // (nx, ny, nz, curvature) per point
-    hipStream_t st = nullptr;
+    hipStream_t st = h->stream;          // where upload_view put the copies
     for (int attempt = 0;; ++attempt) {
         rc = normals_on_device(h, k_search, radius_search, viewpoint, h->stage_feat.p, 16,
                                (char *)h->stage_feat.p + 12, 16, st);
@@ -935,7 +993,7 @@ int kpl_cloud_resolution(kpl_detector *h, const void *xyz, size_t xyz_stride, in
     KPL_HIP(h, h->stage_feat.ensure(sizeof(float) * nn));
     KPL_HIP(h, h->out_scores.ensure(3 * sizeof(double)));
     KPL_HIP(h, h->out_kp.ensure(resolution_scratch_bytes()));
-    hipStream_t st = nullptr;
+    hipStream_t st = h->stream;          // where upload_view put the copies
     for (int attempt = 0;; ++attempt) {
         rc = build_index(h, st, true);
         if (rc) return rc;

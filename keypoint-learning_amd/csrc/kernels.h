@@ -100,6 +100,7 @@ struct ViewDev {
     // draws pass + compaction ("detectKeypoints")
     int *draw_list, *draw_count, *skip;
     int *kp_idx;
+    float *kp_score;             // [kp_cap] forest response of each keypoint (may be null; needs `scores`)
     int kp_cap;
     int *kp_count;
     StatsDev *stats;             // null unless counters are collected

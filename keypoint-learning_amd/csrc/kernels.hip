@@ -1846,6 +1846,7 @@ __global__ __launch_bounds__(256) void compact_kernel(Batch b) {
     const int *prefix = v.prefix;
     const int n = v.n, kp_cap = v.kp_cap;
     int *kp_idx = v.kp_idx, *kp_count = v.kp_count, *cand_count = v.cand.count;
+    float *kp_score = v.kp_score;
     int *skip = v.nd.draws_remove ? v.skip : nullptr;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {
@@ -1856,7 +1857,10 @@ __global__ __launch_bounds__(256) void compact_kernel(Batch b) {
     if (skip) skip[i] = 0;
     if (flags[i]) {
         int pos = prefix[i];
-        if (pos < kp_cap) kp_idx[pos] = i;
+        if (pos < kp_cap) {
+            kp_idx[pos] = i;
+            if (kp_score) kp_score[pos] = v.scores[i];       // (scores is set whenever kp_score is)
+        }
         flags[i] = 0;
     }
 }

@@ -150,6 +150,7 @@ struct ProbeDetector : pcl::keypoints::KeypointLearningDetector<PointInT, Keypoi
     // returns the number of mismatches between runForest / computePointFeatures and compute()
     int check(const pcl::PointCloud<PointInT> &cloud) {
         pcl::PointCloud<KeypointT> kp, all;
+        this->setKeepScores(true);
         this->compute(kp);
         const std::vector<float> scores = this->getScores();
         if (!this->initCompute()) return -1;

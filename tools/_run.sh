@@ -1,6 +1,6 @@
-for sp in 43 42 25 23 85 83; do echo SPLIT=$sp; KPL_SPLIT=$sp python tools/run_configs.py cfg5 2>/dev/null | python -c "
-import sys,json
-for l in sys.stdin:
-    if l.startswith('{'):
-        j=json.loads(l); print(j['gpu_Mpts'], j['gpu_ms'], j['phases_ms']['forest_ms'], j['parity'])
-"; done
+true
+python bench.py --steps 100 --warmup 10 > gpurun_out/r2_bench_b.json 2> gpurun_out/r2_bench_b.err; tail -3 gpurun_out/r2_bench_b.err; python - <<'PY'
+import json
+j=json.load(open('gpurun_out/r2_bench_b.json'))
+print(j['value'], j['ms_per_step'], j['phases_ms']); print(j['single_view']); print(j.get('host_buffer_path')); print(j.get('single_view_cfg1')); print(j['roofline']['valu_busy'], j['roofline']['traffic'], j['roofline']['hbm_counter_frac'], j['roofline']['counters'])
+PY
