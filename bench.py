@@ -147,7 +147,7 @@ def main():
     # ---- synthetic views, resident in HBM before the timed region ----------------------------------
     # keypoint output per view = one packed buffer [count, idx_0, idx_1, ...]; the buffers of a rank's
     # batch are rows of ONE tensor, which with N > 1 is the RCCL all-gather payload as it stands
-    gather_cap = 32768                     # keypoints per view that travel (a view has ~22 k)
+    gather_cap = min(32768, args.nx * args.ny)   # keypoints per view that travel (a 200 k view has ~22 k)
     views, dets, d_in, d_scores, d_cnt, d_kp = [], [], [], [], [], []
     nv = nb * ng                           # views resident on this GPU
     for k in range(nv):

@@ -1,5 +1,6 @@
 """GPU path against the committed golden fixtures (no oracle in the loop for the expected values)
 and, at BASELINE.json's full sizes, against the oracle + size-independent properties."""
+import json
 import os
 
 import numpy as np
@@ -301,3 +302,46 @@ def test_batch_call_can_be_captured_in_a_hip_graph(kpl, oracle, cases):
             o_sc, o_kp = oracle.detect(xyz, nrm, 5, 6, r, rn, thr, of)
             assert cases.same_bits(ds.cpu().numpy(), o_sc)
             assert np.array_equal(dk[1:1 + int(dk[0].item())].cpu().numpy(), o_kp)
+
+
+def _child(cmd, timeout=600):
+    import subprocess
+    import sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable] + cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert lines, out.stdout[-2000:] + out.stderr[-2000:]
+    return json.loads(lines[-1])
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_bench_two_ranks_on_one_device_in_fresh_processes():
+    """The N > 1 path of bench.py exactly as the driver launches it (torch.distributed.run, one process per
+    rank), 2 ranks sharing the one GPU of this box, gloo instead of RCCL: views sharded, every step ends
+    with the gather of the packed keypoint lists, each rank finds its own lists in the gathered tensor
+    (asserted inside bench.py), parity gate on, one JSON line from rank 0."""
+    j = _child(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "3",
+                "--warmup", "1", "--repeats", "2", "--batch", "2", "--nx", "80", "--ny", "60", "--lean",
+                "--no-cpu-baseline"])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == "weak"
+    assert j["parity"]["scores_bit_exact"] and j["parity"]["keypoints_identical"]
+    assert j["value"] > 0 and j["config"]["views_per_step_per_gpu"] == 2
+
+
+def test_config3_recipe_two_ranks_gloo():
+    """tools/run_cfg3.py (the one-command recipe of BASELINE.json configs[2]) at reduced size: 8 views over 2
+    ranks on this one GPU, gloo; rank 0 checks its views against the oracle and its own lists in the gather."""
+    j = _child(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(_free_port()), "tools/run_cfg3.py", "--backend", "gloo", "--views", "8", "--nx", "80",
+                "--ny", "60", "--rounds", "2"])
+    assert j["n_gpus"] == 2 and j["views_per_rank"] == 4 and j["parity_first_4_views_rank0"] is True
