@@ -170,6 +170,41 @@ def test_cli_estimates_normals_and_resolution(tmp_path):
     assert np.array_equal(kp[:, :3], xyz[o_kp]) and np.array_equal(kp[:, 3], o_sc[o_kp])
 
 
+def test_cli_subsampling_equals_the_tools_uniform_sampling(tmp_path):
+    """--subSampling --leaf: the C++ UniformSampling of TestDetector (one point per leaf-sized voxel, the one
+    closest to the voxel centre) keeps exactly the points tools/train_detector.uniform_sampling keeps; the rest
+    of the run (normals on the subsampled cloud, radii from the resolution of the FULL cloud like
+    /root/reference/src/main_test_detector.cpp:143-157) equals the oracle pipeline on those points."""
+    from oracle import kplo
+    from tests import helpers
+    from tools import forest_yaml
+    from tools.train_detector import uniform_sampling
+    z = np.load(os.path.join(GOLD, "small_case.npz"))
+    xyz = np.ascontiguousarray(z["xyz"][np.isfinite(z["xyz"]).all(axis=1)])
+    pcd, out = tmp_path / "small.pcd", tmp_path / "kp.pcd"
+    write_pcd(pcd, xyz, None, True)
+    forest = os.path.join(GOLD, "small_forest.yaml.gz")
+    cmd = [EXE, "--pathCloud", str(pcd), "--pathRF", forest, "--radiusFeatures", "6", "--pathKP=%s" % out,
+           "--radiusNMS", "4", "--radiusInMr", "--subSampling", "--leaf", "1.5", "--annuli", "5", "--bins", "6",
+           "-t", "0.5", "--flipNormals", "--json"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    info = json.loads(res.stdout.strip().splitlines()[-1])
+    mr = kplo.cloud_resolution(xyz)                               # of the full cloud
+    leaf = float(np.float32(1.5 * mr))
+    keep = uniform_sampling(xyz, leaf)
+    sub = np.ascontiguousarray(xyz[keep])
+    assert 0 < len(sub) < len(xyz) and info["points"] == len(sub)
+    nrm, _ = kplo.estimate_normals(sub, k=10, viewpoint=(0, 0, 0))
+    nrm = -nrm                                                    # --flipNormals
+    r, rn = float(np.float32(6 * mr)), float(np.float32(4 * mr))
+    fa = forest_yaml.load_forest(forest)
+    o_sc, o_kp = kplo.detect(sub, nrm, 5, 6, r, rn, float(np.float32(0.5)), helpers.oracle_forest(fa))
+    kp = np.loadtxt(out, skiprows=11, dtype=np.float32).reshape(-1, 4)
+    assert info["keypoints"] == len(o_kp) > 0
+    assert np.array_equal(kp[:, :3], sub[o_kp]) and np.array_equal(kp[:, 3], o_sc[o_kp])
+
+
 def test_protected_members_of_the_class(tmp_path):
     """runForest / computePointFeatures (protected in the reference, include/KeypointLearning.h:164-177) through a
     subclass: same scores and feature rows as the public path."""
