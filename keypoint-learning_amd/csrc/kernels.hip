@@ -1346,12 +1346,16 @@ __global__ __launch_bounds__(kLanes) void features_kernel(const float4 *__restri
 }
 
 // detectKeypoints, hpp:197-256 with draws_remove == false (order-independent predicate):
-// keypoint <=> score >= thr (float promoted to double, hpp:207 -- tested by the score kernel,
+// keypoint <=> score >= thr (float promoted to double, hpp:207 -- tested by the forest kernel,
 // which appends the candidates to `cand`) and no neighbor within r_nms has a strictly greater
-// score (hpp:219).  16 lanes share one candidate and sweep its rows of cells 16 storage
-// positions at a time (coalesced 16-B loads of xyz, 4-B loads of the score), stopping at the
-// first greater neighbor; groups stride over the candidate list.
+// score (hpp:219).  16 lanes share one candidate.  The kernel is a chain of dependent loads, so
+// the chain is kept short: the 16 lanes fetch the ranges of the (<= 16) rows of cells of the search
+// box at once, the rows are then treated as ONE list of positions (prefix sums over the 16 lanes,
+// binary search per position), and the scores of four steps of 16 positions are requested together.
+// A position only matters if its score is greater (or, for the draws pass, equal): only then is its
+// point loaded and its distance tested -- rare, most candidates sit on score plateaus and survive.
 constexpr int kNmsGroup = 16;
+constexpr int kNmsAhead = 4;     // steps of 16 positions whose score loads are in flight together (8 measured the same)
 
 template <bool STATS>
 __global__ __launch_bounds__(256) void nms_kernel(Batch b) {
@@ -1368,48 +1372,88 @@ __global__ __launch_bounds__(256) void nms_kernel(Batch b) {
     const GridDesc g = v.ds->grid;
     const int ncand = *cand.count;
     const int lane = threadIdx.x & (kNmsGroup - 1);
-    const int group_in_wave = (threadIdx.x & 63) / kNmsGroup;
+    const int wlane = threadIdx.x & (kWave - 1), gbase = wlane & ~(kNmsGroup - 1);
     const int groups = gridDim.x * (blockDim.x / kNmsGroup);
-    for (int k = (blockIdx.x * blockDim.x + threadIdx.x) / kNmsGroup; k < ncand; k += groups) {
-        const int s = cand.list[k];
+    const int t_last = max(cell_start[g.ncells] - 1, 0);
+    for (int k0 = (blockIdx.x * blockDim.x + threadIdx.x) / kNmsGroup;; k0 += groups) {
+        const bool have = k0 < ncand;
+        if (!__any(have)) break;                      // (groups of a wave finish together: whole waves leave)
+        const int s = have ? cand.list[k0] : 0;
         const float si = score_sorted[s];
         const float4 p = pts[s];
-        const CellBox b = make_box(g, p.x, p.y, p.z, nd.rr);
+        const CellBox bx = make_box(g, p.x, p.y, p.z, nd.rr);
+        // rows of the box in blocks of 4 x 4 (one block when r_nms <= the cell edge, the usual case);
+        // lane r of the group owns row r = (kz, ky) of the block
+        const int nyb = have ? bx.hi[1] - bx.lo[1] + 1 : 0, nzb = have ? bx.hi[2] - bx.lo[2] + 1 : 0;
+        int wny = max(nyb, __shfl_xor(nyb, 16)), wnz = max(nzb, __shfl_xor(nzb, 16));
+        wny = max(wny, __shfl_xor(wny, 32));
+        wnz = max(wnz, __shfl_xor(wnz, 32));
         bool greater = false, draw = false;
         int kn = 0;
-        for (int cz = b.lo[2]; cz <= b.hi[2] && (!greater || STATS); ++cz) {
-            for (int cy = b.lo[1]; cy <= b.hi[1] && (!greater || STATS); ++cy) {
-                const int row = (cz * g.dims[1] + cy) * g.dims[0];
-                const int t0 = cell_start[row + b.lo[0]];
-                const int t1 = cell_start[row + b.hi[0] + 1];
-                for (int tb = t0; tb < t1 && (!greater || STATS); tb += kNmsGroup) {
-                    const int t = tb + lane;
-                    bool hit = false, eq = false;
-                    if (t < t1) {
-                        const bool in = dist2(p.x, p.y, p.z, pts[t]) < nd.r2;
-                        if (STATS) kn += in;
-                        const float sj = score_sorted[t];
-                        hit = in && si < sj;                                       // hpp:219
-                        if (DRAWS) eq = in && si == sj && t != s;                  // hpp:224-229
+        for (int kz0 = 0; kz0 < wnz; kz0 += 4)
+        for (int ky0 = 0; ky0 < wny; ky0 += 4) {
+            const int ky = ky0 + (lane & 3), kz = kz0 + (lane >> 2);
+            const bool rvalid = ky < nyb && kz < nzb;
+            const int row = rvalid ? ((bx.lo[2] + kz) * g.dims[1] + bx.lo[1] + ky) * g.dims[0] : 0;
+            const int r0 = rvalid ? cell_start[row + bx.lo[0]] : 0;
+            const int r1 = rvalid ? cell_start[row + bx.hi[0] + 1] : 0;
+            const int len = r1 - r0;
+            int incl = len;                              // inclusive prefix over the 16 lanes of the group
+            for (int off = 1; off < kNmsGroup; off <<= 1) {
+                const int o = __shfl_up(incl, off, kNmsGroup);
+                if (lane >= off) incl += o;
+            }
+            const int total = __shfl(incl, gbase + kNmsGroup - 1);
+            int wtotal = total;                          // the longest list of the wave's 4 groups bounds the loop
+            wtotal = max(wtotal, __shfl_xor(wtotal, 16));
+            wtotal = max(wtotal, __shfl_xor(wtotal, 32));
+            for (int f0 = 0; f0 < wtotal; f0 += kNmsAhead * kNmsGroup) {
+                int t[kNmsAhead];
+                float sj[kNmsAhead];
+                bool in[kNmsAhead];
+#pragma unroll
+                for (int a = 0; a < kNmsAhead; ++a) {
+                    const int f = f0 + a * kNmsGroup + lane;
+                    in[a] = f < total;
+                    // row of position f: the first row whose inclusive prefix exceeds f (binary search over 16 lanes)
+                    int lo = 0;
+#pragma unroll
+                    for (int step = 8; step > 0; step >>= 1) {
+                        const int pre = __shfl(incl, gbase + lo + step - 1);
+                        lo += pre <= f ? step : 0;
                     }
-                    const unsigned long long any = __ballot(hit);
-                    if ((any >> (group_in_wave * kNmsGroup)) & 0xffffull) greater = true;
-                    if (DRAWS) {
-                        const unsigned long long anyeq = __ballot(eq);
-                        if ((anyeq >> (group_in_wave * kNmsGroup)) & 0xffffull) draw = true;
+                    lo = min(lo, kNmsGroup - 1);
+                    const int rincl = __shfl(incl, gbase + lo), rlen = __shfl(len, gbase + lo), rstart = __shfl(r0, gbase + lo);
+                    t[a] = in[a] ? rstart + (f - (rincl - rlen)) : t_last;
+                    sj[a] = score_sorted[min(max(t[a], 0), t_last)];
+                }
+#pragma unroll
+                for (int a = 0; a < kNmsAhead; ++a) {
+                    const bool gt = in[a] && si < sj[a];                                  // hpp:219
+                    const bool eq = DRAWS && in[a] && si == sj[a] && t[a] != s;           // hpp:224-229
+                    const bool need = STATS ? in[a] : (gt || eq);
+                    if (__any(need)) {
+                        const float4 q = pts[need ? t[a] : 0];
+                        const bool inside = need && dist2(p.x, p.y, p.z, q) < nd.r2;
+                        if (STATS) kn += inside;
+                        const unsigned long long hit = __ballot(inside && gt), tie = __ballot(inside && eq);
+                        if ((hit >> gbase) & 0xffffull) greater = true;
+                        if ((tie >> gbase) & 0xffffull) draw = true;
                     }
                 }
+                if (!STATS && !__any(have && !greater)) break;
             }
+            if (!STATS && !__any(have && !greater)) break;
         }
         if (STATS) {
             for (int off = kNmsGroup / 2; off > 0; off >>= 1) kn += __shfl_xor(kn, off);
-            if (lane == 0) {
+            if (lane == 0 && have) {
                 atomicAdd(&stats->sum_kn, (unsigned long long)kn);
                 atomicAdd(&stats->n_thresholded, 1ull);
             }
         }
         // 1 = keypoint (hpp:252-253); 2 = maximum with draws, decided by draws_kernel (hpp:233-250)
-        if (lane == 0 && !greater) flags[__float_as_int(p.w)] = (DRAWS && draw) ? 2 : 1;
+        if (lane == 0 && have && !greater) flags[__float_as_int(p.w)] = (DRAWS && draw) ? 2 : 1;
     }
 }
 
