@@ -1222,17 +1222,36 @@ __global__ __launch_bounds__(1024) void forest_kernel(Batch b, int maxF, int nld
     __syncthreads();
     float *H = reinterpret_cast<float *>(lnodes + nlds_cap) + (size_t)wid * maxF * kLanes;
     const int nchunks = (a.n + kLanes - 1) / kLanes;
-    for (int chunk = blockIdx.x * nwaves + wid; chunk < nchunks; chunk += gridDim.x * nwaves) {
+    const int F = a.f.F, stride = gridDim.x * nwaves;
+    // the feature block of the NEXT chunk of this wave is requested before the trees of the current one are
+    // walked (up to kFeatAhead floats per lane in registers; larger histograms load the rest at the chunk's
+    // turn): a wave would otherwise sit out a trip to memory at the start of every chunk
+    constexpr int kFeatAhead = 32;
+    float ahead[kFeatAhead];
+    auto request = [&](int chunk) {
+        const float *o = a.feat + (size_t)chunk * F * kLanes + lane;
+#pragma unroll
+        for (int c = 0; c < kFeatAhead; ++c) ahead[c] = (chunk < nchunks && c < F) ? o[c * kLanes] : 0.0f;
+    };
+    int chunk = blockIdx.x * nwaves + wid;
+    request(chunk);
+    for (; chunk < nchunks; chunk += stride) {
         {   // per ORIGINAL point: NaN for points that are not in the grid
             const int i = chunk * kLanes + lane;
             if (i < a.n && a.scores && a.cid[i] < 0) a.scores[i] = NAN;
         }
         const WavePoint w = wave_point(a, chunk, lane, false);
+#pragma unroll
+        for (int c = 0; c < kFeatAhead; ++c)
+            if (c < F) H[c * kLanes + lane] = ahead[c];
+        if (F > kFeatAhead) {
+            const float *o = a.feat + (size_t)chunk * F * kLanes + lane;
+            for (int c = kFeatAhead; c < F; ++c) H[c * kLanes + lane] = o[c * kLanes];
+        }
+        request(chunk + stride);
         if (!w.in_range) continue;
         float score = NAN;
         if (w.scoreable) {
-            const float *o = a.feat + (size_t)chunk * a.f.F * kLanes + lane;
-            for (int c = 0; c < a.f.F; ++c) H[c * kLanes + lane] = o[c * kLanes];
             int depth = 0;
             // trees out of step only where it pays (more trees than ways) and is exact (integer leaves)
             float fsum;
