@@ -5,3 +5,4 @@ for l in sys.stdin:
     if l.startswith('{'):
         j=json.loads(l); print(j['value'], j['phases_ms'], j['parity'])
 "
+timeout 100 python tools/fuzz_parity.py 40 31 2>&1 | tail -1
