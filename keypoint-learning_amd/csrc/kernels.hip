@@ -629,7 +629,9 @@ __global__ __launch_bounds__(kSortWaves *kWave) void cell_sort_store_kernel(Batc
                 if (in) {
                     const int pos = sbase + cnt[cc] + rank;
                     pts_out[pos] = make_float4(ax[k], ay[k], az[k], aw[k]);
-                    nrm_out[pos] = make_float4(bx[k], by[k], bz[k], finite3(bx[k], by[k], bz[k]) ? 1.0f : 0.0f);
+                    // w: the normal is finite; x of one that is not: NaN (all a 12-byte read of the record needs)
+                    const bool fin = finite3(bx[k], by[k], bz[k]);
+                    nrm_out[pos] = make_float4(fin ? bx[k] : NAN, by[k], bz[k], fin ? 1.0f : 0.0f);
                 }
                 if (in && rank == same - 1) cnt[cc] += same;   // after every lane's read above (one wave: in order)
                 wave_lds_fence();
@@ -701,7 +703,9 @@ __device__ __forceinline__ CellBox make_box(const GridDesc &g, float x, float y,
 // same order; left to itself the compiler pairs components of two different candidates and pays
 // for it in register moves.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float dist2(float px, float py, float pz, const float4 &q) {
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+template <class Q>
+__device__ __forceinline__ float dist2(float px, float py, float pz, const Q &q) {
     const f32x2 pxy = {px, py}, qxy = {q.x, q.y};
     const f32x2 dxy = pxy - qxy;
     const f32x2 sq = dxy * dxy;
@@ -731,8 +735,9 @@ struct Contribution {
     bool same_a, same_b;     // a' == a / b' == b: the pair index was clamped onto the index (range ends)
 };
 
+template <class NQ>
 __device__ __forceinline__ Contribution neighbor_contribution(const FeatDesc &f, float d2,
-                                                              const float4 &np, const float4 &nq) {
+                                                              const float4 &np, const NQ &nq) {
     const float dot = np.x * nq.x + (np.y * nq.y + np.z * nq.z);                   // hpp:342
     float cosine = 1 - dot;
     int a, ap, bi, bp;
@@ -801,6 +806,10 @@ __device__ __forceinline__ void apply_contribution(float *H, const Contribution 
 __device__ __forceinline__ float4 ld16(const float4 *__restrict__ base, int idx) {
     return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + ((unsigned)idx << 4));
 }
+// the first 12 bytes of a 16-byte record: one dwordx3 load (a quarter less for the texture path to return)
+__device__ __forceinline__ f32x3 ld12(const float4 *__restrict__ base, int idx) {
+    return *reinterpret_cast<const f32x3 *>(reinterpret_cast<const char *>(base) + ((unsigned)idx << 4));
+}
 __device__ __forceinline__ int ld4(const int *__restrict__ base, int idx) {
     return *reinterpret_cast<const int *>(reinterpret_cast<const char *>(base) + ((unsigned)idx << 2));
 }
@@ -813,7 +822,7 @@ constexpr int kStepW = 4;      // candidates per search step: one address, kStep
 constexpr int kWordSteps = 8;  // search steps per accept word (32 candidates)
 
 struct Cand {
-    float4 q[kStepW];
+    f32x3 q[kStepW];
 };
 
 // the kStepW candidates starting at storage position t: ONE address, constant offsets.  Positions
@@ -822,7 +831,7 @@ struct Cand {
 __device__ __forceinline__ Cand load_cand(const float4 *__restrict__ pts, int t) {
     Cand c;
 #pragma unroll
-    for (int j = 0; j < kStepW; ++j) c.q[j] = ld16(pts + j, t);   // uniform base + j, one 32-bit offset
+    for (int j = 0; j < kStepW; ++j) c.q[j] = ld12(pts + j, t);   // uniform base + j, one 32-bit offset
     return c;
 }
 
@@ -848,6 +857,30 @@ __host__ __device__ inline size_t feature_lds_bytes(int F, int ecap) {
     return sizeof(float) * (size_t)F * kLanes + sizeof(uint2) * (size_t)ecap * kLanes;
 }
 
+// The end of one accept word: bits past the end of the row are cleared, the first accepted neighbor of the
+// query is dropped (hpp:336 starts at neigh_indx = 1), a non-empty word goes to the lane's list.  Returns
+// the length of the list.
+__device__ __forceinline__ int list_word(unsigned w, int wbase, int t1, int &kf, bool &first_pending, uint2 *ent,
+                                         int &ecnt, int tid) {
+    const int nv = min(max(t1 - wbase, 0), 32);                  // candidates of this word inside the row
+    w = nv > 0 ? (w & (0xffffffffu << ((32 - nv) & 31))) : 0u;
+    kf += __popc(w);
+    if (first_pending & (w != 0u)) {                             // hpp:336
+        w &= 0x7fffffffu >> (__clz((int)w) & 31);
+        first_pending = false;
+    }
+    if (w != 0u) {
+        ent[ecnt * kLanes + tid] = make_uint2((unsigned)wbase, w);
+        ++ecnt;
+    }
+    return ecnt;
+}
+
+// the latency variant of the search (point_features<true>): the candidate sets of kSearchRing steps in flight
+// per lane.  (The drain gains nothing from more neighbors in flight: 2, 3, 4, 6 and 8 measured the same on one
+// small view, one large view and a batch of 8 -- profiles/r02_notes.md.)
+constexpr int kSearchRing = 4;
+
 // Returns K_f.
 //
 // Two alternating phases per wave, each a loop in which every lane works on ITS OWN query:
@@ -863,6 +896,7 @@ __host__ __device__ inline size_t feature_lds_bytes(int F, int ecap) {
 // then drained and the search resumes.  A wave spends about max-over-lanes(candidates) / 4 cheap
 // search iterations plus max-over-lanes(K_f) accumulate iterations; neighbors never go through
 // global memory, and nothing but the histogram and the accept words lives in LDS.
+template <bool DEEP>
 __device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
                                               const float4 *__restrict__ nrm,
                                               const int *__restrict__ cell_start,
@@ -917,81 +951,121 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
         // ================= search: fill the lanes' word lists =================
         int ecnt = 0;                        // words in the lane's list
         bool full = false;
-        while (!full) {
-            if (!__any(t < t1)) {            // every lane is through with its current row
-                if (!slots_left) break;
-                t = n0;
-                t1 = n1;
-                pre = load_cand(pts, min(t, t_max));
-                if (++ky == wny) {
-                    ky = 0;
-                    ++kz;
+        if constexpr (DEEP) {
+            // kSearchRing steps of candidates in flight.  Nothing is kept across a drain: the ring is requested
+            // afresh at the lane's position whenever the search (re)starts
+            Cand ring[kSearchRing];
+#pragma unroll
+            for (int s = 0; s < kSearchRing; ++s) ring[s] = load_cand(pts, min(t + s * kStepW, t_max));
+            while (!full) {
+                if (!__any(t < t1)) {            // every lane is through with its current row
+                    if (!slots_left) break;
+                    t = n0;
+                    t1 = n1;
+#pragma unroll
+                    for (int s = 0; s < kSearchRing; ++s) ring[s] = load_cand(pts, min(t + s * kStepW, t_max));
+                    if (++ky == wny) {
+                        ky = 0;
+                        ++kz;
+                    }
+                    slots_left = kz < wnz;
+                    if (slots_left) row_range(ky, kz, n0, n1);
+                    continue;
                 }
-                slots_left = kz < wnz;
-                if (slots_left) row_range(ky, kz, n0, n1);
-                continue;
+                // one word: up to kWordSteps steps, each on the ring entry requested kSearchRing steps earlier.
+                // The row can only end for every lane where a pair of steps ends; the ring is then out of step
+                // with t, but the next thing to happen is the switch to another row, which requests it afresh
+                const int wbase = t;
+                unsigned w = 0u;
+                int steps = 0;
+                do {
+                    w = search_step(w, p, ring[0], f.r2);
+                    ring[0] = load_cand(pts, min(t + 4 * kStepW, t_max));
+                    w = search_step(w, p, ring[1], f.r2);
+                    ring[1] = load_cand(pts, min(t + 5 * kStepW, t_max));
+                    steps += 2;
+                    if (!__any(t + 2 * kStepW < t1)) {
+                        t += 2 * kStepW;
+                        break;
+                    }
+                    w = search_step(w, p, ring[2], f.r2);
+                    ring[2] = load_cand(pts, min(t + 6 * kStepW, t_max));
+                    w = search_step(w, p, ring[3], f.r2);
+                    ring[3] = load_cand(pts, min(t + 7 * kStepW, t_max));
+                    steps += 2;
+                    t += 4 * kStepW;
+                } while (steps < kWordSteps && __any(t < t1));
+                w <<= (32 - kStepW * steps) & 31;                            // first candidate -> bit 31
+                full = __any(list_word(w, wbase, t1, kf, first_pending, ent, ecnt, tid) == ecap);
             }
-            // one word: up to kWordSteps steps, two per round so that the two candidate sets swap roles
-            const int wbase = t;
-            unsigned w = 0u;
-            int rounds = 0;
-            do {
-                Cand nxt = load_cand(pts, min(t + kStepW, t_max));
-                w = search_step(w, p, pre, f.r2);
-                pre = load_cand(pts, min(t + 2 * kStepW, t_max));
-                w = search_step(w, p, nxt, f.r2);
-                t += 2 * kStepW;
-                ++rounds;
-            } while (rounds < kWordSteps / 2 && __any(t < t1));
-            w <<= (32 - 2 * kStepW * rounds) & 31;                       // first candidate -> bit 31
-            const int nv = min(max(t1 - wbase, 0), 32);                  // candidates of this word inside the row
-            w = nv > 0 ? (w & (0xffffffffu << ((32 - nv) & 31))) : 0u;
-            kf += __popc(w);
-            if (first_pending & (w != 0u)) {                             // hpp:336
-                w &= 0x7fffffffu >> (__clz((int)w) & 31);
-                first_pending = false;
+        } else {
+            while (!full) {
+                if (!__any(t < t1)) {            // every lane is through with its current row
+                    if (!slots_left) break;
+                    t = n0;
+                    t1 = n1;
+                    pre = load_cand(pts, min(t, t_max));
+                    if (++ky == wny) {
+                        ky = 0;
+                        ++kz;
+                    }
+                    slots_left = kz < wnz;
+                    if (slots_left) row_range(ky, kz, n0, n1);
+                    continue;
+                }
+                // one word: up to kWordSteps steps, two per round so that the two candidate sets swap roles
+                const int wbase = t;
+                unsigned w = 0u;
+                int rounds = 0;
+                do {
+                    Cand nxt = load_cand(pts, min(t + kStepW, t_max));
+                    w = search_step(w, p, pre, f.r2);
+                    pre = load_cand(pts, min(t + 2 * kStepW, t_max));
+                    w = search_step(w, p, nxt, f.r2);
+                    t += 2 * kStepW;
+                    ++rounds;
+                } while (rounds < kWordSteps / 2 && __any(t < t1));
+                w <<= (32 - 2 * kStepW * rounds) & 31;                       // first candidate -> bit 31
+                full = __any(list_word(w, wbase, t1, kf, first_pending, ent, ecnt, tid) == ecap);
             }
-            if (w != 0u) {
-                ent[ecnt * kLanes + tid] = make_uint2((unsigned)wbase, w);
-                ++ecnt;
-            }
-            full = __any(ecnt == ecap);
         }
         // ================= drain: accumulate the listed neighbors =================
         if (__any(ecnt > 0)) {
             struct Taken {
                 bool valid;
-                float4 q, n;
+                f32x3 q, n;      // n.x is NaN for a normal that is not finite
             };
-            Taken pa, pb;
-            pa.valid = pb.valid = false;
-            pa.q = pa.n = pb.q = pb.n = make_float4(0.f, 0.f, 0.f, 0.f);
             int e = tid;                               // list position (in uint2 units) of the next word
             const int e_end = ecnt * kLanes + tid;
             unsigned w = 0u;
             int wbase = 0;
             uint2 nw = ent[tid];                       // next word, requested one iteration ahead
-            // One iteration: take the next neighbor into `nxt` and request its point and normal,
-            // accumulate `now` (taken one iteration ago).  Loads are issued unconditionally with a
-            // clamped address: a load behind a branch makes the compiler wait for it at the join.
-            // (A deeper pipeline -- neighbors taken two iterations ahead, the cells of one
-            // contribution requested under the arithmetic of the next -- measured 8 % slower: the
-            // loop is bound by VALU issue, not by its latencies, profiles/r02_notes.md.)
+            // the next neighbor of the lane's list -> `slot`, its point and normal requested (clamped address:
+            // a load behind a branch makes the compiler wait for it at the join)
+            auto take = [&](Taken &slot) {
+                const bool refill = (w == 0u) & (e < e_end);
+                w = refill ? nw.y : w;
+                wbase = refill ? (int)nw.x : wbase;
+                e += refill ? kLanes : 0;
+                nw = ent[min(e, ent_last)];
+                slot.valid = w != 0u;
+                const int j = __clz((int)w) & 31;
+                const int tt = slot.valid ? wbase + j : 0;
+                w &= 0x7fffffffu >> j;
+                slot.q = ld12(pts, tt);
+                slot.n = ld12(nrm, tt);
+            };
+            Taken pa, pb;
+            pa.valid = pb.valid = false;
+            pa.q = pa.n = pb.q = pb.n = f32x3{0.f, 0.f, 0.f};
+            // One iteration: take the next neighbor into `nxt`, accumulate `now` (taken one iteration ago).
+            // (A deeper pipeline costs instructions: with enough waves per SIMD this loop is bound by VALU
+            // issue, not by its latencies, and the two-slot form is the faster one -- profiles/r02_notes.md.)
 #define KPL_DRAIN_ITERATION(now, nxt)                                                              \
     {                                                                                              \
-        const bool refill_ = (w == 0u) & (e < e_end);                                              \
-        w = refill_ ? nw.y : w;                                                                    \
-        wbase = refill_ ? (int)nw.x : wbase;                                                       \
-        e += refill_ ? kLanes : 0;                                                                 \
-        nw = ent[min(e, ent_last)];                                                                \
-        nxt.valid = w != 0u;                                                                       \
-        const int j_ = __clz((int)w) & 31;                                                         \
-        const int t_ = nxt.valid ? wbase + j_ : 0;                                                 \
-        w &= 0x7fffffffu >> j_;                                                                    \
-        nxt.q = ld16(pts, t_);                                                                     \
-        nxt.n = ld16(nrm, t_);                                                                     \
+        take(nxt);                                                                                 \
         /* hpp:338: a neighbor with a non-finite normal is skipped */                              \
-        if (now.valid & (now.n.w != 0.0f)) {                                                       \
+        if (now.valid & (now.n.x == now.n.x)) {                                                    \
             const Contribution c_ = neighbor_contribution(f, dist2(p.x, p.y, p.z, now.q), np, now.n); \
             apply_contribution(H, c_, request_cells(H, c_));                                       \
         }                                                                                          \
@@ -1192,7 +1266,7 @@ __device__ __forceinline__ WavePoint wave_point(const ViewDev &a, int chunk, int
 
 // Several independent views per launch (blockIdx.y = view): 200 k points are only ~3 waves per
 // SIMD, too few to hide the latencies of this kernel; a batch of views fills the chip.
-template <bool STATS>
+template <bool STATS, bool DEEP>
 __global__ __launch_bounds__(kLanes) void feature_kernel(Batch b, int maxF, int ecap) {
     extern __shared__ float H[];
     const ViewDev &v = b.view[blockIdx.y];
@@ -1201,7 +1275,7 @@ __global__ __launch_bounds__(kLanes) void feature_kernel(Batch b, int maxF, int 
     const WavePoint w = wave_point(v, chunk, threadIdx.x, true);
     // every lane of the wave runs the feature code (wave-level votes inside); lanes without a
     // scoreable point simply have no rows
-    const int kf = point_features(v.pts, v.nrm, v.cell_start, v.ds->grid, v.f, w.p, w.np, H,
+    const int kf = point_features<DEEP>(v.pts, v.nrm, v.cell_start, v.ds->grid, v.f, w.p, w.np, H,
                                   reinterpret_cast<uint2 *>(H + maxF * kLanes), ecap, w.scoreable);
     if (STATS && w.scoreable) atomicAdd(&v.stats->sum_kf, (unsigned long long)kf);
     float *o = v.feat + (size_t)chunk * v.f.F * kLanes + threadIdx.x;
@@ -1358,7 +1432,7 @@ __global__ __launch_bounds__(kLanes) void features_kernel(const float4 *__restri
     }
     const float4 p = s >= 0 ? pts[s] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 np = s >= 0 ? nrm[s] : make_float4(0.f, 0.f, 0.f, 0.f);
-    point_features(pts, nrm, cell_start, g, f, p, np, H, ent, ecap, s >= 0);
+    point_features<false>(pts, nrm, cell_start, g, f, p, np, H, ent, ecap, s >= 0);
     if (qi >= m) return;
     float *o = out + (size_t)qi * f.F;
     for (int c = 0; c < f.F; ++c) o[c] = s >= 0 ? H[c * kLanes + threadIdx.x] : NAN;
@@ -2016,8 +2090,9 @@ size_t pts_bytes(int n) { return sizeof(float4) * ((size_t)(n > 0 ? n : 1) + kSt
 // while kMinWaves waves per CU stay resident (160 KB of LDS per CU), between 4 and 16.  A lane whose
 // neighborhood needs more words than that simply searches and drains in several rounds.
 constexpr int kLdsPerCu = 160 * 1024, kMinWavesPerCu = 12;
-static int accept_words(int F) {
-    const long long room = kLdsPerCu / kMinWavesPerCu - (long long)sizeof(float) * F * kLanes;
+constexpr double kDeepBelow = 2.5;
+static int accept_words(int F, int waves_per_cu) {
+    const long long room = kLdsPerCu / waves_per_cu - (long long)sizeof(float) * F * kLanes;
     long long e = room / (long long)(sizeof(uint2) * kLanes);
     if (e < 4) e = 4;
     if (e > 16) e = 16;
@@ -2071,11 +2146,28 @@ void launch_feature_stage(const Batch &b, hipStream_t st) {
         maxF = b.view[v].f.F > maxF ? b.view[v].f.F : maxF;
         stats |= b.view[v].stats != nullptr;
     }
-    const int ecap = accept_words(maxF);
+    long long waves = 0;
+    for (int v = 0; v < b.nviews; ++v) waves += div_up(b.view[v].n > 0 ? b.view[v].n : 0, kLanes);
+    // Waves resident per SIMD with the throughput variant: what the launch offers and what fits in LDS.  Below
+    // kDeepBelow the loops of the feature code wait for memory at every step with nothing else to run, and the
+    // latency variant (several steps in flight per lane, more instructions) is the faster one
+    int ecap = accept_words(maxF, kMinWavesPerCu);
+    const double fit = (double)kLdsPerCu / (double)feature_lds_bytes(maxF, ecap) / 4.0;
+    const double offered = (double)waves / (4.0 * cu_count());
+    const bool deep = (offered < fit ? offered : fit) < kDeepBelow;
+    if (deep && offered < fit) {                  // few waves: LDS to spare, longer word lists, fewer drains
+        int per_cu = (int)(waves / cu_count()) + 1;
+        ecap = accept_words(maxF, per_cu < kMinWavesPerCu ? per_cu : kMinWavesPerCu);
+    }
     const size_t lds = feature_lds_bytes(maxF, ecap);
     const dim3 grid(div_up(n, kLanes), b.nviews);
-    if (stats) feature_kernel<true><<<grid, kLanes, lds, st>>>(b, maxF, ecap);
-    else feature_kernel<false><<<grid, kLanes, lds, st>>>(b, maxF, ecap);
+    if (stats) {
+        if (deep) feature_kernel<true, true><<<grid, kLanes, lds, st>>>(b, maxF, ecap);
+        else feature_kernel<true, false><<<grid, kLanes, lds, st>>>(b, maxF, ecap);
+    } else {
+        if (deep) feature_kernel<false, true><<<grid, kLanes, lds, st>>>(b, maxF, ecap);
+        else feature_kernel<false, false><<<grid, kLanes, lds, st>>>(b, maxF, ecap);
+    }
 }
 
 // second kernel: feat -> forest response (score_sorted, scores) and the NMS candidates
@@ -2125,7 +2217,7 @@ void launch_features(const float4 *pts, const float4 *nrm, const int *cell_start
                      const int *pos_of, const DevState *ds, FeatDesc f, const int *query, int m, int n,
                      float *out, hipStream_t st) {
     if (m <= 0) return;
-    const int ecap = accept_words(f.F);
+    const int ecap = accept_words(f.F, kMinWavesPerCu);
     features_kernel<<<div_up(m, kLanes), kLanes, feature_lds_bytes(f.F, ecap), st>>>(pts, nrm, cell_start, pos_of, ds, f,
                                                                                     query, m, n, ecap, out);
 }
