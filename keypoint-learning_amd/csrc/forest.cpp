@@ -424,7 +424,15 @@ bool flatten_forest(const ForestModel &m, FlatForest &out, std::string &err) {
         out.nodes.push_back(FlatNode{0, 0});
         level.push_back(Item{r, out.roots.back(), 1});
     }
-    std::vector<Item> pairs;          // left members of the sibling pairs that start the blocked part
+    // the resting leaf (value 0) right behind the roots: where a walk without a tree sits (kernels.hip)
+    {
+        FlatNode rest;
+        const float zero = 0.0f;
+        memcpy(&rest.x, &zero, 4);
+        rest.y = kLeafVar << 24;
+        out.nodes.push_back(rest);
+    }
+    std::vector<Item> pairs;          // internal nodes of the last top level: their children start the blocked part
     while (!level.empty()) {
         size_t internal = 0;
         for (const Item &it : level) internal += m.var[it.src] >= 0 ? 1 : 0;
@@ -448,40 +456,44 @@ bool flatten_forest(const ForestModel &m, FlatForest &out, std::string &err) {
         if (!top) break;
         level.swap(next);
     }
-    // Blocked part: every pending internal node gets a 16-slot block for its descendants, three levels
-    // of them: slots [0,1] its children, [2,3] / [4,5] their children, [6..13] the grandchildren's
-    // level; the children of THAT level start blocks of their own.
+    out.ntop = (uint32_t)out.nodes.size();
+    // Blocked part: the two children of every pending internal node get one 128-byte line: two blocks of
+    // kBlockSlots = 8 slots, the left child's at `base`, the right child's at base + 8.  A block holds a
+    // subtree of three levels: slot 0 its root, slots 1 2 the root's children, slots 3 4 the children of
+    // slot 1, slots 5 6 those of slot 2 (slot 7 stays empty).  Inside a block the walk needs no child
+    // index; a node of the third level points at the line of ITS children, as the pending node does.
     while (!pairs.empty()) {
         const Item parent = pairs.back();
         pairs.pop_back();
         size_t base = out.nodes.size();
-        base = (base + kBlockSlots - 1) / kBlockSlots * kBlockSlots;
-        if (base + kBlockSlots > (size_t)kMaxFlatNodes) { err = "forest needs more than 2^24 node slots"; return false; }
-        out.nodes.resize(base + kBlockSlots, FlatNode{0, 0});
-        if (emit(parent, (uint32_t)base, err) < 0) return false;                  // the parent's record points at slot 0
-        // slot s of the block holds the node src[s]; children of slot s (s < 6) live at slots 2 + 2s, 3 + 2s
-        int src[kBlockSlots];
-        int depth[kBlockSlots];
-        for (uint32_t k = 0; k < kBlockSlots; ++k) src[k] = -1;
-        src[0] = m.left[parent.src];
-        src[1] = m.right[parent.src];
-        depth[0] = depth[1] = parent.depth + 1;
-        for (uint32_t sl = 0; sl < 14; ++sl) {
-            if (src[sl] < 0) continue;
-            const Item it{src[sl], (uint32_t)(base + sl), depth[sl]};
-            if (sl < 6) {
-                const uint32_t c = 2 + 2 * sl;
-                const int kind = emit(it, (uint32_t)(base + c), err);
-                if (kind < 0) return false;
-                if (kind == 1) {
-                    src[c] = m.left[it.src];
-                    src[c + 1] = m.right[it.src];
-                    depth[c] = depth[c + 1] = it.depth + 1;
+        base = (base + 2 * kBlockSlots - 1) / (2 * kBlockSlots) * (2 * kBlockSlots);
+        if (base + 2 * kBlockSlots > (size_t)kMaxFlatNodes) { err = "forest needs more than 2^24 node slots"; return false; }
+        out.nodes.resize(base + 2 * kBlockSlots, FlatNode{0, 0});
+        if (emit(parent, (uint32_t)base, err) < 0) return false;                  // the parent's record points at the left block
+        for (uint32_t side = 0; side < 2; ++side) {
+            const uint32_t b = (uint32_t)base + side * kBlockSlots;
+            int src[kBlockSlots];
+            int depth[kBlockSlots];
+            for (uint32_t k = 0; k < kBlockSlots; ++k) src[k] = -1;
+            src[0] = side == 0 ? m.left[parent.src] : m.right[parent.src];
+            depth[0] = parent.depth + 1;
+            for (uint32_t sl = 0; sl < 7; ++sl) {
+                if (src[sl] < 0) continue;
+                const Item it{src[sl], b + sl, depth[sl]};
+                if (sl < 3) {
+                    const uint32_t c = 1 + 2 * sl;                                // children of slot sl: slots 1 + 2 sl, 2 + 2 sl
+                    const int kind = emit(it, b + c, err);
+                    if (kind < 0) return false;
+                    if (kind == 1) {
+                        src[c] = m.left[it.src];
+                        src[c + 1] = m.right[it.src];
+                        depth[c] = depth[c + 1] = it.depth + 1;
+                    }
+                } else if (m.var[it.src] >= 0) {
+                    pairs.push_back(it);                 // emitted when the line of its children is placed
+                } else if (emit(it, 0u, err) < 0) {
+                    return false;
                 }
-            } else if (m.var[it.src] >= 0) {
-                pairs.push_back(it);                 // emitted when its own block is placed
-            } else if (emit(it, 0u, err) < 0) {
-                return false;
             }
         }
     }

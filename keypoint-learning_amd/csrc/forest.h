@@ -28,14 +28,19 @@ struct ForestModel {
 // Device layout: one 8-byte record per node.
 //   x = threshold bits (internal) or leaf value as float bits (leaf)
 //   y = [31:24] split variable (0..254; 255 = leaf)   [23:0] index of the LEFT child
-// Siblings are adjacent (right = left + 1).  The forest is laid out breadth first, level by level
+// In the top part siblings are adjacent (right = left + 1).  The forest is laid out breadth first, level by level
 // ACROSS the trees: node t is the root of tree t, then come the second levels of all trees, and so
-// on -- the first k nodes are the top of every tree (what the forest kernel stages in LDS) -- for
-// as many whole levels as fit kTopNodes slots.  What lies below is laid out for the cache line:
-// blocks of 16 slots (128 bytes) holding a sibling pair, its 4 children and its 8 grandchildren,
-// so that a walk through global memory touches one line per three levels instead of one per level
-// (a 100-tree forest of 2 M nodes is 16 MB: its deep nodes come from beyond the L2).  Slots that
-// hold no node are never referenced.
+// on -- the first k nodes are the top of every tree (what the forest kernel stages in LDS); slot ntrees,
+// right behind the roots, is a "resting leaf" of value 0 that belongs to no tree (kernels.hip parks idle walks
+// there) -- for
+// as many whole levels as fit kTopNodes slots (FlatForest::ntop slots in all).  What lies below is
+// laid out for the cache line and for one lane fetching a whole subtree at once: blocks of 8 slots
+// (64 bytes) holding a node, its 2 children and its 4 grandchildren (slots 0 | 1 2 | 3 4 5 6), the
+// blocks of two siblings side by side in one 128-byte line.  A walk below the top part costs one
+// 64-byte fetch per three levels instead of one line per level (a 100-tree forest of 2 M nodes is
+// 16 MB: its deep nodes come from beyond the L1, and lines do not survive there from one level to
+// the next).  A record whose children start blocks holds the slot of the LEFT child's block; the
+// right child's block is 8 slots further.  Slots that hold no node are never referenced.
 struct FlatNode {
     uint32_t x;
     uint32_t y;
@@ -43,7 +48,7 @@ struct FlatNode {
 constexpr uint32_t kLeafVar = 255u;
 constexpr uint32_t kMaxFlatNodes = 1u << 24;   // slots, padding of the blocked part included
 constexpr uint32_t kTopNodes = 8192;           // = the forest kernel's LDS node budget (64 KB)
-constexpr uint32_t kBlockSlots = 16;
+constexpr uint32_t kBlockSlots = 8;
 
 struct FlatForest {
     int ntrees = 0;
@@ -53,6 +58,7 @@ struct FlatForest {
                                      // trees: the sum of leaf values is exact in any order (and fits an int32)
     std::vector<uint32_t> roots;     // [ntrees] node index of each root (= the tree's number)
     std::vector<FlatNode> nodes;     // slots
+    uint32_t ntop = 0;               // slots of the level-major top part; every slot >= ntop belongs to a block
     int64_t nnodes = 0;              // nodes of the model (nodes.size() counts padding slots too)
 };
 

@@ -57,7 +57,8 @@ struct NmsList {
 struct ForestDev {
     const uint2 *nodes;      // level-major (forest.h): node t is the root of tree t, the first k nodes are the top of every tree
     int ntrees;
-    int nnodes;
+    int nnodes;              // slots
+    int ntop;                // slots of the level-major top part; slots >= ntop are 8-slot blocks (forest.h)
     int order_free;          // FlatForest::order_free: the trees of a point may be summed in any order
 };
 

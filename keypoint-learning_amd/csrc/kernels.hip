@@ -801,12 +801,9 @@ __device__ __forceinline__ void apply_contribution(float *H, const Contribution 
     hist_at(H, c.c3) = x3;
 }
 
-// 16-byte / 4-byte loads addressed by a 32-bit byte offset from a wave-uniform base (one shift
-// instead of 64-bit address arithmetic per load; views are limited to 2^28 points)
-__device__ __forceinline__ float4 ld16(const float4 *__restrict__ base, int idx) {
-    return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + ((unsigned)idx << 4));
-}
-// the first 12 bytes of a 16-byte record: one dwordx3 load (a quarter less for the texture path to return)
+// 12-byte / 4-byte loads addressed by a 32-bit byte offset from a wave-uniform base (one shift
+// instead of 64-bit address arithmetic per load; views are limited to 2^28 points).
+// The first 12 bytes of a 16-byte record: one dwordx3 load (a quarter less for the texture path to return)
 __device__ __forceinline__ f32x3 ld12(const float4 *__restrict__ base, int idx) {
     return *reinterpret_cast<const f32x3 *>(reinterpret_cast<const char *>(base) + ((unsigned)idx << 4));
 }
@@ -1095,25 +1092,31 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
 
 // runForest, hpp:267-296 + cv::ml::RTrees::predict(PREDICT_SUM) restated (hpp:281): per tree
 // walk "val <= thr ? left : right", double sum of leaf values in tree order, (float)sum,
-// score = 1 - sum / (T * 1.0f).  kTreeWays trees are walked at once per lane so that several
-// dependent node reads are in flight; a finished walk re-reads its leaf until the others end.
-// The first `nlds` nodes of the (level-major) forest are read from LDS, deeper ones from global
-// memory: 64 lanes at 64 different nodes are 64 cache lines for one load instruction, and the
-// texture path takes about a cycle per line -- the LDS serves the same request in a few cycles.
-// The walk is written without data-dependent branches: a walk that has reached its leaf is parked on
-// the root of its tree (a node in LDS) with its leaf value kept in a register, the split variable of
-// a leaf reads feature 0 and is ignored, and all node reads of a level are issued before the first
-// one is used, then all feature reads -- one LDS round trip each per level for all ways together.
-// Lanes whose node is in LDS send their global load to node 0: the requests of a wave are served
-// line by line, and one shared line costs one cycle however many lanes ask for it.
-constexpr int kTreeWays = 10;
+// score = 1 - sum / (T * 1.0f).  Several trees are walked at once per lane so that several
+// dependent node reads are in flight.  The walks are written without data-dependent branches: the
+// split variable of a leaf reads feature 0 and is ignored, and all node reads of a level are issued
+// before the first one is used, then all feature reads -- one LDS round trip each per level for all
+// ways together.
+//
+// Where the nodes come from (layout: forest.h):
+//   top part, slots < ntop   level-major; its first `nlds` slots are staged in LDS by the forest
+//                            kernels (all of it unless the histograms leave less than 64 KB); the
+//                            rest, if any, is read node by node from global memory
+//   blocks, slots >= ntop    8-slot (64-byte) subtrees of three levels: a lane fetches the whole block
+//                            with four 16-byte loads and walks its three levels out of registers.
+//                            Node by node, 64 lanes at 64 different nodes are 64 cache lines per level,
+//                            and with thousands of such lines in flight per CU a line does not survive
+//                            in the L1 until the walk comes back for the next level: the deep walk of
+//                            config 5 moved 28 GB from the L2 for 1.8 GB of nodes (profiles/r02_notes.md).
+constexpr int kTreeWays = 10;    // forest entirely in LDS
+constexpr int kDeepWays = 4;     // forest with blocks: 16 VGPRs of block per way
 
 template <int WAYS>
 __device__ __forceinline__ void fetch_nodes(const ForestDev &forest, const uint2 *lnodes, uint32_t last_lds,
                                             bool all_in_lds, const uint32_t (&nd)[WAYS], uint2 (&node)[WAYS]) {
 #pragma unroll
     for (int k = 0; k < WAYS; ++k) node[k] = lnodes[min(nd[k], last_lds)];
-    if (!all_in_lds) {      // deep nodes of a large forest: global memory, all ways issued before the first use
+    if (!all_in_lds) {      // nodes beyond the LDS: global memory, all ways issued before the first use
         bool far_any = false;
 #pragma unroll
         for (int k = 0; k < WAYS; ++k) far_any |= nd[k] > last_lds;
@@ -1129,10 +1132,9 @@ __device__ __forceinline__ void fetch_nodes(const ForestDev &forest, const uint2
     }
 }
 
-// PARK = false: the whole forest is in LDS; a finished walk simply keeps re-reading its leaf (the
-// leanest loop).  PARK = true: part of the forest is in global memory; a finished walk is parked on the
-// root of its tree with its leaf value kept in a register, so that it costs no more global loads.
-template <bool STATS, bool PARK>
+// The whole forest is in LDS (the leanest loop): kTreeWays trees in step, a finished walk keeps re-reading
+// its leaf until the others end.
+template <bool STATS>
 __device__ __forceinline__ float forest_sum(const ForestDev &forest, const uint2 *lnodes, int nlds,
                                             const float *x, int &depth) {
     double sum = 0.0;
@@ -1140,16 +1142,14 @@ __device__ __forceinline__ float forest_sum(const ForestDev &forest, const uint2
     for (int t0 = 0; t0 < forest.ntrees; t0 += kTreeWays) {
         uint32_t nd[kTreeWays];
         uint2 node[kTreeWays];
-        float leafval[kTreeWays];
-        bool done[kTreeWays];          // PARK, or STATS: the walk had reached its leaf before this read
+        bool done[kTreeWays];          // STATS: the walk had reached its leaf before this read
 #pragma unroll
         for (int k = 0; k < kTreeWays; ++k) {
             nd[k] = t0 + k < forest.ntrees ? t0 + k : t0;       // level-major layout: the root of tree t is node t
             done[k] = t0 + k >= forest.ntrees;
-            leafval[k] = 0.0f;
         }
         for (;;) {
-            fetch_nodes<kTreeWays>(forest, lnodes, last_lds, !PARK, nd, node);
+            fetch_nodes<kTreeWays>(forest, lnodes, last_lds, true, nd, node);
             float val[kTreeWays];
             bool leaf[kTreeWays];
 #pragma unroll
@@ -1163,75 +1163,190 @@ __device__ __forceinline__ float forest_sum(const ForestDev &forest, const uint2
             for (int k = 0; k < kTreeWays; ++k) {
                 const uint32_t next = (node[k].y & 0x00ffffffu) + (val[k] <= __uint_as_float(node[k].x) ? 0u : 1u);
                 if (STATS) depth += done[k] ? 0 : 1;            // visited nodes: internal ones and the leaf, once
-                if (PARK) {
-                    const bool arrives = leaf[k] & !done[k];
-                    leafval[k] = arrives ? __uint_as_float(node[k].x) : leafval[k];
-                    done[k] |= leaf[k];
-                    nd[k] = done[k] ? (uint32_t)t0 : next;      // parked on a root: a node that is always in LDS
-                    all_done &= done[k];
-                } else {
-                    if (STATS) done[k] = leaf[k];
-                    nd[k] = leaf[k] ? nd[k] : next;
-                    all_done &= leaf[k];
-                }
+                if (STATS) done[k] = leaf[k];
+                nd[k] = leaf[k] ? nd[k] : next;
+                all_done &= leaf[k];
             }
             if (__all(all_done)) break;
         }
 #pragma unroll
         for (int k = 0; k < kTreeWays; ++k)
-            if (t0 + k < forest.ntrees) sum += (double)(PARK ? leafval[k] : __uint_as_float(node[k].x));
+            if (t0 + k < forest.ntrees) sum += (double)__uint_as_float(node[k].x);
     }
     return (float)sum;
 }
 
-// The same walk for a forest whose leaf values are small integers (class labels: every forest the
-// reference trains, src/main_train_detector.cpp:405-407): the double sum of hpp:281 is then exact in
-// any order and equals an int32 sum, so a lane need not keep its trees in step.  Each of its
-// walks takes the lane's next tree as soon as it reaches a leaf; the loop runs for about
-// sum-of-depths / ways steps instead of (trees / ways) x the depth of the deepest tree.
-// The lane walks the trees first, first + tstride, ...; its features are x[var * xstride].
-template <bool STATS, int kQueueWays>
-__device__ __forceinline__ int forest_sum_any_order(const ForestDev &forest, const uint2 *lnodes, int nlds,
-                                                    const float *x, int xstride, int first, int tstride, bool active,
-                                                    int &depth) {
-    const bool all_in_lds = nlds >= forest.nnodes;
-    const uint32_t last_lds = (uint32_t)(nlds - 1);
-    const int ntrees = active ? forest.ntrees : 0;
-    int sum = 0;
-    int next_tree = first + tstride * kQueueWays;      // per lane: its first kQueueWays trees are taken
-    uint32_t nd[kQueueWays];
-    bool live[kQueueWays];
+// WAYS trees of a forest with blocks, walked to their leaves: tree[k] < 0 = no tree (leaf value 0).
+//   phase 1  the top part, one level per step, until every walk is at a leaf or at the root of a block
+//   phase 2  one block = up to three levels per step.  A finished walk fetches block 0 (one line shared
+//            by every such lane: the requests of a wave are served line by line).
+// The features of the lane's point are x[var * xstride].
+template <bool STATS, int WAYS>
+__device__ __forceinline__ void walk_deep(const ForestDev &forest, const uint2 *lnodes, int nlds, const float *x,
+                                          int xstride, const int (&tree)[WAYS], float (&leafval)[WAYS], int &depth) {
+    const uint32_t last_lds = (uint32_t)(nlds - 1), ntop = (uint32_t)forest.ntop;
+    const bool top_in_lds = (uint32_t)nlds >= ntop;
+    uint32_t nd[WAYS];
+    bool done[WAYS];
 #pragma unroll
-    for (int k = 0; k < kQueueWays; ++k) {
-        live[k] = first + tstride * k < ntrees;
-        nd[k] = live[k] ? first + tstride * k : 0;     // level-major layout: the root of tree t is node t
+    for (int k = 0; k < WAYS; ++k) {
+        done[k] = tree[k] < 0;
+        nd[k] = done[k] ? 0u : (uint32_t)tree[k];               // level-major layout: the root of tree t is node t
+        leafval[k] = 0.0f;
     }
-    for (;;) {
-        uint2 node[kQueueWays];
-        fetch_nodes<kQueueWays>(forest, lnodes, last_lds, all_in_lds, nd, node);
-        float val[kQueueWays];
-        bool leaf[kQueueWays];
+    for (;;) {                                                  // ---- phase 1
+        bool go = false;
 #pragma unroll
-        for (int k = 0; k < kQueueWays; ++k) {
+        for (int k = 0; k < WAYS; ++k) go |= !done[k] & (nd[k] < ntop);
+        if (!__any(go)) break;
+        uint32_t at[WAYS];
+        uint2 node[WAYS];
+#pragma unroll
+        for (int k = 0; k < WAYS; ++k) at[k] = (done[k] | (nd[k] >= ntop)) ? 0u : nd[k];
+        fetch_nodes<WAYS>(forest, lnodes, last_lds, top_in_lds, at, node);
+        float val[WAYS];
+        bool leaf[WAYS];
+#pragma unroll
+        for (int k = 0; k < WAYS; ++k) {
             const uint32_t var = node[k].y >> 24;
             leaf[k] = var == 255u;
             val[k] = x[(leaf[k] ? 0u : var) * xstride];
         }
-        bool any_live = false;
+#pragma unroll
+        for (int k = 0; k < WAYS; ++k) {
+            const bool walking = !done[k] & (nd[k] < ntop);
+            const uint32_t child = node[k].y & 0x00ffffffu;
+            // siblings are adjacent in the top part, their blocks 8 slots apart below it
+            const uint32_t next = child + (val[k] <= __uint_as_float(node[k].x) ? 0u : (child >= ntop ? 8u : 1u));
+            if (STATS) depth += walking ? 1 : 0;
+            leafval[k] = (walking & leaf[k]) ? __uint_as_float(node[k].x) : leafval[k];
+            done[k] |= walking & leaf[k];
+            nd[k] = (walking & !leaf[k]) ? next : nd[k];
+        }
+    }
+    for (;;) {                                                  // ---- phase 2
+        bool go = false;
+#pragma unroll
+        for (int k = 0; k < WAYS; ++k) go |= !done[k];
+        if (!__any(go)) break;
+        uint4 blk[WAYS][4];                                     // slots (0 1) (2 3) (4 5) (6 -)
+#pragma unroll
+        for (int k = 0; k < WAYS; ++k) {
+            const char *src = reinterpret_cast<const char *>(forest.nodes) + ((done[k] ? 0u : nd[k]) << 3);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) blk[k][j] = *reinterpret_cast<const uint4 *>(src + 16 * j);
+        }
+        // level by level for all ways, so that the feature reads of a level are in flight together
+        uint2 n0[WAYS], n1[WAYS], n2[WAYS];
+        float v[WAYS];
+        bool r0[WAYS], r1[WAYS];
+#pragma unroll
+        for (int k = 0; k < WAYS; ++k) {
+            n0[k] = make_uint2(blk[k][0].x, blk[k][0].y);
+            const uint32_t var = n0[k].y >> 24;
+            v[k] = x[(var == 255u ? 0u : var) * xstride];
+        }
+#pragma unroll
+        for (int k = 0; k < WAYS; ++k) {
+            r0[k] = !(v[k] <= __uint_as_float(n0[k].x));
+            n1[k] = r0[k] ? make_uint2(blk[k][1].x, blk[k][1].y) : make_uint2(blk[k][0].z, blk[k][0].w);
+            const uint32_t var = n1[k].y >> 24;
+            v[k] = x[(var == 255u ? 0u : var) * xstride];
+        }
+#pragma unroll
+        for (int k = 0; k < WAYS; ++k) {
+            r1[k] = !(v[k] <= __uint_as_float(n1[k].x));
+            const uint2 a = r1[k] ? make_uint2(blk[k][2].x, blk[k][2].y) : make_uint2(blk[k][1].z, blk[k][1].w);   // slots 4 : 3
+            const uint2 b = r1[k] ? make_uint2(blk[k][3].x, blk[k][3].y) : make_uint2(blk[k][2].z, blk[k][2].w);   // slots 6 : 5
+            n2[k] = r0[k] ? b : a;
+            const uint32_t var = n2[k].y >> 24;
+            v[k] = x[(var == 255u ? 0u : var) * xstride];
+        }
+#pragma unroll
+        for (int k = 0; k < WAYS; ++k) {
+            const bool l0 = (n0[k].y >> 24) == 255u, l1 = (n1[k].y >> 24) == 255u, l2 = (n2[k].y >> 24) == 255u;
+            const bool ends = l0 | l1 | l2;
+            const uint32_t lv = l0 ? n0[k].x : l1 ? n1[k].x : n2[k].x;
+            if (STATS) depth += done[k] ? 0 : (l0 ? 1 : l1 ? 2 : 3);
+            leafval[k] = (!done[k] & ends) ? __uint_as_float(lv) : leafval[k];
+            nd[k] = (n2[k].y & 0x00ffffffu) + (v[k] <= __uint_as_float(n2[k].x) ? 0u : 8u);
+            done[k] |= ends;
+        }
+    }
+}
+
+// Forest with blocks, one lane per point: kDeepWays trees at a time, leaf values added in tree order (hpp:281).
+template <bool STATS>
+__device__ __forceinline__ float forest_sum_deep(const ForestDev &forest, const uint2 *lnodes, int nlds,
+                                                 const float *x, int &depth) {
+    double sum = 0.0;
+    for (int t0 = 0; t0 < forest.ntrees; t0 += kDeepWays) {
+        int tree[kDeepWays];
+        float leafval[kDeepWays];
+#pragma unroll
+        for (int k = 0; k < kDeepWays; ++k) tree[k] = t0 + k < forest.ntrees ? t0 + k : -1;
+        walk_deep<STATS, kDeepWays>(forest, lnodes, nlds, x, kLanes, tree, leafval, depth);
+#pragma unroll
+        for (int k = 0; k < kDeepWays; ++k)
+            if (t0 + k < forest.ntrees) sum += (double)leafval[k];
+    }
+    return (float)sum;
+}
+
+// A forest whose leaf values are small integers (class labels: every forest the reference trains,
+// src/main_train_detector.cpp:405-407): the double sum of hpp:281 is then exact in any order and equals an
+// int32 sum, so the trees of a point may be shared out over several lanes and need not be kept in step.
+// The lane walks the trees first, first + tstride, ...; its features are x[var * xstride].  Each of its
+// kQueueWays walks takes the lane's next tree as soon as it reaches a leaf; the loop runs for about
+// sum-of-depths / ways steps instead of (trees / ways) x the depth of the deepest tree.
+//
+// A walk without a tree sits on the forest's resting leaf (slot `ntrees`, value 0, forest.h): it "reaches a
+// leaf" at every step, adds 0 and stays -- no per-walk flags, the loop is bound by VALU issue.
+//
+// DEEP: the forest has blocks (slots >= ntop); nodes beyond the LDS are read one by one from global memory,
+// lanes whose node is in LDS send that load to node 0 (one line shared by all of them).  A walk goes 2
+// levels below the top part on average on config 5: too few to pay for the four loads of a whole block
+// (walk_deep in step for every lane: 2.46 ms against 1.56; top-part steps and deep steps taken apart: 7.1 ms,
+// 3.2 G instructions; deep loads issued by the lanes that need one only: 1.73 ms -- profiles/r02_notes.md).
+template <bool STATS, int kQueueWays, bool DEEP>
+__device__ __forceinline__ int forest_sum_any_order(const ForestDev &forest, const uint2 *lnodes, int nlds,
+                                                    const float *x, int xstride, int nvars, int first, int tstride,
+                                                    bool active, int &depth) {
+    const uint32_t last_lds = (uint32_t)(nlds - 1);
+    const uint32_t rest = (uint32_t)forest.ntrees;                  // the resting leaf
+    const uint32_t line0 = ((uint32_t)forest.ntop + 15u) & ~15u;   // DEEP: slot of the first pair of blocks
+    const uint32_t last_var = (uint32_t)nvars - 1u;
+    const int ntrees = active ? forest.ntrees : 0;
+    int sum = 0;
+    int next_tree = first + tstride * kQueueWays;      // per lane: its first kQueueWays trees are taken
+    uint32_t nd[kQueueWays];
+#pragma unroll
+    for (int k = 0; k < kQueueWays; ++k)               // level-major layout: the root of tree t is node t
+        nd[k] = first + tstride * k < ntrees ? (uint32_t)(first + tstride * k) : rest;
+    for (;;) {
+        uint2 node[kQueueWays];
+        fetch_nodes<kQueueWays>(forest, lnodes, last_lds, !DEEP, nd, node);
+        float val[kQueueWays];
+#pragma unroll
+        for (int k = 0; k < kQueueWays; ++k)           // a leaf (var = 255) reads the last feature and ignores it
+            val[k] = x[__umul24(min(node[k].y >> 24, last_var), (uint32_t)xstride)];
+        bool walking = false;
 #pragma unroll
         for (int k = 0; k < kQueueWays; ++k) {
-            const uint32_t next = (node[k].y & 0x00ffffffu) + (val[k] <= __uint_as_float(node[k].x) ? 0u : 1u);
-            if (STATS) depth += live[k] ? 1 : 0;
-            const bool done = live[k] & leaf[k];
-            sum += done ? (int)__uint_as_float(node[k].x) : 0;
-            const bool more = next_tree < ntrees;
-            // a finished walk takes the lane's next tree (its root is node next_tree) or parks on node 0
-            nd[k] = done ? (more ? (uint32_t)next_tree : 0u) : (live[k] ? next : 0u);
-            live[k] = done ? more : live[k];
-            next_tree += (done & more) ? tstride : 0;
-            any_live |= live[k];
+            const bool leaf = (node[k].y >> 24) == 255u;
+            const uint32_t child = node[k].y & 0x00ffffffu;
+            // right sibling: the next slot, except where the children start blocks of their own (the left one's
+            // at the head of a 16-slot line, forest.h) -- then 8 slots on
+            const uint32_t stride = (DEEP && ((child - line0) & 0x8000000fu) == 0u) ? 8u : 1u;
+            const uint32_t next = child + (val[k] <= __uint_as_float(node[k].x) ? 0u : stride);
+            if (STATS) depth += nd[k] != rest ? 1 : 0;
+            sum += leaf ? (int)__uint_as_float(node[k].x) : 0;
+            // a walk that has reached its leaf takes the lane's next tree (its root is node next_tree) or rests
+            nd[k] = leaf ? (next_tree < ntrees ? (uint32_t)next_tree : rest) : next;
+            next_tree += leaf ? tstride : 0;           // (runs on past ntrees while the lane rests: a few steps)
+            walking |= nd[k] != rest;
         }
-        if (!__any(any_live)) break;
+        if (!__any(walking)) break;
     }
     return sum;
 }
@@ -1291,7 +1406,7 @@ __global__ __launch_bounds__(1024) void forest_kernel(Batch b, int maxF, int nld
     extern __shared__ uint2 lnodes[];
     const ViewDev &a = b.view[blockIdx.y];
     const int lane = threadIdx.x & (kLanes - 1), wid = threadIdx.x / kLanes, nwaves = blockDim.x / kLanes;
-    const int nlds = min(nlds_cap, a.forest.nnodes);
+    const int nlds = min(nlds_cap, a.forest.ntop);        // the top part, or as much of it as fits
     for (int i = threadIdx.x; i < nlds; i += blockDim.x) lnodes[i] = a.forest.nodes[i];
     __syncthreads();
     float *H = reinterpret_cast<float *>(lnodes + nlds_cap) + (size_t)wid * maxF * kLanes;
@@ -1327,14 +1442,14 @@ __global__ __launch_bounds__(1024) void forest_kernel(Batch b, int maxF, int nld
         float score = NAN;
         if (w.scoreable) {
             int depth = 0;
-            // trees out of step only where it pays (more trees than ways) and is exact (integer leaves)
             float fsum;
-            if (a.forest.order_free && a.forest.ntrees > kTreeWays)
-                fsum = (float)forest_sum_any_order<STATS, kTreeWays>(a.forest, lnodes, nlds, H + lane, kLanes, 0, 1, true, depth);
-            else if (nlds >= a.forest.nnodes)
-                fsum = forest_sum<STATS, false>(a.forest, lnodes, nlds, H + lane, depth);
+            if (nlds < a.forest.nnodes)                      // blocks below the top part (or a top part beyond the LDS budget)
+                fsum = forest_sum_deep<STATS>(a.forest, lnodes, nlds, H + lane, depth);
+            // trees out of step only where it pays (more trees than ways) and is exact (integer leaves)
+            else if (a.forest.order_free && a.forest.ntrees > kTreeWays)
+                fsum = (float)forest_sum_any_order<STATS, kTreeWays, false>(a.forest, lnodes, nlds, H + lane, kLanes, F, 0, 1, true, depth);
             else
-                fsum = forest_sum<STATS, true>(a.forest, lnodes, nlds, H + lane, depth);
+                fsum = forest_sum<STATS>(a.forest, lnodes, nlds, H + lane, depth);
             score = 1 - (fsum / (a.forest.ntrees * 1.0f));                         // hpp:287
             if (STATS) {
                 atomicAdd(&a.stats->sum_depth, (unsigned long long)depth);
@@ -1368,7 +1483,7 @@ __global__ __launch_bounds__(1024) void forest_split_kernel(Batch b, int maxF, i
     const ViewDev &a = b.view[blockIdx.y];
     const int lane = threadIdx.x & (kLanes - 1), wid = threadIdx.x / kLanes, nwaves = blockDim.x / kLanes;
     const int ppw = kLanes / G, p = lane % ppw, g = lane / ppw;
-    const int nlds = min(nlds_cap, a.forest.nnodes);
+    const int nlds = min(nlds_cap, a.forest.ntop);        // the top part, or as much of it as fits
     for (int i = threadIdx.x; i < nlds; i += blockDim.x) lnodes[i] = a.forest.nodes[i];
     __syncthreads();
     float *H = reinterpret_cast<float *>(lnodes + nlds_cap) + (size_t)wid * maxF * ppw;
@@ -1389,7 +1504,9 @@ __global__ __launch_bounds__(1024) void forest_split_kernel(Batch b, int maxF, i
         }
         wave_lds_fence();
         int depth = 0;
-        int sum = forest_sum_any_order<STATS, kSplitWays>(a.forest, lnodes, nlds, H + p, ppw, g, G, scoreable, depth);
+        int sum = nlds < a.forest.nnodes
+                      ? forest_sum_any_order<STATS, kSplitWays, true>(a.forest, lnodes, nlds, H + p, ppw, F, g, G, scoreable, depth)
+                      : forest_sum_any_order<STATS, kSplitWays, false>(a.forest, lnodes, nlds, H + p, ppw, F, g, G, scoreable, depth);
         for (int off = ppw; off < kLanes; off <<= 1) {
             sum += __shfl_xor(sum, off);
             if (STATS) depth += __shfl_xor(depth, off);
@@ -2178,7 +2295,7 @@ void launch_forest_stage(const Batch &b, hipStream_t st) {
     bool stats = false, any_order = true;
     for (int v = 0; v < b.nviews; ++v) {
         maxF = b.view[v].f.F > maxF ? b.view[v].f.F : maxF;
-        max_nodes = b.view[v].forest.nnodes > max_nodes ? b.view[v].forest.nnodes : max_nodes;
+        max_nodes = b.view[v].forest.ntop > max_nodes ? b.view[v].forest.ntop : max_nodes;      // what is staged in LDS
         min_trees = b.view[v].forest.ntrees < min_trees ? b.view[v].forest.ntrees : min_trees;
         any_order &= b.view[v].forest.order_free != 0;
         stats |= b.view[v].stats != nullptr;

@@ -384,3 +384,32 @@ def test_fractional_leaf_values_are_summed_in_tree_order(kpl, oracle, cases, ntr
     assert cases.same_bits(scores, o_scores)
     assert np.array_equal(det.getKeypointsIndices(), o_kp)
     assert len(np.unique(o_scores[np.isfinite(o_scores)])) > 100
+
+
+@pytest.mark.parametrize("A,B,ntrees,nodes_per_tree,max_depth,walker", [
+    (5, 6, 10, 5000, 25, "forest_sum_deep: top part in LDS, then whole blocks, trees in step"),
+    (5, 6, 60, 1500, 20, "forest_sum_deep, more trees than ways"),
+    (5, 6, 3, 40000, 28, "forest_sum_deep, chains of blocks"),
+    (8, 10, 50, 100, 12, "forest_split_kernel, forest entirely in LDS: every lane's walks out of step"),
+    (8, 10, 64, 1200, 22, "forest_split_kernel with blocks: out of step, deep nodes one by one"),
+    (5, 6, 40, 150, 12, "forest_kernel, entirely in LDS, more trees than ways: out of step"),
+])
+def test_every_forest_walker(kpl, oracle, cases, A, B, ntrees, nodes_per_tree, max_depth, walker):
+    """Class-label forests (integer leaf values, what the reference trains) of the shapes that take the
+    different walks of kernels.hip: entirely in LDS or with 8-slot blocks below the top part (forest.h), one
+    lane or four lanes per point."""
+    from tools import synth
+    xyz, nrm = cases.cloud()
+    mr = cases.resolution()
+    r, rn = float(np.float32(6 * mr)), float(np.float32(4 * mr))
+    feat = oracle.Grid(xyz, r).features(nrm, A, B, r, np.arange(0, len(xyz), 5, dtype=np.int32))
+    fa = synth.random_forest(A * B, ntrees=ntrees, max_depth=max_depth, seed=17, target_nodes_per_tree=nodes_per_tree, feat=feat)
+    thr = float(np.float32(0.4))
+    det = make_det(kpl, A, B, r, rn, thr, fa)
+    det.setInputCloud(xyz)
+    det.setNormals(nrm)
+    _, scores = det.compute()
+    o_scores, o_kp = oracle.detect(xyz, nrm, A, B, r, rn, thr, cases.oracle_forest(fa))
+    assert cases.same_bits(scores, o_scores), walker
+    assert np.array_equal(det.getKeypointsIndices(), o_kp), walker
+    assert len(np.unique(o_scores[np.isfinite(o_scores)])) >= 3       # the walks do reach different leaves
