@@ -1115,7 +1115,7 @@ template <int WAYS>
 __device__ __forceinline__ void fetch_nodes(const ForestDev &forest, const uint2 *lnodes, uint32_t last_lds,
                                             bool all_in_lds, const uint32_t (&nd)[WAYS], uint2 (&node)[WAYS]) {
 #pragma unroll
-    for (int k = 0; k < WAYS; ++k) node[k] = lnodes[min(nd[k], last_lds)];
+    for (int k = 0; k < WAYS; ++k) node[k] = lnodes[all_in_lds ? nd[k] : min(nd[k], last_lds)];
     if (!all_in_lds) {      // nodes beyond the LDS: global memory, all ways issued before the first use
         bool far_any = false;
 #pragma unroll
@@ -1136,9 +1136,9 @@ __device__ __forceinline__ void fetch_nodes(const ForestDev &forest, const uint2
 // its leaf until the others end.
 template <bool STATS>
 __device__ __forceinline__ float forest_sum(const ForestDev &forest, const uint2 *lnodes, int nlds,
-                                            const float *x, int &depth) {
+                                            const float *x, int nvars, int &depth) {
     double sum = 0.0;
-    const uint32_t last_lds = (uint32_t)(nlds - 1);
+    const uint32_t last_lds = (uint32_t)(nlds - 1), last_var = (uint32_t)nvars - 1u;
     for (int t0 = 0; t0 < forest.ntrees; t0 += kTreeWays) {
         uint32_t nd[kTreeWays];
         uint2 node[kTreeWays];
@@ -1156,7 +1156,7 @@ __device__ __forceinline__ float forest_sum(const ForestDev &forest, const uint2
             for (int k = 0; k < kTreeWays; ++k) {
                 const uint32_t var = node[k].y >> 24;
                 leaf[k] = var == 255u;
-                val[k] = x[(leaf[k] ? 0u : var) * kLanes];
+                val[k] = x[min(var, last_var) * kLanes];        // a leaf reads the last feature and ignores it
             }
             bool all_done = true;
 #pragma unroll
@@ -1449,7 +1449,7 @@ __global__ __launch_bounds__(1024) void forest_kernel(Batch b, int maxF, int nld
             else if (a.forest.order_free && a.forest.ntrees > kTreeWays)
                 fsum = (float)forest_sum_any_order<STATS, kTreeWays, false>(a.forest, lnodes, nlds, H + lane, kLanes, F, 0, 1, true, depth);
             else
-                fsum = forest_sum<STATS>(a.forest, lnodes, nlds, H + lane, depth);
+                fsum = forest_sum<STATS>(a.forest, lnodes, nlds, H + lane, F, depth);
             score = 1 - (fsum / (a.forest.ntrees * 1.0f));                         // hpp:287
             if (STATS) {
                 atomicAdd(&a.stats->sum_depth, (unsigned long long)depth);
