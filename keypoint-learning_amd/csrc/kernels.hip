@@ -969,28 +969,22 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
                     if (slots_left) row_range(ky, kz, n0, n1);
                     continue;
                 }
-                // one word: up to kWordSteps steps, each on the ring entry requested kSearchRing steps earlier.
-                // The row can only end for every lane where a pair of steps ends; the ring is then out of step
-                // with t, but the next thing to happen is the switch to another row, which requests it afresh
+                // one word: up to kWordSteps steps, each on the ring entry requested kSearchRing steps earlier.  A
+                // pass over the ring is not left half way: with one order of requests on every path into the
+                // loop the compiler waits for exactly the entry it is about to use (a second exit made it wait
+                // for all of them at the top of every pass)
                 const int wbase = t;
                 unsigned w = 0u;
                 int steps = 0;
                 do {
-                    w = search_step(w, p, ring[0], f.r2);
-                    ring[0] = load_cand(pts, min(t + 4 * kStepW, t_max));
-                    w = search_step(w, p, ring[1], f.r2);
-                    ring[1] = load_cand(pts, min(t + 5 * kStepW, t_max));
-                    steps += 2;
-                    if (!__any(t + 2 * kStepW < t1)) {
-                        t += 2 * kStepW;
-                        break;
+#pragma unroll
+                    for (int s = 0; s < kSearchRing; ++s) {
+                        w = search_step(w, p, ring[s], f.r2);
+                        ring[s] = load_cand(pts, min(t + (kSearchRing + s) * kStepW, t_max));
+                        __builtin_amdgcn_sched_barrier(0);      // the request leaves now, not at the end of the pass
                     }
-                    w = search_step(w, p, ring[2], f.r2);
-                    ring[2] = load_cand(pts, min(t + 6 * kStepW, t_max));
-                    w = search_step(w, p, ring[3], f.r2);
-                    ring[3] = load_cand(pts, min(t + 7 * kStepW, t_max));
-                    steps += 2;
-                    t += 4 * kStepW;
+                    steps += kSearchRing;
+                    t += kSearchRing * kStepW;
                 } while (steps < kWordSteps && __any(t < t1));
                 w <<= (32 - kStepW * steps) & 31;                            // first candidate -> bit 31
                 full = __any(list_word(w, wbase, t1, kf, first_pending, ent, ecnt, tid) == ecap);
