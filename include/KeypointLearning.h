@@ -176,20 +176,27 @@ protected:
             return false;
         }
         if (!normals_) {                                                     // hpp:125-148
-            if (this->surface_->isOrganized()) {
-                PCL_ERROR("[pcl::%s::initCompute] organized cloud without normals: IntegralImageNormalEstimation is not provided, call setNormals\n", this->name_.c_str());
-                return false;
-            }
             std::cout << "Computing normals for KPL" << std::endl;
             PointCloudNPtr normals(new PointCloudN());
             const int n = (int)this->surface_->points.size();
             normals->points.resize((size_t)n);
-            normals->width = (uint32_t)n;
-            normals->height = 1;
-            int rc = kpl_estimate_normals(handle_, n ? &this->surface_->points[0].x : nullptr, sizeof(PointInT), n, 0,
+            normals->width = this->surface_->width;
+            normals->height = this->surface_->height;
+            int rc;
+            if (!this->surface_->isOrganized()) {                            // hpp:129-136: pcl::NormalEstimation, radius search
+                normals->width = (uint32_t)n;
+                normals->height = 1;
+                rc = kpl_estimate_normals(handle_, n ? &this->surface_->points[0].x : nullptr, sizeof(PointInT), n, 0,
                                           this->search_radius_, nullptr,
                                           n ? &normals->points[0].normal_x : nullptr, sizeof(NormalT),
                                           n ? &normals->points[0].curvature : nullptr, sizeof(NormalT));
+            } else {                                                         // hpp:138-145: IntegralImageNormalEstimation,
+                                                                             // SIMPLE_3D_GRADIENT, smoothing size 5.0
+                rc = kpl_estimate_normals_organized(handle_, n ? &this->surface_->points[0].x : nullptr, sizeof(PointInT),
+                                                    (int)this->surface_->width, (int)this->surface_->height, 5.0f, nullptr,
+                                                    n ? &normals->points[0].normal_x : nullptr, sizeof(NormalT),
+                                                    n ? &normals->points[0].curvature : nullptr, sizeof(NormalT));
+            }
             if (rc != KPL_OK) return report("initCompute", rc);
             normals_ = normals;
         }

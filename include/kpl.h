@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define KPL_VERSION 110
+#define KPL_VERSION 120
 
 typedef enum kpl_status {
     KPL_OK = 0,
@@ -227,6 +227,23 @@ int kpl_estimate_normals(kpl_detector *h, const void *xyz, size_t xyz_stride, in
 int kpl_estimate_normals_device(kpl_detector *h, int k_search, double radius_search,
                                 const float *viewpoint, void *d_normals, size_t normals_stride,
                                 void *d_curvature, size_t curvature_stride, void *stream);
+
+/* Normals of an ORGANIZED cloud (width x height, row-major) as the detector's own fallback computes them
+ * when the caller gave none: include/impl/KeypointLearning.hpp:138-145 = pcl::IntegralImageNormalEstimation,
+ * setNormalEstimationMethod(SIMPLE_3D_GRADIENT), setNormalSmoothingSize(5.0) (pass 5.0f), border policy
+ * IGNORE, smoothing independent of depth, viewpoint = the cloud's sensor origin (null = (0, 0, 0)).
+ * Pixels PCL leaves without a normal (the border of (int)smoothing pixels, non-finite depth, closer than
+ * 2 pixels to a depth discontinuity, degenerate gradient) get NaN normals; curvature is NaN everywhere
+ * (this method computes none).  PCL 1.8.0 is not part of the reference checkout: restated from its
+ * published source, every float in PCL's order ("parity unpinned"). */
+int kpl_estimate_normals_organized(kpl_detector *h, const void *xyz, size_t xyz_stride, int width, int height,
+                                   float normal_smoothing_size, const float *viewpoint, void *normals_out,
+                                   size_t normals_stride, void *curvature_out, size_t curvature_stride);
+/* the same on device buffers, asynchronous on `stream` */
+int kpl_estimate_normals_organized_device(kpl_detector *h, const void *d_xyz, size_t xyz_stride, int width,
+                                          int height, float normal_smoothing_size, const float *viewpoint,
+                                          void *d_normals, size_t normals_stride, void *d_curvature,
+                                          size_t curvature_stride, void *stream);
 
 #ifdef __cplusplus
 }

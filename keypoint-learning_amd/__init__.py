@@ -88,6 +88,10 @@ SYMBOLS = {
     "kpl_estimate_normals": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, C.c_int, C.c_double, _vp, _vp, C.c_size_t,
                                        _vp, C.c_size_t]),
     "kpl_estimate_normals_device": (C.c_int, [_vp, C.c_int, C.c_double, _vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp]),
+    "kpl_estimate_normals_organized": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, C.c_int, C.c_float, _vp, _vp, C.c_size_t,
+                                                 _vp, C.c_size_t]),
+    "kpl_estimate_normals_organized_device": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, C.c_int, C.c_float, _vp, _vp,
+                                                        C.c_size_t, _vp, C.c_size_t, _vp]),
 }
 
 _lib = None
@@ -342,6 +346,19 @@ class KeypointLearningDetector:
         out = np.empty((max(n, 1), 4), dtype=np.float32)
         self._check(self._lib.kpl_estimate_normals(self._h, xyz.ctypes.data, xs, n, int(k), float(radius), vp.ctypes.data,
                                                    out.ctypes.data, 16, out.ctypes.data + 12, 16))
+        return out[:n, :3].copy(), out[:n, 3].copy()
+
+    def estimateNormalsOrganized(self, cloud, width, height, smoothing_size=5.0, viewpoint=(0.0, 0.0, 0.0)):
+        """pcl::IntegralImageNormalEstimation (SIMPLE_3D_GRADIENT) as the detector's fallback drives it on an
+        organized cloud (hpp:138-145).  Returns (normals[n,3], curvature[n]); NaN where PCL leaves NaN."""
+        xyz, xs = self._rows(cloud)
+        n = int(width) * int(height)
+        assert xyz.shape[0] == n
+        vp = np.ascontiguousarray(viewpoint, dtype=np.float32)
+        out = np.empty((max(n, 1), 4), dtype=np.float32)
+        self._check(self._lib.kpl_estimate_normals_organized(self._h, xyz.ctypes.data, xs, int(width), int(height),
+                                                             float(smoothing_size), vp.ctypes.data, out.ctypes.data, 16,
+                                                             out.ctypes.data + 12, 16))
         return out[:n, :3].copy(), out[:n, 3].copy()
 
     def estimateNormalsDevice(self, k, radius, viewpoint, d_normals, normals_stride, d_curvature=None,

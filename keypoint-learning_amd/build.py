@@ -11,8 +11,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libkpl.so")
-SOURCES = ["kernels.hip", "api.cpp", "forest.cpp"]
-HEADERS = ["kernels.h", "forest.h", os.path.join("..", "..", "include", "kpl.h")]
+SOURCES = ["kernels.hip", "organized_normals.hip", "api.cpp", "forest.cpp"]
+HEADERS = ["kernels.h", "organized_normals.h", "forest.h", os.path.join("..", "..", "include", "kpl.h")]
 TOOLS = {"TestDetector": ["test_detector_main.cpp"], "DetectViews": ["batch_views_main.cpp"]}
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

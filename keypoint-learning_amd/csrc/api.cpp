@@ -18,6 +18,7 @@
 
 #include "forest.h"
 #include "kernels.h"
+#include "organized_normals.h"
 
 using namespace kpl;
 
@@ -72,6 +73,7 @@ struct kpl_detector {
     DevBuf dstate, cid, btable, cell_start, tmp_idx, scan_tmp, pts, nrm, pos_of;
     DevBuf score_sorted, flags, prefix, stats, out_scores, out_kp, out_count, cand_list, cand_count;
     DevBuf draw_list, draw_count, skip, feat;
+    DevBuf org_scratch;           // kpl_estimate_normals_organized: change map, distance map, integral image
     int cells_cap = 0;            // capacity (cells) of cell_start
     DevState *h_state = nullptr;  // pinned copy of the device state (status read-back)
     int *h_count = nullptr;       // pinned
@@ -618,7 +620,7 @@ int kpl_create(kpl_detector **out, int device) {
 void kpl_destroy(kpl_detector *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    DevBuf *bufs[] = {&h->d_nodes, &h->d_roots, &h->stage_xyz, &h->stage_nrm, &h->stage_idx, &h->stage_feat,
+    DevBuf *bufs[] = {&h->org_scratch, &h->d_nodes, &h->d_roots, &h->stage_xyz, &h->stage_nrm, &h->stage_idx, &h->stage_feat,
                       &h->dstate, &h->cid, &h->btable, &h->cell_start, &h->tmp_idx, &h->scan_tmp,
                       &h->pts, &h->nrm, &h->pos_of, &h->score_sorted, &h->flags, &h->prefix, &h->stats,
                       &h->out_scores, &h->out_kp, &h->out_count, &h->cand_list, &h->cand_count,
@@ -977,6 +979,78 @@ int kpl_estimate_normals(kpl_detector *h, const void *xyz, size_t xyz_stride, in
     for (int i = 0; i < n; ++i) {
         memcpy((char *)normals_out + (size_t)i * normals_stride, &tmp[4 * (size_t)i], 12);
         if (curvature_out) memcpy((char *)curvature_out + (size_t)i * curvature_stride, &tmp[4 * (size_t)i + 3], 4);
+    }
+    return KPL_OK;
+}
+
+// pcl::IntegralImageNormalEstimation (SIMPLE_3D_GRADIENT) on an organized cloud in device memory
+static int organized_normals_on_device(kpl_detector *h, const void *d_xyz, size_t xs, int width, int height,
+                                       float smoothing, const float *viewpoint, void *d_normals, size_t ns, void *d_curv,
+                                       size_t cs, hipStream_t st) {
+    if (width < 0 || height < 0 || (long long)width * (long long)height > (1ll << 28))
+        return fail(h, KPL_ERR_INVALID_ARG, "width x height must be in 0 .. 2^28");
+    if ((long long)width * height > 0 && (!d_xyz || !d_normals)) return fail(h, KPL_ERR_INVALID_ARG, "null cloud or normals buffer");
+    if (xs < 12 || ns < 12 || (xs & 3) || (ns & 3) || (d_curv && (cs < 4 || (cs & 3))))
+        return fail(h, KPL_ERR_INVALID_ARG, "strides must be multiples of 4 (points and normals >= 12 bytes)");
+    if (!(smoothing >= 0.0f) || !(smoothing < 1.0e6f)) return fail(h, KPL_ERR_INVALID_ARG, "normal smoothing size must be in [0, 1e6)");
+    if (width == 0 || height == 0) return KPL_OK;
+    KPL_HIP(h, h->org_scratch.ensure(organized_normals_scratch_bytes(width, height)));
+    OrganizedView v{};
+    v.xyz = (const char *)d_xyz;
+    v.xs = xs;
+    v.W = width;
+    v.H = height;
+    v.smoothing = smoothing;
+    for (int k = 0; k < 3; ++k) v.vp[k] = viewpoint ? viewpoint[k] : 0.0f;
+    v.normals = (char *)d_normals;
+    v.ns = ns;
+    v.curvature = (char *)d_curv;
+    v.cs = cs;
+    launch_organized_normals(v, h->org_scratch.p, st);
+    KPL_HIP(h, hipGetLastError());
+    return KPL_OK;
+}
+
+int kpl_estimate_normals_organized_device(kpl_detector *h, const void *d_xyz, size_t xyz_stride, int width, int height,
+                                          float normal_smoothing_size, const float *viewpoint, void *d_normals,
+                                          size_t normals_stride, void *d_curvature, size_t curvature_stride, void *stream) {
+    if (!h) return KPL_ERR_INVALID_ARG;
+    int rc = use_device(h);
+    if (rc) return rc;
+    return organized_normals_on_device(h, d_xyz, xyz_stride, width, height, normal_smoothing_size, viewpoint, d_normals,
+                                       normals_stride, d_curvature, curvature_stride, (hipStream_t)stream);
+}
+
+int kpl_estimate_normals_organized(kpl_detector *h, const void *xyz, size_t xyz_stride, int width, int height,
+                                   float normal_smoothing_size, const float *viewpoint, void *normals_out,
+                                   size_t normals_stride, void *curvature_out, size_t curvature_stride) {
+    if (!h) return KPL_ERR_INVALID_ARG;
+    if (width < 0 || height < 0 || (long long)width * (long long)height > (1ll << 28))
+        return fail(h, KPL_ERR_INVALID_ARG, "width x height must be in 0 .. 2^28");
+    const int n = width * height;
+    if (n > 0 && (!xyz || !normals_out)) return fail(h, KPL_ERR_INVALID_ARG, "null cloud or normals buffer");
+    if (xyz_stride < 12 || (xyz_stride & 3) || normals_stride < 12 || (normals_stride & 3) ||
+        (curvature_out && (curvature_stride < 4 || (curvature_stride & 3))))
+        return fail(h, KPL_ERR_INVALID_ARG, "strides must be multiples of 4 (points and normals >= 12 bytes)");
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (n == 0) return KPL_OK;
+    const size_t nn = (size_t)n;
+    KPL_HIP(h, h->stage_xyz.ensure(nn * xyz_stride));
+    KPL_HIP(h, h->stage_feat.ensure(sizeof(float) * 4 * nn));       // (nx, ny, nz, curvature) per pixel
+    hipStream_t st = h->stream;
+    KPL_HIP(h, hipMemcpyAsync(h->stage_xyz.p, xyz, (nn - 1) * xyz_stride + 12, hipMemcpyHostToDevice, st));
+    h->bound = false;                       // the staging buffer of a bound host view was just overwritten
+    h->index_valid = false;
+    rc = organized_normals_on_device(h, h->stage_xyz.p, xyz_stride, width, height, normal_smoothing_size, viewpoint,
+                                     h->stage_feat.p, 16, (char *)h->stage_feat.p + 12, 16, st);
+    if (rc) return rc;
+    std::vector<float> tmp(4 * nn);
+    KPL_HIP(h, hipMemcpyAsync(tmp.data(), h->stage_feat.p, sizeof(float) * 4 * nn, hipMemcpyDeviceToHost, st));
+    KPL_HIP(h, hipStreamSynchronize(st));
+    for (size_t i = 0; i < nn; ++i) {
+        memcpy((char *)normals_out + i * normals_stride, &tmp[4 * i], 12);
+        if (curvature_out) memcpy((char *)curvature_out + i * curvature_stride, &tmp[4 * i + 3], 4);
     }
     return KPL_OK;
 }

@@ -56,7 +56,7 @@ inline bool load_pcd(const std::string &path, pcl::PointCloud<PointInT> &cloud, 
     std::vector<std::string> fields;
     std::vector<int> sizes, counts;
     std::vector<char> types;
-    size_t npoints = 0;
+    size_t npoints = 0, width = 0, height = 0;
     std::string data_kind, line;
     while (std::getline(f, line)) {
         if (!line.empty() && line.back() == '\r') line.pop_back();
@@ -67,6 +67,8 @@ inline bool load_pcd(const std::string &path, pcl::PointCloud<PointInT> &cloud, 
         else if (key == "SIZE") { int s; while (ls >> s) sizes.push_back(s); }
         else if (key == "TYPE") { char c; while (ls >> c) types.push_back(c); }
         else if (key == "COUNT") { int c; while (ls >> c) counts.push_back(c); }
+        else if (key == "WIDTH") ls >> width;
+        else if (key == "HEIGHT") ls >> height;
         else if (key == "POINTS") ls >> npoints;
         else if (key == "DATA") { ls >> data_kind; break; }
     }
@@ -131,6 +133,10 @@ inline bool load_pcd(const std::string &path, pcl::PointCloud<PointInT> &cloud, 
     }
     cloud.is_dense = true;
     for (auto &p : cloud.points) if (!pcl::isFinite(p)) cloud.is_dense = false;
+    if (height > 1 && width * height == npoints) {      // an organized cloud keeps its image shape, as with pcl::PCDReader
+        cloud.width = (uint32_t)width;
+        cloud.height = (uint32_t)height;
+    }
     return true;
 }
 

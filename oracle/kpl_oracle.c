@@ -740,3 +740,138 @@ void kplo_estimate_normals(const float *xyz, int n, int k, double radius, const 
     free(best);
     kplo_grid_free(g);
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * pcl::IntegralImageNormalEstimation as the detector's fallback drives it on an ORGANIZED cloud
+ * (include/impl/KeypointLearning.hpp:138-145): setNormalEstimationMethod(SIMPLE_3D_GRADIENT),
+ * setInputCloud, setNormalSmoothingSize(5.0), compute().  The algorithm lives in PCL 1.8.0
+ * (README.md:66), absent from /root/reference: features/include/pcl/features/impl/
+ * integral_image_normal.hpp (computeFeature, computeFeatureFull with BORDER_POLICY_IGNORE and
+ * depth-independent smoothing, computePointNormal's SIMPLE_3D_GRADIENT branch) and
+ * integral_image2D.hpp (first-order integral image, double sums).  Restated here from the
+ * published source, loop by loop, "parity unpinned":
+ *   1. depth-change map: a pixel and its right / lower neighbor are marked where their depths differ
+ *      by more than max_depth_change_factor (20.0f * 0.001f) * (|z| + 1) * 2 or either is not finite
+ *   2. distance map: 0 on marked pixels, width + height elsewhere, then the two chamfer passes
+ *      (1.0 straight, 1.4 diagonal) with PCL's loop bounds -- the first pass runs ci up to
+ *      width - 1 and reads previous_row[ci + 1], i.e. the first pixel of the current row at the
+ *      right edge; the second reads next_row[ci - 1] at ci = 0.  Neither reaches a pixel that is
+ *      kept: the 5-pixel border is set to NaN and values >= 5 are clipped to 5
+ *   3. first-order integral image of (x, y, z) in double, points whose x + y + z (float) is not
+ *      finite counted as zero: cur[c + 1] = prev[c + 1] + cur[c] - prev[c] (+ point)
+ *   4. per kept pixel with finite z: s = min(distance, 5); s > 2 -> rectangle (int)s x (int)s:
+ *      gx = column sum at x + w/2 minus column sum at x - w/2, gy = row sum at y + h/2 minus row sum
+ *      at y - h/2 (both from y - h/2 resp. x - w/2), n = gy x gx normalised in double, cast to float,
+ *      flipped towards the viewpoint (sensor origin = 0 unless given); curvature = NaN.
+ * Eigen detail that cannot be pinned: n /= sqrt(len) is a true division here (Eigen 3.3; 3.2
+ * multiplies by the reciprocal) -- at most one ulp of the double before the cast to float.
+ * ------------------------------------------------------------------------------------------- */
+static void ii_sum(const double *ii, int W, int sx, int sy, int w, int h, double out[3])
+{
+    const size_t ul = (size_t)sy * (size_t)(W + 1) + (size_t)sx, ur = ul + (size_t)w;
+    const size_t ll = (size_t)(sy + h) * (size_t)(W + 1) + (size_t)sx, lr = ll + (size_t)w;
+    for (int a = 0; a < 3; ++a) out[a] = ((ii[3 * lr + a] + ii[3 * ul + a]) - ii[3 * ur + a]) - ii[3 * ll + a];
+}
+
+void kplo_integral_image_normals(const float *xyz, int width, int height, float smoothing_size,
+                                 const float *viewpoint, float *normals_out, float *curvature_out)
+{
+    const int W = width, H = height;
+    const size_t n = (size_t)(W > 0 ? W : 0) * (size_t)(H > 0 ? H : 0);
+    const float bad = NAN;
+    for (size_t i = 0; i < n; ++i) {
+        normals_out[3 * i] = normals_out[3 * i + 1] = normals_out[3 * i + 2] = bad;
+        if (curvature_out) curvature_out[i] = bad;
+    }
+    const int border = (int)smoothing_size;
+    if (n == 0 || border < 0 || W <= 2 * border || H <= 2 * border) return;
+    const float vp[3] = {viewpoint ? viewpoint[0] : 0.0f, viewpoint ? viewpoint[1] : 0.0f, viewpoint ? viewpoint[2] : 0.0f};
+    /* 1. depth-change map */
+    unsigned char *change = (unsigned char *)malloc(n);
+    memset(change, 255, n);
+    const float factor = 20.0f * 0.001f;
+    for (int ri = 0; ri < H - 1; ++ri)
+        for (int ci = 0; ci < W - 1; ++ci) {
+            const size_t index = (size_t)ri * (size_t)W + (size_t)ci;
+            const float depth = xyz[3 * index + 2], depthR = xyz[3 * (index + 1) + 2], depthD = xyz[3 * (index + (size_t)W) + 2];
+            const float limit = (factor * (fabsf(depth) + 1.0f) * 2.0f);
+            if (fabs(depth - depthR) > limit || !isfinite(depth) || !isfinite(depthR)) {
+                change[index] = 0;
+                change[index + 1] = 0;
+            }
+            if (fabs(depth - depthD) > limit || !isfinite(depth) || !isfinite(depthD)) {
+                change[index] = 0;
+                change[index + (size_t)W] = 0;
+            }
+        }
+    /* 2. distance map */
+    float *dist = (float *)malloc(sizeof(float) * n);
+    for (size_t i = 0; i < n; ++i) dist[i] = change[i] == 0 ? 0.0f : (float)(W + H);
+    for (int ri = 1; ri < H; ++ri) {
+        const float *previous_row = dist + (size_t)(ri - 1) * (size_t)W;
+        float *current_row = dist + (size_t)ri * (size_t)W;
+        for (int ci = 1; ci < W; ++ci) {
+            /* previous_row[W] at ci = W - 1 is the first pixel of the current row (rows are contiguous) */
+            const float upLeft = previous_row[ci - 1] + 1.4f, up = previous_row[ci] + 1.0f, upRight = previous_row[ci + 1] + 1.4f;
+            const float left = current_row[ci - 1] + 1.0f, center = current_row[ci];
+            const float a = upLeft < up ? upLeft : up, b2 = left < upRight ? left : upRight;   /* std::min(std::min(upLeft, up), std::min(left, upRight)) */
+            const float minValue = a < b2 ? a : b2;
+            if (minValue < center) current_row[ci] = minValue;
+        }
+    }
+    for (int ri = H - 2; ri >= 0; --ri) {
+        const float *next_row = dist + (size_t)(ri + 1) * (size_t)W;
+        float *current_row = dist + (size_t)ri * (size_t)W;
+        for (int ci = W - 2; ci >= 0; --ci) {
+            /* next_row[-1] at ci = 0 is the last pixel of the current row (rows are contiguous) */
+            const float lowerLeft = next_row[ci - 1] + 1.4f, lower = next_row[ci] + 1.0f, lowerRight = next_row[ci + 1] + 1.4f;
+            const float right = current_row[ci + 1] + 1.0f, center = current_row[ci];
+            const float a = lowerLeft < lower ? lowerLeft : lower, b2 = right < lowerRight ? right : lowerRight;
+            const float minValue = a < b2 ? a : b2;
+            if (minValue < center) current_row[ci] = minValue;
+        }
+    }
+    /* 3. integral image (width + 1) x (height + 1), 3 doubles per element */
+    double *ii = (double *)calloc((size_t)(W + 1) * (size_t)(H + 1) * 3, sizeof(double));
+    for (int r = 0; r < H; ++r) {
+        const double *prev = ii + 3 * (size_t)r * (size_t)(W + 1);
+        double *cur = ii + 3 * (size_t)(r + 1) * (size_t)(W + 1);
+        for (int c = 0; c < W; ++c) {
+            const float *e = xyz + 3 * ((size_t)r * (size_t)W + (size_t)c);
+            for (int a = 0; a < 3; ++a) cur[3 * (c + 1) + a] = (prev[3 * (c + 1) + a] + cur[3 * c + a]) - prev[3 * c + a];
+            const float s = (e[0] + e[1]) + e[2];
+            if (isfinite(s))
+                for (int a = 0; a < 3; ++a) cur[3 * (c + 1) + a] += (double)e[a];
+        }
+    }
+    /* 4. normals of the pixels inside the border */
+    for (int ri = border; ri < H - border; ++ri)
+        for (int ci = border; ci < W - border; ++ci) {
+            const size_t index = (size_t)ri * (size_t)W + (size_t)ci;
+            const float *pt = xyz + 3 * index;
+            if (!isfinite(pt[2])) continue;
+            const float smoothing = dist[index] < smoothing_size ? dist[index] : smoothing_size;
+            if (!(smoothing > 2.0f)) continue;
+            const int rw = (int)smoothing, rh = (int)smoothing, rw2 = rw / 2, rh2 = rh / 2;
+            double s1[3], s0[3], gx[3], gy[3];
+            ii_sum(ii, W, ci + rw2, ri - rh2, 1, rh, s1);
+            ii_sum(ii, W, ci - rw2, ri - rh2, 1, rh, s0);
+            for (int a = 0; a < 3; ++a) gx[a] = s1[a] - s0[a];
+            ii_sum(ii, W, ci - rw2, ri + rh2, rw, 1, s1);
+            ii_sum(ii, W, ci - rw2, ri - rh2, rw, 1, s0);
+            for (int a = 0; a < 3; ++a) gy[a] = s1[a] - s0[a];
+            double nv[3] = {gy[1] * gx[2] - gy[2] * gx[1], gy[2] * gx[0] - gy[0] * gx[2], gy[0] * gx[1] - gy[1] * gx[0]};
+            const double len = (nv[0] * nv[0] + nv[1] * nv[1]) + nv[2] * nv[2];
+            if (len == 0.0) continue;
+            const double root = sqrt(len);
+            float nx = (float)(nv[0] / root), ny = (float)(nv[1] / root), nz = (float)(nv[2] / root);
+            /* pcl::flipNormalTowardsViewpoint (float overload) */
+            const float vx = vp[0] - pt[0], vy = vp[1] - pt[1], vz = vp[2] - pt[2];
+            const float cos_theta = (vx * nx + vy * ny + vz * nz);
+            if (cos_theta < 0) { nx *= -1; ny *= -1; nz *= -1; }
+            normals_out[3 * index] = nx; normals_out[3 * index + 1] = ny; normals_out[3 * index + 2] = nz;
+        }
+    free(ii);
+    free(dist);
+    free(change);
+}

@@ -100,6 +100,13 @@ double kplo_cloud_resolution(const float *xyz, int n);
 void kplo_estimate_normals(const float *xyz, int n, int k, double radius, const float *viewpoint,
                            float *normals_out, float *curvature_out);
 
+/* pcl::IntegralImageNormalEstimation (SIMPLE_3D_GRADIENT, BORDER_POLICY_IGNORE, smoothing independent
+ * of depth) restated: what include/impl/KeypointLearning.hpp:138-145 computes for an organized cloud
+ * without normals.  xyz[3 * width * height] row-major; normals_out[3 n] (NaN where PCL leaves NaN),
+ * curvature_out[n] (all NaN, may be NULL).  "parity unpinned" (PCL absent). */
+void kplo_integral_image_normals(const float *xyz, int width, int height, float smoothing_size,
+                                 const float *viewpoint, float *normals_out, float *curvature_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,6 +77,8 @@ def lib():
     L.kplo_cloud_resolution.restype = C.c_double
     L.kplo_estimate_normals.argtypes = [fp, C.c_int, C.c_int, C.c_double, fp, fp, fp]
     L.kplo_estimate_normals.restype = None
+    L.kplo_integral_image_normals.argtypes = [fp, C.c_int, C.c_int, C.c_float, fp, fp, fp]
+    L.kplo_integral_image_normals.restype = None
     _lib = L
     return L
 
@@ -259,4 +261,18 @@ def estimate_normals(xyz, k=10, radius=0.0, viewpoint=(0.0, 0.0, 0.0)):
     cv = np.empty(max(n, 1), dtype=np.float32)
     lib().kplo_estimate_normals(_p(xyz, C.c_float), n, int(k), float(radius), _p(vp, C.c_float),
                                 _p(nrm, C.c_float), _p(cv, C.c_float))
+    return nrm[:n], cv[:n]
+
+
+def integral_image_normals(xyz, width, height, smoothing_size=5.0, viewpoint=(0.0, 0.0, 0.0)):
+    """pcl::IntegralImageNormalEstimation (SIMPLE_3D_GRADIENT, smoothing size as set by the detector's fallback)
+    restated for an organized cloud xyz[height * width, 3] (row-major).  Returns (normals[n,3], curvature[n])."""
+    xyz = _f32(xyz).reshape(-1, 3)
+    n = int(width) * int(height)
+    assert xyz.shape[0] == n
+    vp = _f32(np.asarray(viewpoint, dtype=np.float32))
+    nrm = np.empty((max(n, 1), 3), dtype=np.float32)
+    cv = np.empty(max(n, 1), dtype=np.float32)
+    lib().kplo_integral_image_normals(_p(xyz, C.c_float), int(width), int(height), float(smoothing_size), _p(vp, C.c_float),
+                                      _p(nrm, C.c_float), _p(cv, C.c_float))
     return nrm[:n], cv[:n]

@@ -258,3 +258,40 @@ def test_cli_errors():
     assert res.returncode != 0 and "impossible to load random forest" in res.stderr
     res = subprocess.run([EXE, "--subSampling"], capture_output=True, text=True)
     assert "Subsampling needs leaf." in res.stdout
+
+
+def test_cli_organized_cloud_without_normals(tmp_path):
+    """An ORGANIZED .pcd (WIDTH x HEIGHT, NaN holes) and no setNormals: the detector's fallback is
+    pcl::IntegralImageNormalEstimation, SIMPLE_3D_GRADIENT, smoothing size 5 (hpp:138-145) -- here
+    kpl_estimate_normals_organized.  The whole run equals the oracle pipeline on the same file."""
+    from oracle import kplo
+    from tests import helpers
+    from tests.test_oracle_organized_normals import depth_image
+    from tools import forest_yaml
+    W, H = 96, 72
+    xyz = depth_image(W, H, seed=5, step=50, holes=12, bumps=0.12, period=5.0)
+    pcd, out = tmp_path / "org.pcd", tmp_path / "kp.pcd"
+    write_pcd(pcd, xyz, None, True)
+    hdr = open(pcd, "rb").read().replace(b"WIDTH %d\nHEIGHT 1\n" % (W * H), b"WIDTH %d\nHEIGHT %d\n" % (W, H))
+    open(pcd, "wb").write(hdr)
+    mr = kplo.cloud_resolution(xyz)
+    r, rn = float(np.float32(6 * mr)), float(np.float32(4 * mr))
+    nrm, _ = kplo.integral_image_normals(xyz, W, H, 5.0)
+    assert 0 < np.isnan(nrm[:, 0]).sum() < len(xyz)
+    # a forest whose thresholds come from this cloud's own features, so that the responses differ
+    from tools import synth
+    ok = np.flatnonzero(np.isfinite(nrm[:, 0]))[::7].astype(np.int32)
+    feat = kplo.Grid(xyz, r).features(nrm, 5, 6, r, ok)
+    forest = str(tmp_path / "forest.yaml.gz")
+    forest_yaml.save_forest(synth.random_forest(30, ntrees=12, max_depth=9, seed=23, target_nodes_per_tree=120, feat=feat), forest)
+    cmd = [EXE, "--pathCloud", str(pcd), "--pathRF", forest, "--radiusFeatures", "6", "--pathKP=%s" % out,
+           "--radiusNMS", "4", "--radiusInMr", "--annuli", "5", "--bins", "6", "-t", "0.3", "--json", "--detectorNormals"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr + res.stdout
+    assert "Computing normals for KPL" in res.stdout
+    info = json.loads(res.stdout.strip().splitlines()[-1])
+    fa = forest_yaml.load_forest(forest)
+    o_sc, o_kp = kplo.detect(xyz, nrm, 5, 6, r, rn, float(np.float32(0.3)), helpers.oracle_forest(fa))
+    kp = np.loadtxt(out, skiprows=11, dtype=np.float32).reshape(-1, 4)
+    assert info["points"] == len(xyz) and info["keypoints"] == len(o_kp) > 0
+    assert np.array_equal(kp[:, :3], xyz[o_kp]) and np.array_equal(kp[:, 3], o_sc[o_kp])

@@ -100,3 +100,48 @@ def test_committed_fixture(kpl):
     nk, ck = det.estimateNormals(c["xyz"], k=int(z["k"]), viewpoint=z["viewpoint"])
     nr, cr = det.estimateNormals(c["xyz"], k=0, radius=float(z["radius"]), viewpoint=z["viewpoint"])
     assert same(nk, z["nrm_k"]) and same(ck, z["curv_k"]) and same(nr, z["nrm_r"]) and same(cr, z["curv_r"])
+
+
+def same_nan(a, b):
+    a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+    return a.shape == b.shape and np.array_equal(np.isnan(a), np.isnan(b)) and \
+        np.array_equal(a.view(np.uint32)[~np.isnan(a)], b.view(np.uint32)[~np.isnan(b)])
+
+
+@pytest.mark.parametrize("W,H,step,holes,smoothing,vp", [
+    (64, 48, None, 0, 5.0, (0.0, 0.0, 0.0)),
+    (160, 120, 77, 25, 5.0, (0.0, 0.0, 0.0)),
+    (333, 77, 40, 60, 5.0, (1.0, -2.0, 9.0)),
+    (40, 1100, 13, 80, 5.0, (0.0, 0.0, 0.0)),          # more rows than one band of the skewed recurrences
+    (90, 70, 31, 10, 10.0, (0.0, 0.0, 0.0)),           # PCL's default smoothing size
+    (50, 40, 20, 5, 3.5, (0.0, 0.0, 0.0)),
+    (640, 480, 300, 400, 5.0, (0.0, 0.0, 0.0)),        # a Kinect frame
+])
+def test_organized_normals_bit_exact(kpl, oracle, W, H, step, holes, smoothing, vp):
+    """kpl_estimate_normals_organized (pcl::IntegralImageNormalEstimation, SIMPLE_3D_GRADIENT: the detector's
+    fallback on an organized cloud, hpp:138-145) against the oracle's loop-by-loop restatement."""
+    from tests.test_oracle_organized_normals import depth_image
+    xyz = depth_image(W, H, seed=W + H, step=step, holes=holes)
+    det = kpl.KeypointLearningDetector()
+    nrm, curv = det.estimateNormalsOrganized(xyz, W, H, smoothing, vp)
+    o_nrm, o_curv = oracle.integral_image_normals(xyz, W, H, smoothing, vp)
+    assert same_nan(nrm, o_nrm)
+    assert np.isnan(curv).all() and np.isnan(o_curv).all()
+    assert np.isfinite(o_nrm[:, 0]).sum() > (W - 2 * int(smoothing)) * (H - 2 * int(smoothing)) // 2
+
+
+def test_organized_normals_strides_and_degenerate_shapes(kpl, oracle):
+    from tests.test_oracle_organized_normals import depth_image
+    W, H = 57, 41
+    xyz = depth_image(W, H, seed=3, step=30, holes=8)
+    rec = np.zeros((W * H, 4), np.float32)               # pcl::PointXYZ: 16-byte records
+    rec[:, :3] = xyz
+    det = kpl.KeypointLearningDetector()
+    nrm, _ = det.estimateNormalsOrganized(rec, W, H)
+    assert same_nan(nrm, oracle.integral_image_normals(xyz, W, H)[0])
+    for w, h in ((9, 40), (40, 10), (1, 1)):             # no pixel is further than the border from an edge
+        small = depth_image(w, h, seed=1)
+        n2, c2 = det.estimateNormalsOrganized(small, w, h)
+        assert np.isnan(n2).all() and np.isnan(c2).all()
+    n0, _ = det.estimateNormalsOrganized(np.zeros((0, 3), np.float32), 0, 0)
+    assert n0.shape == (0, 3)
