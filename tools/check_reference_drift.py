@@ -30,12 +30,14 @@ ORACLE = os.path.join(ROOT, "oracle", "kpl_oracle.c")
 
 # (reference file, first line, last line, sha256 of the lines with all whitespace removed)
 PINNED = [
+    (HPP, 116, 156, "initCompute (normal fallbacks)"),
     (HPP, 179, 263, "detectKeypoints"),
     (HPP, 267, 296, "runForest"),
     (HPP, 321, 376, "computePointFeatures"),
     (CPP, 41, 92, "findAnnulusPair / findBinPair"),
 ]
 HASHES = {
+    (HPP, 116, 156): "1b1c29a3b76c3fce65acad1a0d7cb47d78dc51a130f58bcc66fe3e87d8734dad",   # initCompute (normal fallbacks)
     (HPP, 179, 263): "4397a7b8d4c81732719f2f35f1a1b3e8bdd54bba36dd4b12c0f14f6abb7198b2",   # detectKeypoints
     (HPP, 267, 296): "5829a53d374d0834076bfe58b9a833fdb46451592af603f28e1f5f17e2ffe5d9",   # runForest
     (HPP, 321, 376): "36c4d414169943d6709fea080b17ab1df7ffe6871b985d3bf674c69ebca68e89",   # computePointFeatures
@@ -52,6 +54,9 @@ LINE_TOKENS = {
     362: "histograms.row(i).norm()>0", 364: "histograms.row(i).normalize()", 368: "(i*this->n_bins_)+k",
     # runForest
     277: "isFinite", 279: "computePointFeatures(pIdx)", 281: "PREDICT_SUM", 287: "1-(sum/(forest_size*1.0f))",
+    # initCompute: which estimator, with which settings (oracle: kplo_estimate_normals radius branch, kplo_integral_image_normals)
+    130: "!this->surface_->isOrganized()", 135: "setRadiusSearch(this->search_radius_)", 140: "IntegralImageNormalEstimation<PointInT,NormalT>",
+    141: "::SIMPLE_3D_GRADIENT", 143: "setNormalSmoothingSize(5.0)",
     # detectKeypoints
     205: "!isFinite(response->points[idx])", 206: "!pcl_isfinite(response->points[idx].intensity)", 207: "intensity<this->prediction_th_",
     213: "radiusSearch(idx,this->non_maxima_radius_", 219: "points[idx].intensity<response->points[*iIt].intensity",
