@@ -56,7 +56,7 @@ struct kpl_detector {
     bool has_forest = false;
     ForestModel model;
     FlatForest flat;
-    DevBuf d_nodes, d_roots;
+    DevBuf d_nodes;
 
     // bound view
     const char *d_xyz = nullptr, *d_nrm = nullptr;
@@ -191,21 +191,16 @@ int install_forest(kpl_detector *h, ForestModel &&m) {
     if (rc) return rc;
     // the new device copy is complete before the handle sees any of it: a failure on the way
     // leaves the previous forest (host and device side) in place
-    DevBuf nodes, roots;
+    DevBuf nodes;                           // (the root of tree t is slot t: no table of roots)
     hipError_t e = nodes.ensure(sizeof(FlatNode) * flat.nodes.size());
-    if (e == hipSuccess) e = roots.ensure(sizeof(uint32_t) * flat.roots.size());
     if (e == hipSuccess) e = hipMemcpy(nodes.p, flat.nodes.data(), sizeof(FlatNode) * flat.nodes.size(), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(roots.p, flat.roots.data(), sizeof(uint32_t) * flat.roots.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         nodes.release();
-        roots.release();
         return fail(h, KPL_ERR_DEVICE, "forest upload failed: %s", hipGetErrorString(e));
     }
     KPL_HIP(h, hipDeviceSynchronize());     // no kernel of an earlier call still walks the old nodes
     h->d_nodes.release();
-    h->d_roots.release();
     h->d_nodes = nodes;
-    h->d_roots = roots;
     h->model = std::move(m);
     h->flat = std::move(flat);
     h->has_forest = true;
@@ -620,7 +615,7 @@ int kpl_create(kpl_detector **out, int device) {
 void kpl_destroy(kpl_detector *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    DevBuf *bufs[] = {&h->org_scratch, &h->d_nodes, &h->d_roots, &h->stage_xyz, &h->stage_nrm, &h->stage_idx, &h->stage_feat,
+    DevBuf *bufs[] = {&h->org_scratch, &h->d_nodes, &h->stage_xyz, &h->stage_nrm, &h->stage_idx, &h->stage_feat,
                       &h->dstate, &h->cid, &h->btable, &h->cell_start, &h->tmp_idx, &h->scan_tmp,
                       &h->pts, &h->nrm, &h->pos_of, &h->score_sorted, &h->flags, &h->prefix, &h->stats,
                       &h->out_scores, &h->out_kp, &h->out_count, &h->cand_list, &h->cand_count,

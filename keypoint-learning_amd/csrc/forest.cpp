@@ -420,9 +420,8 @@ bool flatten_forest(const ForestModel &m, FlatForest &out, std::string &err) {
     for (int t = 0; t < m.ntrees(); ++t) {
         const int r = m.root[t];
         if (r < 0 || r >= nn) { err = "root index out of range"; return false; }
-        out.roots.push_back((uint32_t)out.nodes.size());
+        level.push_back(Item{r, (uint32_t)out.nodes.size(), 1});      // the root of tree t is slot t
         out.nodes.push_back(FlatNode{0, 0});
-        level.push_back(Item{r, out.roots.back(), 1});
     }
     // the resting leaf (value 0) right behind the roots: where a walk without a tree sits (kernels.hip)
     {

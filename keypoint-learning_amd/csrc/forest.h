@@ -56,7 +56,6 @@ struct FlatForest {
     int max_depth = 0;               // longest root->leaf path, counted in nodes
     bool order_free = false;         // every leaf value is an integer of magnitude <= 2^15 and there are at most 2^15
                                      // trees: the sum of leaf values is exact in any order (and fits an int32)
-    std::vector<uint32_t> roots;     // [ntrees] node index of each root (= the tree's number)
     std::vector<FlatNode> nodes;     // slots
     uint32_t ntop = 0;               // slots of the level-major top part; every slot >= ntop belongs to a block
     int64_t nnodes = 0;              // nodes of the model (nodes.size() counts padding slots too)
