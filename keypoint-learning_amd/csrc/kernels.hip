@@ -717,15 +717,7 @@ __device__ __forceinline__ float dist2(float px, float py, float pz, const Q &q)
     return d;
 }
 
-// computePointFeatures, hpp:321-376.  One lane = one query point, one wave = 64 consecutive
-// storage positions (spatially coherent: same or adjacent cells).
-//   H[c * 64 + lane]          LDS: the lane's A x B histogram       (bank = lane mod 32: no conflicts)
-// Neighbors are visited in canonical order (rows of cells ascending, storage positions
-// ascending); the first accepted one is dropped (hpp:336 starts at neigh_indx = 1).  Every lane
-// walks its own non-empty rows of cells back to back with the next search step's 16-B loads
-// always in flight; the expensive part (sqrt, two soft assignments, 4 histogram adds) only ever
-// runs on accepted neighbors -- see point_features.
-constexpr int kLanes = 64;   // one wave per workgroup: waves never synchronise with each other
+constexpr int kLanes = 64;   // lanes of a wave = threads of a workgroup of the feature kernels
 
 // what one accepted neighbor adds to the histogram: 4 cells and 4 weights (hpp:342-355).  The
 // cells are byte offsets of the lane's entries from H (cell c of lane l lives at (c * 64 + l) * 4)
@@ -735,9 +727,11 @@ struct Contribution {
     bool same_a, same_b;     // a' == a / b' == b: the pair index was clamped onto the index (range ends)
 };
 
-template <class NQ>
+// kCols = points whose histograms share the LDS block (H[c * kCols + col]): 64 with one lane per point,
+// 16 with four
+template <int kCols = 64, class NQ>
 __device__ __forceinline__ Contribution neighbor_contribution(const FeatDesc &f, float d2,
-                                                              const float4 &np, const NQ &nq) {
+                                                              const float4 &np, const NQ &nq, int col) {
     const float dot = np.x * nq.x + (np.y * nq.y + np.z * nq.z);                   // hpp:342
     float cosine = 1 - dot;
     int a, ap, bi, bp;
@@ -752,9 +746,9 @@ __device__ __forceinline__ Contribution neighbor_contribution(const FeatDesc &f,
     c.w11 = bw * aw;
     c.same_a = ap == a;
     c.same_b = bp == bi;
-    const int row_bytes = f.B * (kLanes * 4), lane_bytes = (int)threadIdx.x * 4;
+    const int row_bytes = f.B * (kCols * 4), lane_bytes = col * 4;
     const int ra = __mul24(a, row_bytes) + lane_bytes, rap = __mul24(ap, row_bytes) + lane_bytes;
-    const int cb = bi * (kLanes * 4), cbp = bp * (kLanes * 4);
+    const int cb = bi * (kCols * 4), cbp = bp * (kCols * 4);
     c.c0 = ra + cb;
     c.c1 = ra + cbp;
     c.c2 = rap + cb;
@@ -816,7 +810,6 @@ __device__ __forceinline__ int pin_i(int x) { return __builtin_amdgcn_readfirstl
 __device__ __forceinline__ float pin_f(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
 
 constexpr int kStepW = 4;      // candidates per search step: one address, kStepW 16-byte loads
-constexpr int kWordSteps = 8;  // search steps per accept word (32 candidates)
 
 struct Cand {
     f32x3 q[kStepW];
@@ -845,64 +838,67 @@ __device__ __forceinline__ unsigned search_step(unsigned w, const float4 &p, con
     return w;
 }
 
-// LDS of one wave of the feature code: the histograms, then the accept words
-//   H[c * 64 + lane]            float  the lane's A x B histogram      (bank = lane mod 32: no conflicts)
-//   ent[e * 64 + lane]          uint2  the lane's e-th non-empty accept word: x = storage position of
-//                                      the word's first candidate, y = accept bits (first candidate
-//                                      = highest bit); `ecap` words per lane
-__host__ __device__ inline size_t feature_lds_bytes(int F, int ecap) {
-    return sizeof(float) * (size_t)F * kLanes + sizeof(uint2) * (size_t)ecap * kLanes;
-}
-
-// The end of one accept word: bits past the end of the row are cleared, the first accepted neighbor of the
-// query is dropped (hpp:336 starts at neigh_indx = 1), a non-empty word goes to the lane's list.  Returns
-// the length of the list.
-__device__ __forceinline__ int list_word(unsigned w, int wbase, int t1, int &kf, bool &first_pending, uint2 *ent,
-                                         int &ecnt, int tid) {
-    const int nv = min(max(t1 - wbase, 0), 32);                  // candidates of this word inside the row
-    w = nv > 0 ? (w & (0xffffffffu << ((32 - nv) & 31))) : 0u;
-    kf += __popc(w);
-    if (first_pending & (w != 0u)) {                             // hpp:336
-        w &= 0x7fffffffu >> (__clz((int)w) & 31);
-        first_pending = false;
-    }
-    if (w != 0u) {
-        ent[ecnt * kLanes + tid] = make_uint2((unsigned)wbase, w);
-        ++ecnt;
-    }
-    return ecnt;
-}
-
-// the latency variant of the search (point_features<true>): the candidate sets of kSearchRing steps in flight
-// per lane.  (The drain gains nothing from more neighbors in flight: 2, 3, 4, 6 and 8 measured the same on one
-// small view, one large view and a batch of 8 -- profiles/r02_notes.md.)
-constexpr int kSearchRing = 4;
-
-// Returns K_f.
+// ---------------------------------------------------------------------------------------------
+// computePointFeatures, hpp:321-376: G = kGroup lanes per query point (lanes G i .. G i + G - 1 of the
+// wave: a "group"), 64 / G consecutive storage positions per wave (spatially coherent: same or adjacent
+// cells); one wave per workgroup, waves never synchronise with each other.  Returns K_f.
 //
-// Two alternating phases per wave, each a loop in which every lane works on ITS OWN query:
-//   search  the lane walks the rows of cells of its search box in canonical order ((cz, cy)
-//           ascending, storage positions ascending), kStepW distance tests per step on candidates
-//           requested one step earlier, and collects the accept bits of 32 consecutive candidates
-//           in one word; non-empty words go to the lane's list in LDS.  The first accepted
-//           neighbor of the query is dropped here (hpp:336 starts at neigh_indx = 1).
-//   drain   the lane takes its accepted neighbors one per iteration, in order, from its list of
-//           words (find-first-bit), requests point and normal one iteration ahead of their use,
-//           and accumulates (exact sqrt, two soft assignments, 4 histogram adds).
-// The search runs until a lane's list is full (ecap words) or the rows are used up; the lists are
-// then drained and the search resumes.  A wave spends about max-over-lanes(candidates) / 4 cheap
-// search iterations plus max-over-lanes(K_f) accumulate iterations; neighbors never go through
-// global memory, and nothing but the histogram and the accept words lives in LDS.
-template <bool DEEP>
-__device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
-                                              const float4 *__restrict__ nrm,
-                                              const int *__restrict__ cell_start,
-                                              const GridDesc &g, const FeatDesc &fin, float4 p,
-                                              float4 np, float *H, uint2 *ent, int ecap, bool active) {
-    const int tid = threadIdx.x;
-    // the per-launch constants of the loops below, pinned in scalar registers: left as kernel
-    // arguments the compiler re-reads them from memory inside the accumulate loop (scalar loads whose
-    // s_waitcnt lgkmcnt(0) also waits for the LDS reads in flight)
+// Two alternating phases per wave:
+//   search  the group walks the rows of cells of its point's search box in canonical order ((cz, cy)
+//           ascending, storage positions ascending) TOGETHER: 4 G candidates per step (4 per lane, adjacent
+//           pieces of the row), requested one step earlier; the 4-bit results (sign of d2 - r2 through
+//           v_alignbit) are OR-ed across the group with DPP, 8 / G steps make an accept word of 32 consecutive
+//           candidates; non-empty words go to the POINT's list in LDS.  The first accepted neighbor of the
+//           query is dropped here (hpp:336 starts at neigh_indx = 1).  All points of the wave are at the same
+//           row slot of their boxes; a row costs the wave as many steps as its longest instance.
+//   drain   G neighbors of the point per round, in order, from the list of words: lane g takes the g-th set
+//           bit of what is left of the current word (a round never spans two words), requests point and
+//           normal one round ahead of their use, and computes its contribution -- exact sqrt, two soft
+//           assignments: the expensive, order-free part.  Then the G contributions are added to the point's
+//           histogram one lane after the other (4 cells read, added with register forwarding where cells
+//           coincide, written back): the order of hpp:350-355 over the neighbors is the order of the lanes
+//           (LDS operations of a wave execute in order).
+// The search runs until a point's list is full (ecap words) or the rows are used up; the lists are then
+// drained and the search resumes.  Neighbors never go through global memory; nothing but the histograms
+// and the accept words lives in LDS:
+//   H[c * (64 / G) + point]     float  the point's A x B histogram
+//   ent[e * (64 / G) + point]   uint2  its e-th non-empty accept word: x = storage position of the word's first
+//                                      candidate, y = accept bits (first candidate = highest bit)
+// One lane per point (rounds 1 and 2 until r02e) needs fewer instructions per neighbor (no bit selection,
+// one add step instead of G: x 1.4 at G = 2, x 1.8 at G = 4) but twice the LDS per wave, runs every loop for
+// the maximum over 64 instead of 32 points, and moves a point half as fast: G = 2 measured faster on every
+// workload -- 8 views of 200 k points 0.667 -> 0.652 ms, one such view 0.137 -> 0.118, one 62 k-point
+// view 0.091 -> 0.076, 500 k points at r = 10 mr 0.767 -> 0.494, config 5 (F = 80) 1.72 -> 1.21 ms; G = 4:
+// 0.164 / 0.088 / - / 1.19 (profiles/r02_notes.md).
+constexpr int kGroup = 2;
+
+template <int G>
+__host__ __device__ inline size_t feature_lds_bytes(int F, int ecap) {
+    return (sizeof(float) * (size_t)F + sizeof(uint2) * (size_t)ecap) * (size_t)(kLanes / G);
+}
+
+// OR over the G lanes of a group (DPP quad_perm [1,0,3,2], then [2,3,0,1])
+template <int G>
+__device__ __forceinline__ unsigned group_or(unsigned v) {
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);
+    if (G == 4) v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);
+    return v;
+}
+
+// x without its highest set bit (0 stays 0)
+__device__ __forceinline__ unsigned drop_first_bit(unsigned x) { return x & (0x7fffffffu >> (__clz((int)x) & 31)); }
+
+template <int G>
+__device__ __forceinline__ int point_features(const float4 *__restrict__ pts, const float4 *__restrict__ nrm,
+                                                    const int *__restrict__ cell_start, const GridDesc &g,
+                                                    const FeatDesc &fin, float4 p, float4 np, float *H, uint2 *ent,
+                                                    int ecap, bool active) {
+    static_assert(G == 2 || G == 4, "lanes per point");
+    constexpr int kPts = kLanes / G, kStepBits = kStepW * G, kSteps = 32 / kStepBits;    // 16 / 8 candidates per step
+    const int tid = threadIdx.x, pi = tid / G, gq = tid % G;
+    // the per-launch constants of the loops below, pinned in scalar registers: left as kernel arguments the
+    // compiler re-reads them from memory inside the accumulate loop (scalar loads whose s_waitcnt lgkmcnt(0)
+    // also waits for the LDS reads in flight)
     FeatDesc f;
     f.A = pin_i(fin.A);
     f.B = pin_i(fin.B);
@@ -916,17 +912,14 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
     f.bin_rdim = pin_f(fin.bin_rdim);
     f.r2 = pin_f(fin.r2);
     f.rr = fin.rr;
-    for (int c = 0; c < f.F; ++c) H[c * kLanes + tid] = 0.0f;                    // hpp:325
-    // ---- the lane's search box; cell edge = radius: never more than 4 x 4 rows of cells
+    for (int c = gq; c < f.F; c += G) H[c * kPts + pi] = 0.0f;                     // hpp:325
     CellBox b = make_box(g, p.x, p.y, p.z, f.rr);
     b.hi[1] = min(b.hi[1], b.lo[1] + 3);
     b.hi[2] = min(b.hi[2], b.lo[2] + 3);
     const int ny = active ? b.hi[1] - b.lo[1] + 1 : 0, nz = active ? b.hi[2] - b.lo[2] + 1 : 0;
-    // wave-uniform extent of the row walk
     const int wny = __any(ny > 3) ? 4 : __any(ny > 2) ? 3 : __any(ny > 1) ? 2 : __any(ny > 0) ? 1 : 0;
     const int wnz = __any(nz > 3) ? 4 : __any(nz > 2) ? 3 : __any(nz > 1) ? 2 : __any(nz > 0) ? 1 : 0;
-    const int t_max = max(cell_start[g.ncells] - 1, 0);   // last valid storage position
-    // row slot (ky, kz) of the lane = its row of cells (lo_y + ky, lo_z + kz), x range [lo_x, hi_x]
+    const int t_max = max(cell_start[g.ncells] - 1, 0);
     auto row_range = [&](int ky, int kz, int &r0, int &r1) {
         const bool valid = (ky < ny) & (kz < nz);
         const int row = valid ? ((b.lo[2] + kz) * g.dims[1] + b.lo[1] + ky) * g.dims[0] : 0;
@@ -935,152 +928,132 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts,
         r0 = valid ? x : 0;
         r1 = valid ? y : 0;
     };
-    int ky = 0, kz = 0;                      // next row slot (wave-uniform)
+    int ky = 0, kz = 0;
     bool slots_left = wny > 0 && wnz > 0;
-    int n0 = 0, n1 = 0;                      // its range, requested ahead
+    int n0 = 0, n1 = 0;
     if (slots_left) row_range(0, 0, n0, n1);
-    int t = 0, t1 = 0;                       // current row of the lane: next candidate, end
-    Cand pre = load_cand(pts, 0);            // candidates at t, requested one step ahead
-    bool first_pending = true;               // the first accepted neighbor has not been dropped yet (hpp:336)
+    int t = 0, t1 = 0;                            // current row of the group: next candidate of lane 0, end
+    const int mine = kStepW * gq;                 // this lane's 4 candidates of a step start here
+    Cand pre = load_cand(pts, 0);
+    bool first_pending = true;
     int kf = 0;
-    const int ent_last = (ecap - 1) * kLanes + tid;
+    const int ent_last = (ecap - 1) * kPts + pi;
+    const int nib_shift = 4 * (G - 1 - gq);
     for (;;) {
-        // ================= search: fill the lanes' word lists =================
-        int ecnt = 0;                        // words in the lane's list
+        // ================= search: accept words of the point (identical in the lanes of the group) =================
+        int ecnt = 0;
         bool full = false;
-        if constexpr (DEEP) {
-            // kSearchRing steps of candidates in flight.  Nothing is kept across a drain: the ring is requested
-            // afresh at the lane's position whenever the search (re)starts
-            Cand ring[kSearchRing];
-#pragma unroll
-            for (int s = 0; s < kSearchRing; ++s) ring[s] = load_cand(pts, min(t + s * kStepW, t_max));
-            while (!full) {
-                if (!__any(t < t1)) {            // every lane is through with its current row
-                    if (!slots_left) break;
-                    t = n0;
-                    t1 = n1;
-#pragma unroll
-                    for (int s = 0; s < kSearchRing; ++s) ring[s] = load_cand(pts, min(t + s * kStepW, t_max));
-                    if (++ky == wny) {
-                        ky = 0;
-                        ++kz;
-                    }
-                    slots_left = kz < wnz;
-                    if (slots_left) row_range(ky, kz, n0, n1);
-                    continue;
+        while (!full) {
+            if (!__any(t < t1)) {
+                if (!slots_left) break;
+                t = n0;
+                t1 = n1;
+                pre = load_cand(pts, min(t + mine, t_max));
+                if (++ky == wny) {
+                    ky = 0;
+                    ++kz;
                 }
-                // one word: up to kWordSteps steps, each on the ring entry requested kSearchRing steps earlier.  A
-                // pass over the ring is not left half way: with one order of requests on every path into the
-                // loop the compiler waits for exactly the entry it is about to use (a second exit made it wait
-                // for all of them at the top of every pass)
-                const int wbase = t;
-                unsigned w = 0u;
-                int steps = 0;
-                do {
+                slots_left = kz < wnz;
+                if (slots_left) row_range(ky, kz, n0, n1);
+                continue;
+            }
+            // one word = kSteps steps of 4 G candidates, two per round so that the two candidate sets swap roles
+            const int wbase = t;
+            unsigned w = 0u;
 #pragma unroll
-                    for (int s = 0; s < kSearchRing; ++s) {
-                        w = search_step(w, p, ring[s], f.r2);
-                        ring[s] = load_cand(pts, min(t + (kSearchRing + s) * kStepW, t_max));
-                        __builtin_amdgcn_sched_barrier(0);      // the request leaves now, not at the end of the pass
-                    }
-                    steps += kSearchRing;
-                    t += kSearchRing * kStepW;
-                } while (steps < kWordSteps && __any(t < t1));
-                w <<= (32 - kStepW * steps) & 31;                            // first candidate -> bit 31
-                full = __any(list_word(w, wbase, t1, kf, first_pending, ent, ecnt, tid) == ecap);
-            }
-        } else {
-            while (!full) {
-                if (!__any(t < t1)) {            // every lane is through with its current row
-                    if (!slots_left) break;
-                    t = n0;
-                    t1 = n1;
-                    pre = load_cand(pts, min(t, t_max));
-                    if (++ky == wny) {
-                        ky = 0;
-                        ++kz;
-                    }
-                    slots_left = kz < wnz;
-                    if (slots_left) row_range(ky, kz, n0, n1);
-                    continue;
+            for (int r = 0; r < kSteps / 2; ++r) {
+                Cand nxt = load_cand(pts, min(t + kStepBits + mine, t_max));
+                w = (w << kStepBits) | group_or<G>(search_step(0u, p, pre, f.r2) << nib_shift);
+                pre = load_cand(pts, min(t + 2 * kStepBits + mine, t_max));
+                w = (w << kStepBits) | group_or<G>(search_step(0u, p, nxt, f.r2) << nib_shift);
+                t += 2 * kStepBits;
+                if (r + 1 < kSteps / 2 && !__any(t < t1)) {              // the row is over for every point: a short word
+                    w <<= 32 - 2 * kStepBits * (r + 1);
+                    break;
                 }
-                // one word: up to kWordSteps steps, two per round so that the two candidate sets swap roles
-                const int wbase = t;
-                unsigned w = 0u;
-                int rounds = 0;
-                do {
-                    Cand nxt = load_cand(pts, min(t + kStepW, t_max));
-                    w = search_step(w, p, pre, f.r2);
-                    pre = load_cand(pts, min(t + 2 * kStepW, t_max));
-                    w = search_step(w, p, nxt, f.r2);
-                    t += 2 * kStepW;
-                    ++rounds;
-                } while (rounds < kWordSteps / 2 && __any(t < t1));
-                w <<= (32 - 2 * kStepW * rounds) & 31;                       // first candidate -> bit 31
-                full = __any(list_word(w, wbase, t1, kf, first_pending, ent, ecnt, tid) == ecap);
             }
+            const int nv = min(max(t1 - wbase, 0), 32);                  // candidates of this word inside the row
+            w = nv > 0 ? (w & (0xffffffffu << ((32 - nv) & 31))) : 0u;
+            kf += __popc(w);
+            if (first_pending & (w != 0u)) {                             // hpp:336
+                w = drop_first_bit(w);
+                first_pending = false;
+            }
+            if (w != 0u) {
+                if (gq == 0) ent[ecnt * kPts + pi] = make_uint2((unsigned)wbase, w);
+                ++ecnt;
+            }
+            full = __any(ecnt == ecap);
         }
-        // ================= drain: accumulate the listed neighbors =================
+        // ================= drain: G neighbors of the point per round =================
         if (__any(ecnt > 0)) {
+            wave_lds_fence();                      // the words were stored by lane 0 of the group
             struct Taken {
                 bool valid;
                 f32x3 q, n;      // n.x is NaN for a normal that is not finite
             };
-            int e = tid;                               // list position (in uint2 units) of the next word
-            const int e_end = ecnt * kLanes + tid;
+            int e = 0;                             // words of the point's list consumed
             unsigned w = 0u;
             int wbase = 0;
-            uint2 nw = ent[tid];                       // next word, requested one iteration ahead
-            // the next neighbor of the lane's list -> `slot`, its point and normal requested (clamped address:
-            // a load behind a branch makes the compiler wait for it at the join)
+            uint2 nw = ent[pi];                    // next word, requested one round ahead
             auto take = [&](Taken &slot) {
-                const bool refill = (w == 0u) & (e < e_end);
+                const bool refill = (w == 0u) & (e < ecnt);
                 w = refill ? nw.y : w;
                 wbase = refill ? (int)nw.x : wbase;
-                e += refill ? kLanes : 0;
-                nw = ent[min(e, ent_last)];
-                slot.valid = w != 0u;
-                const int j = __clz((int)w) & 31;
-                const int tt = slot.valid ? wbase + j : 0;
-                w &= 0x7fffffffu >> j;
+                e += refill ? 1 : 0;
+                nw = ent[min(e * kPts + pi, ent_last)];
+                // the next G set bits of the word, one per lane (a round never spans two words)
+                unsigned m;
+                if (G == 2) {
+                    const unsigned c1 = drop_first_bit(w);
+                    m = gq == 0 ? w : c1;
+                    w = drop_first_bit(c1);
+                } else {
+                    const unsigned c1 = drop_first_bit(w), c2 = drop_first_bit(c1), c3 = drop_first_bit(c2);
+                    m = gq == 0 ? w : gq == 1 ? c1 : gq == 2 ? c2 : c3;
+                    w = drop_first_bit(c3);
+                }
+                slot.valid = m != 0u;
+                const int tt = slot.valid ? wbase + (__clz((int)m) & 31) : 0;
                 slot.q = ld12(pts, tt);
                 slot.n = ld12(nrm, tt);
             };
             Taken pa, pb;
             pa.valid = pb.valid = false;
             pa.q = pa.n = pb.q = pb.n = f32x3{0.f, 0.f, 0.f};
-            // One iteration: take the next neighbor into `nxt`, accumulate `now` (taken one iteration ago).
-            // (A deeper pipeline costs instructions: with enough waves per SIMD this loop is bound by VALU
-            // issue, not by its latencies, and the two-slot form is the faster one -- profiles/r02_notes.md.)
-#define KPL_DRAIN_ITERATION(now, nxt)                                                              \
+#define KPL_GROUP_ROUND(now, nxt)                                                                  \
     {                                                                                              \
         take(nxt);                                                                                 \
-        /* hpp:338: a neighbor with a non-finite normal is skipped */                              \
-        if (now.valid & (now.n.x == now.n.x)) {                                                    \
-            const Contribution c_ = neighbor_contribution(f, dist2(p.x, p.y, p.z, now.q), np, now.n); \
-            apply_contribution(H, c_, request_cells(H, c_));                                       \
+        const bool has_ = now.valid & (now.n.x == now.n.x);                         /* hpp:338 */  \
+        Contribution c_;                                                                           \
+        if (has_) c_ = neighbor_contribution<kPts>(f, dist2(p.x, p.y, p.z, now.q), np, now.n, pi); \
+        _Pragma("unroll") for (int sub_ = 0; sub_ < G; ++sub_) {                                   \
+            if (has_ & (gq == sub_)) apply_contribution(H, c_, request_cells(H, c_));              \
+            wave_lds_fence();                                                                      \
         }                                                                                          \
         now.valid = false;                                                                         \
     }
             do {
-                KPL_DRAIN_ITERATION(pa, pb)
-                KPL_DRAIN_ITERATION(pb, pa)
-            } while (__any((w != 0u) | (e < e_end) | pa.valid | pb.valid));
-#undef KPL_DRAIN_ITERATION
+                KPL_GROUP_ROUND(pa, pb)
+                KPL_GROUP_ROUND(pb, pa)
+            } while (__any((w != 0u) | (e < ecnt) | pa.valid | pb.valid));
+#undef KPL_GROUP_ROUND
         }
         if (!slots_left && !__any(t < t1)) break;
     }
-    for (int a = 0; a < f.A; ++a) {                                                // hpp:360-370
-        float *h = H + (a * f.B) * kLanes + tid;
+    wave_lds_fence();
+    for (int a = gq; a < f.A; a += G) {                                            // hpp:360-370, one row per lane
+        float *h = H + (a * f.B) * kPts + pi;
         float s = 0.0f;
         for (int k = 0; k < f.B; ++k) {
-            float v = h[k * kLanes];
+            float v = h[k * kPts];
             s += v * v;
         }
         const float nr = sqrtf(s);
         if (nr > 0)
-            for (int k = 0; k < f.B; ++k) h[k * kLanes] = h[k * kLanes] / nr;
+            for (int k = 0; k < f.B; ++k) h[k * kPts] = h[k * kPts] / nr;
     }
+    wave_lds_fence();
     return kf;
 }
 
@@ -1373,22 +1346,25 @@ __device__ __forceinline__ WavePoint wave_point(const ViewDev &a, int chunk, int
     return w;
 }
 
-// Several independent views per launch (blockIdx.y = view): 200 k points are only ~3 waves per
-// SIMD, too few to hide the latencies of this kernel; a batch of views fills the chip.
-template <bool STATS, bool DEEP>
+// Several independent views per launch (blockIdx.y = view): one 200 k-point view is only a few waves per
+// SIMD; a batch of views fills the chip.  Workgroup (= wave) x handles the 64 / kGroup storage positions
+// x * 64 / kGroup ..; it writes its columns of the F x 64 feature block of its chunk of 64 positions.
+template <bool STATS>
 __global__ __launch_bounds__(kLanes) void feature_kernel(Batch b, int maxF, int ecap) {
     extern __shared__ float H[];
+    constexpr int kPts = kLanes / kGroup;
     const ViewDev &v = b.view[blockIdx.y];
-    const int chunk = blockIdx.x;
-    if (chunk * kLanes >= v.n) return;
-    const WavePoint w = wave_point(v, chunk, threadIdx.x, true);
-    // every lane of the wave runs the feature code (wave-level votes inside); lanes without a
-    // scoreable point simply have no rows
-    const int kf = point_features<DEEP>(v.pts, v.nrm, v.cell_start, v.ds->grid, v.f, w.p, w.np, H,
-                                  reinterpret_cast<uint2 *>(H + maxF * kLanes), ecap, w.scoreable);
-    if (STATS && w.scoreable) atomicAdd(&v.stats->sum_kf, (unsigned long long)kf);
-    float *o = v.feat + (size_t)chunk * v.f.F * kLanes + threadIdx.x;
-    for (int c = 0; c < v.f.F; ++c) o[c * kLanes] = H[c * kLanes + threadIdx.x];
+    const int chunk = blockIdx.x / kGroup, pi = threadIdx.x / kGroup, gq = threadIdx.x % kGroup;
+    const int col = (blockIdx.x % kGroup) * kPts + pi;                // the point's column of the chunk's F x 64 block
+    if (chunk * kLanes + col - pi >= v.n) return;
+    const WavePoint w = wave_point(v, chunk, col, true);
+    // every lane of the wave runs the feature code (wave-level votes inside); a group without a scoreable
+    // point simply has no rows
+    const int kf = point_features<kGroup>(v.pts, v.nrm, v.cell_start, v.ds->grid, v.f, w.p, w.np, H,
+                                          reinterpret_cast<uint2 *>(H + maxF * kPts), ecap, w.scoreable);
+    if (STATS && w.scoreable && gq == 0) atomicAdd(&v.stats->sum_kf, (unsigned long long)kf);
+    float *o = v.feat + (size_t)chunk * v.f.F * kLanes + col;
+    for (int c = gq; c < v.f.F; c += kGroup) o[c * kLanes] = H[c * kPts + pi];
 }
 
 // Persistent workgroups of several waves: the workgroup stages the first nlds nodes of its view's
@@ -1524,7 +1500,7 @@ __global__ __launch_bounds__(1024) void forest_split_kernel(Batch b, int maxF, i
     }
 }
 
-// computePointsForTrainingFeatures, hpp:299-318: same feature code, sparse query list.
+// computePointsForTrainingFeatures, hpp:299-318: same feature code, sparse query list (64 / kGroup queries per wave).
 __global__ __launch_bounds__(kLanes) void features_kernel(const float4 *__restrict__ pts,
                                                           const float4 *__restrict__ nrm,
                                                           const int *__restrict__ cell_start,
@@ -1533,9 +1509,11 @@ __global__ __launch_bounds__(kLanes) void features_kernel(const float4 *__restri
                                                           const int *__restrict__ query, int m,
                                                           int n, int ecap, float *__restrict__ out) {
     extern __shared__ float H[];
-    uint2 *ent = reinterpret_cast<uint2 *>(H + f.F * kLanes);
+    constexpr int kPts = kLanes / kGroup;
+    uint2 *ent = reinterpret_cast<uint2 *>(H + f.F * kPts);
     const GridDesc g = ds->grid;
-    const int qi = blockIdx.x * kLanes + threadIdx.x;
+    const int pi = threadIdx.x / kGroup, gq = threadIdx.x % kGroup;
+    const int qi = blockIdx.x * kPts + pi;
     int s = -1;
     if (qi < m) {
         const int i = query[qi];
@@ -1543,10 +1521,10 @@ __global__ __launch_bounds__(kLanes) void features_kernel(const float4 *__restri
     }
     const float4 p = s >= 0 ? pts[s] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 np = s >= 0 ? nrm[s] : make_float4(0.f, 0.f, 0.f, 0.f);
-    point_features<false>(pts, nrm, cell_start, g, f, p, np, H, ent, ecap, s >= 0);
+    point_features<kGroup>(pts, nrm, cell_start, g, f, p, np, H, ent, ecap, s >= 0);
     if (qi >= m) return;
     float *o = out + (size_t)qi * f.F;
-    for (int c = 0; c < f.F; ++c) o[c] = s >= 0 ? H[c * kLanes + threadIdx.x] : NAN;
+    for (int c = gq; c < f.F; c += kGroup) o[c] = s >= 0 ? H[c * kPts + pi] : NAN;
 }
 
 // detectKeypoints, hpp:197-256 with draws_remove == false (order-independent predicate):
@@ -2197,17 +2175,15 @@ size_t feat_bytes(int n, int F) { return sizeof(float) * (size_t)div_up(n > 0 ? 
 
 size_t pts_bytes(int n) { return sizeof(float4) * ((size_t)(n > 0 ? n : 1) + kStepW); }
 
-// Accept words per lane for a histogram of F floats per lane: as many as fit next to the histogram
-// while kMinWaves waves per CU stay resident (160 KB of LDS per CU), between 4 and 16.  A lane whose
-// neighborhood needs more words than that simply searches and drains in several rounds.
-constexpr int kLdsPerCu = 160 * 1024, kMinWavesPerCu = 12;
-constexpr double kDeepBelow = 2.5;
-static int accept_words(int F, int waves_per_cu) {
-    const long long room = kLdsPerCu / waves_per_cu - (long long)sizeof(float) * F * kLanes;
-    long long e = room / (long long)(sizeof(uint2) * kLanes);
-    if (e < 4) e = 4;
-    if (e > 16) e = 16;
-    return (int)e;
+// Accept words per point: 24 (768 candidates between two drains) measured best or level with 12 .. 32 at
+// F = 30 and at F = 80 (12 KB resp. 16 KB of LDS per wave of 32 points); fewer for the largest histograms so
+// that a handful of waves still fit a CU (160 KB of LDS).  A point whose neighborhood needs more words
+// simply searches and drains in several rounds.
+constexpr int kLdsPerCu = 160 * 1024;
+static int accept_words(int F) {
+    int e = 24;
+    while (e > 4 && feature_lds_bytes<kGroup>(F, e) * 6 > (size_t)kLdsPerCu) e -= 4;
+    return e;
 }
 
 // Geometry of the forest kernel: one workgroup per CU; LDS = the top of the forest (at most
@@ -2257,28 +2233,11 @@ void launch_feature_stage(const Batch &b, hipStream_t st) {
         maxF = b.view[v].f.F > maxF ? b.view[v].f.F : maxF;
         stats |= b.view[v].stats != nullptr;
     }
-    long long waves = 0;
-    for (int v = 0; v < b.nviews; ++v) waves += div_up(b.view[v].n > 0 ? b.view[v].n : 0, kLanes);
-    // Waves resident per SIMD with the throughput variant: what the launch offers and what fits in LDS.  Below
-    // kDeepBelow the loops of the feature code wait for memory at every step with nothing else to run, and the
-    // latency variant (several steps in flight per lane, more instructions) is the faster one
-    int ecap = accept_words(maxF, kMinWavesPerCu);
-    const double fit = (double)kLdsPerCu / (double)feature_lds_bytes(maxF, ecap) / 4.0;
-    const double offered = (double)waves / (4.0 * cu_count());
-    const bool deep = (offered < fit ? offered : fit) < kDeepBelow;
-    if (deep && offered < fit) {                  // few waves: LDS to spare, longer word lists, fewer drains
-        int per_cu = (int)(waves / cu_count()) + 1;
-        ecap = accept_words(maxF, per_cu < kMinWavesPerCu ? per_cu : kMinWavesPerCu);
-    }
-    const size_t lds = feature_lds_bytes(maxF, ecap);
-    const dim3 grid(div_up(n, kLanes), b.nviews);
-    if (stats) {
-        if (deep) feature_kernel<true, true><<<grid, kLanes, lds, st>>>(b, maxF, ecap);
-        else feature_kernel<true, false><<<grid, kLanes, lds, st>>>(b, maxF, ecap);
-    } else {
-        if (deep) feature_kernel<false, true><<<grid, kLanes, lds, st>>>(b, maxF, ecap);
-        else feature_kernel<false, false><<<grid, kLanes, lds, st>>>(b, maxF, ecap);
-    }
+    const int ecap = accept_words(maxF);
+    const size_t lds = feature_lds_bytes<kGroup>(maxF, ecap);
+    const dim3 grid(div_up(n, kLanes) * kGroup, b.nviews);
+    if (stats) feature_kernel<true><<<grid, kLanes, lds, st>>>(b, maxF, ecap);
+    else feature_kernel<false><<<grid, kLanes, lds, st>>>(b, maxF, ecap);
 }
 
 // second kernel: feat -> forest response (score_sorted, scores) and the NMS candidates
@@ -2328,9 +2287,9 @@ void launch_features(const float4 *pts, const float4 *nrm, const int *cell_start
                      const int *pos_of, const DevState *ds, FeatDesc f, const int *query, int m, int n,
                      float *out, hipStream_t st) {
     if (m <= 0) return;
-    const int ecap = accept_words(f.F, kMinWavesPerCu);
-    features_kernel<<<div_up(m, kLanes), kLanes, feature_lds_bytes(f.F, ecap), st>>>(pts, nrm, cell_start, pos_of, ds, f,
-                                                                                    query, m, n, ecap, out);
+    const int ecap = accept_words(f.F);
+    features_kernel<<<div_up(m, kLanes / kGroup), kLanes, feature_lds_bytes<kGroup>(f.F, ecap), st>>>(pts, nrm, cell_start, pos_of, ds,
+                                                                                                      f, query, m, n, ecap, out);
 }
 
 // NMS, draws pass (if any view asks for it), flag scan and ordered compaction of every view
