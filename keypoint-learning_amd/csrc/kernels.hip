@@ -2175,10 +2175,27 @@ size_t feat_bytes(int n, int F) { return sizeof(float) * (size_t)div_up(n > 0 ? 
 
 size_t pts_bytes(int n) { return sizeof(float4) * ((size_t)(n > 0 ? n : 1) + kStepW); }
 
-// Accept words per point: 24 (768 candidates between two drains) measured best or level with 12 .. 32 at
-// F = 30 and at F = 80 (12 KB resp. 16 KB of LDS per wave of 32 points); fewer for the largest histograms so
-// that a handful of waves still fit a CU (160 KB of LDS).  A point whose neighborhood needs more words
-// simply searches and drains in several rounds.
+static int cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            n = v;
+        else
+            n = 256;
+    }
+    return n;
+}
+
+// Accept words per point (what a point may collect between two drains; a neighborhood that needs more simply
+// searches and drains in several rounds): 24 = 768 candidates.  Measured 12 / 16 / 24 / 32 on every config
+// (profiles/r02_notes.md): 24 is best or level everywhere -- the larger the neighborhoods the more (500 k
+// points at r = 10 mr: 0.639 / 0.593 / 0.499 ms; config 5: 1.29 / 1.31 / 1.22; one 62 k-point view: 0.086 /
+// 0.076 / 0.077; 8 views of 200 k: 0.654 / - / 0.653 / 0.770) -- with ONE exception that is not taken: 12 words
+// together with a register cap of 88 (five waves per SIMD instead of four) run the 8-view batch in 0.621 ms,
+// and every launch with larger neighborhoods 10-25 % slower; the host cannot know the neighborhood size.
+// Fewer words for the largest histograms so that a handful of waves still fit a CU (160 KB of LDS).
 constexpr int kLdsPerCu = 160 * 1024;
 static int accept_words(int F) {
     int e = 24;
@@ -2210,18 +2227,6 @@ static ForestLaunch forest_launch(int maxF, int max_nodes) {
     return fl;
 }
 
-static int cu_count() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-            n = v;
-        else
-            n = 256;
-    }
-    return n;
-}
 
 // scoring ("runForest") of every view of the batch, first kernel: histogram features -> feat
 void launch_feature_stage(const Batch &b, hipStream_t st) {
