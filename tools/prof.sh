@@ -18,6 +18,6 @@ f=$(find $R/gpurun_out/${tag}_trace -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cut -c1-160 "$f" | head -14
 # keep what travels back small: the per-dispatch trace is not needed, the stats are
 find $R/gpurun_out/${tag}_trace -name "*kernel_trace.csv" -delete
-bash $R/tools/pmc.sh ${tag}_fetch FETCH_SIZE "$@" < /dev/null | cut -c1-200 | grep -A2 "feature_kernel<false, false>\|forest_kernel<false>"
-bash $R/tools/pmc.sh ${tag}_write WRITE_SIZE "$@" < /dev/null | cut -c1-200 | grep -A2 "feature_kernel<false, false>\|forest_kernel<false>"
-bash $R/tools/pmc.sh ${tag}_sq "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE" "$@" < /dev/null | cut -c1-200 | grep -A9 "feature_kernel<false, false>\|forest_kernel<false>"
+bash $R/tools/pmc.sh ${tag}_fetch FETCH_SIZE "$@" < /dev/null | cut -c1-200 | grep -A2 "feature_kernel<false>\|forest_kernel<false>"
+bash $R/tools/pmc.sh ${tag}_write WRITE_SIZE "$@" < /dev/null | cut -c1-200 | grep -A2 "feature_kernel<false>\|forest_kernel<false>"
+bash $R/tools/pmc.sh ${tag}_sq "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE" "$@" < /dev/null | cut -c1-200 | grep -A9 "feature_kernel<false>\|forest_kernel<false>"

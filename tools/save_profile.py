@@ -41,7 +41,7 @@ def main():
         shutil.copy(stats[-1], os.path.join(prof, tag + "_kernel_stats.csv"))
         for r in csv.DictReader(open(stats[-1])):
             name = r["Name"]
-            for k in ("feature_kernel<false, false>", "feature_kernel<false, true>", "forest_kernel<false>", "nms_kernel<false>", "cell_sort_store_kernel",
+            for k in ("feature_kernel<false>", "forest_kernel<false>", "nms_kernel<false>", "cell_sort_store_kernel",
                       "bucket_scatter_kernel", "bucket_hist_kernel"):
                 if k in name:
                     avg_ns[k] = float(r["AverageNs"])
@@ -61,8 +61,7 @@ def main():
         shutil.copy(bench_json, os.path.join(prof, tag + "_bench.json"))
         views = json.load(open(bench_json))["config"].get("views_per_launch")
     kernels = {}
-    # feature_kernel<STATS, DEEP>: the batch of the bench runs the throughput variant (DEEP = false)
-    for k in ("feature_kernel<false, false>", "forest_kernel<false>"):
+    for k in ("feature_kernel<false>", "forest_kernel<false>"):
         c = pmc.get(k)
         if not c:
             continue
