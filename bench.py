@@ -424,11 +424,12 @@ def main():
     iso_ms = max(t_iso["feature_ms"] / max(t_iso["calls"], 1), 1e-9) if t_iso else None
     # measured counters of exactly these kernels (rocprofv3, profiles/counters.json) -- or null
     prof, why_not = load_profile(nb)
-    traffic = valu_busy = hbm_counter_frac = waves_per_simd = None
+    traffic = valu_busy = ta_busy = hbm_counter_frac = waves_per_simd = None
     if prof:
         pk = prof["kernels"].get("feature_kernel", {})
         traffic = pk.get("hbm_bytes")
         valu_busy = pk.get("valu_busy")
+        ta_busy = pk.get("ta_busy")
         waves_per_simd = pk.get("waves_per_simd")
         if traffic and feat_ms > 0:
             hbm_counter_frac = round(traffic / (feat_ms * 1e-3) / HBM_PEAK, 5)
@@ -478,14 +479,16 @@ def main():
                        "parallelism": "views sharded, %d rank(s)" % world},
             "repeats": {"n": repeats, "reported": "median", "ms_per_step": [round(x * 1e3 / args.steps, 5) for x in rep_s]},
             # SURVEY 8(d) contract figure: gather-model bytes of the dominant kernel / its launch time / 8 TB/s.
-            # What actually limits that kernel is VALU issue (valu_busy), its HBM traffic is a few per cent
-            # of peak (hbm_counter_frac); both come from rocprofv3 counters of exactly these kernel sources
+            # What actually limits that kernel is VALU issue (valu_busy: SQ_ACTIVE_INST_VALU x 4 cycles, an upper
+            # bound) together with the texture path (ta_busy), its HBM traffic is a tenth of peak
+            # (hbm_counter_frac); all three come from rocprofv3 counters of exactly these kernel sources
             # (profiles/counters.json, matched by hash) and are null when the profile is stale.
             "roofline": {"bound": "valu", "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 5), "traffic": traffic,
                          "kernel": "feature_kernel (histogram features, %d view(s) per launch)" % nb,
                          "kernel_ms": round(feat_ms, 5), "alg_bytes_per_launch": int(b_alg_feat),
-                         "valu_busy": valu_busy, "hbm_counter_frac": hbm_counter_frac, "waves_per_simd": waves_per_simd,
+                         "valu_busy": valu_busy, "ta_busy": ta_busy, "hbm_counter_frac": hbm_counter_frac,
+                         "waves_per_simd": waves_per_simd,
                          "counters": {"file": "profiles/counters.json", "source_sha256": kernel_source_sha256()[:16],
                                       "matches_these_kernels": prof is not None, "note": why_not},
                          "alone_on_gpu": {"kernel_ms": round(iso_ms, 5),

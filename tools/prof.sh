@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (on the GPU box, via gpurun): tools/prof.sh <tag> [bench args]
 # 1. bench.py under rocprofv3 --kernel-trace --stats (csv)                      -> gpurun_out/<tag>_trace/
-# 2. own passes for --pmc FETCH_SIZE, --pmc WRITE_SIZE and one SQ counter set   -> gpurun_out/pmc_<tag>_{fetch,write,sq}/
+# 2. own passes for --pmc FETCH_SIZE, --pmc WRITE_SIZE, one SQ counter set, TA busy -> gpurun_out/pmc_<tag>_{fetch,write,sq,ta}/
 # 3. the hash of the kernel sources the counters were taken on                  -> gpurun_out/<tag>_sha256.txt
 # Back in the build container: python tools/save_profile.py <tag>  (copies the summaries to profiles/ and
 # refreshes profiles/counters.json, which bench.py quotes only while that hash matches its own kernels).
@@ -21,3 +21,4 @@ find $R/gpurun_out/${tag}_trace -name "*kernel_trace.csv" -delete
 bash $R/tools/pmc.sh ${tag}_fetch FETCH_SIZE "$@" < /dev/null | cut -c1-200 | grep -A2 "feature_kernel<false>\|forest_kernel<false>"
 bash $R/tools/pmc.sh ${tag}_write WRITE_SIZE "$@" < /dev/null | cut -c1-200 | grep -A2 "feature_kernel<false>\|forest_kernel<false>"
 bash $R/tools/pmc.sh ${tag}_sq "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE" "$@" < /dev/null | cut -c1-200 | grep -A9 "feature_kernel<false>\|forest_kernel<false>"
+bash $R/tools/pmc.sh ${tag}_ta "TA_BUSY_avr TA_BUSY_max GRBM_GUI_ACTIVE" "$@" < /dev/null | cut -c1-200 | grep -A4 "feature_kernel<false>\|forest_kernel<false>"

@@ -47,7 +47,7 @@ def main():
                     avg_ns[k] = float(r["AverageNs"])
                     calls[k] = int(r["Calls"])
     pmc = {}
-    for suffix in ("fetch", "write", "sq"):
+    for suffix in ("fetch", "write", "sq", "ta"):
         agg, meta = summarize(os.path.join(out_dir, "pmc_%s_%s" % (tag, suffix)))
         for k, counters in agg.items():
             for c, vals in counters.items():
@@ -76,6 +76,8 @@ def main():
                 e["valu_busy"] = round(c["SQ_ACTIVE_INST_VALU"] * 4.0 / (SIMDS * cycles), 4)
             if c.get("SQ_WAVE_CYCLES") is not None:
                 e["waves_per_simd"] = round(c["SQ_WAVE_CYCLES"] * 4.0 / (SIMDS * cycles), 3)
+            if c.get("TA_BUSY_avr") is not None:       # (its own pass: cycles of that pass)
+                e["ta_busy"] = round(c["TA_BUSY_avr"] / cycles, 4)
             for name in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "SQ_INSTS_VMEM_RD"):
                 if c.get(name) is not None:
                     e[name] = round(c[name], 1)
@@ -83,7 +85,8 @@ def main():
     json.dump({"tag": tag, "source_sha256": sha, "views_per_launch": views, "kernels": kernels,
                "formulas": {"hbm_bytes": "(2*FETCH_SIZE + WRITE_SIZE) KiB * 1024, separate rocprofv3 --pmc passes",
                             "valu_busy": "SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * GRBM_GUI_ACTIVE / 8)",
-                            "waves_per_simd": "SQ_WAVE_CYCLES * 4 / (1024 SIMDs * GRBM_GUI_ACTIVE / 8)"},
+                            "waves_per_simd": "SQ_WAVE_CYCLES * 4 / (1024 SIMDs * GRBM_GUI_ACTIVE / 8)",
+                            "ta_busy": "TA_BUSY_avr / (GRBM_GUI_ACTIVE / 8): the texture-addresser's busy cycles, average over its instances"},
                "files": [tag + "_kernel_stats.csv", tag + "_pmc.json", tag + "_bench.json"]},
               open(os.path.join(prof, "counters.json"), "w"), indent=1)
     print("saved", tag, "->", prof, "kernels:", sorted(kernels))
