@@ -727,9 +727,8 @@ struct Contribution {
     bool same_a, same_b;     // a' == a / b' == b: the pair index was clamped onto the index (range ends)
 };
 
-// kCols = points whose histograms share the LDS block (H[c * kCols + col]): 64 with one lane per point,
-// 16 with four
-template <int kCols = 64, class NQ>
+// kCols = points whose histograms share the LDS block of a wave (H[c * kCols + col]): 64 / kGroup
+template <int kCols, class NQ>
 __device__ __forceinline__ Contribution neighbor_contribution(const FeatDesc &f, float d2,
                                                               const float4 &np, const NQ &nq, int col) {
     const float dot = np.x * nq.x + (np.y * nq.y + np.z * nq.z);                   // hpp:342
@@ -1318,10 +1317,11 @@ __device__ __forceinline__ int forest_sum_any_order(const ForestDev &forest, con
     return sum;
 }
 
-// The scoring stage ("runForest", hpp:267-296) in two kernels, one wave = 64 consecutive storage
+// The scoring stage ("runForest", hpp:267-296) in two kernels over chunks of 64 consecutive storage
 // positions of a view:
-//   feature kernel -> feat[(chunk * F + c) * 64 + lane], one contiguous F x 64 block per wave
-//   forest kernel  <- the same block, staged in LDS again next to the top of the forest.
+//   feature kernel -> feat[(chunk * F + c) * 64 + position in the chunk], one contiguous F x 64 block per
+//                     chunk (kGroup waves of 64 / kGroup points write their columns of it)
+//   forest kernel  <- the same block, one wave per chunk, staged in LDS next to the top of the forest.
 // In one kernel the forest walk (dependent node reads, 64 different cache lines per load instruction)
 // was 26 % of the time and ran no faster on its own at 5 waves per SIMD: it is bound by the texture
 // path, not by occupancy (profiles/r02_notes.md).  On its own it can keep the forest in LDS.
