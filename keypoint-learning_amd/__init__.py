@@ -361,6 +361,14 @@ class KeypointLearningDetector:
                                                              out.ctypes.data + 12, 16))
         return out[:n, :3].copy(), out[:n, 3].copy()
 
+    def estimateNormalsOrganizedDevice(self, d_xyz, xyz_stride, width, height, smoothing_size, viewpoint, d_normals,
+                                       normals_stride, d_curvature=None, curvature_stride=0, stream=None):
+        """kpl_estimate_normals_organized_device: device pointers in and out, asynchronous on `stream`."""
+        vp = np.ascontiguousarray(viewpoint, dtype=np.float32)
+        self._check(self._lib.kpl_estimate_normals_organized_device(self._h, d_xyz, xyz_stride, int(width), int(height),
+                                                                    float(smoothing_size), vp.ctypes.data, d_normals,
+                                                                    normals_stride, d_curvature, curvature_stride, stream))
+
     def estimateNormalsDevice(self, k, radius, viewpoint, d_normals, normals_stride, d_curvature=None,
                               curvature_stride=0, stream=None):
         vp = np.ascontiguousarray(viewpoint, dtype=np.float32)

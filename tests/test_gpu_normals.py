@@ -145,3 +145,26 @@ def test_organized_normals_strides_and_degenerate_shapes(kpl, oracle):
         assert np.isnan(n2).all() and np.isnan(c2).all()
     n0, _ = det.estimateNormalsOrganized(np.zeros((0, 3), np.float32), 0, 0)
     assert n0.shape == (0, 3)
+
+
+def test_organized_normals_on_device_buffers_in_pcl_layouts(kpl, oracle):
+    """kpl_estimate_normals_organized_device: pcl::PointXYZ records in (16 bytes), pcl::Normal records out (32 bytes,
+    curvature at +16) -- the buffers a caller with a device-resident organized cloud already has; asynchronous."""
+    import torch
+    from tests.test_oracle_organized_normals import depth_image
+    W, H = 120, 90
+    xyz = depth_image(W, H, seed=9, step=70, holes=15)
+    rec = np.zeros((W * H, 4), np.float32)
+    rec[:, :3] = xyz
+    dev = torch.device("cuda", 0)
+    dx = torch.from_numpy(rec).to(dev)
+    dn = torch.full((W * H, 8), 7.0, dtype=torch.float32, device=dev)
+    det = kpl.KeypointLearningDetector()
+    st = torch.cuda.current_stream().cuda_stream
+    det.estimateNormalsOrganizedDevice(dx.data_ptr(), 16, W, H, 5.0, (0.0, 0.0, 0.0), dn.data_ptr(), 32, dn.data_ptr() + 16, 32, st)
+    torch.cuda.synchronize()
+    out = dn.cpu().numpy()
+    o_nrm, _ = oracle.integral_image_normals(xyz, W, H, 5.0)
+    assert same_nan(out[:, :3], o_nrm)
+    assert np.isnan(out[:, 4]).all()                                   # curvature
+    assert (out[:, 3] == 7.0).all() and (out[:, 5:] == 7.0).all()       # nothing else of the records is touched
