@@ -722,15 +722,14 @@ constexpr int kLanes = 64;   // lanes of a wave = threads of a workgroup of the 
 // what one accepted neighbor adds to the histogram: 4 cells and 4 weights (hpp:342-355).  The
 // cells are byte offsets of the lane's entries from H (cell c of lane l lives at (c * 64 + l) * 4)
 struct Contribution {
-    int c0, c1, c2, c3;      // (a,b) (a,b') (a',b) (a',b')
+    int c0, c1, c2, c3;      // (a,b) (a,b') (a',b) (a',b'): LDS addresses
     float w00, w01, w10, w11;
-    bool same_a, same_b;     // a' == a / b' == b: the pair index was clamped onto the index (range ends)
 };
 
 // kCols = points whose histograms share the LDS block of a wave (H[c * kCols + col]): 64 / kGroup
 template <int kCols, class NQ>
 __device__ __forceinline__ Contribution neighbor_contribution(const FeatDesc &f, float d2,
-                                                              const float4 &np, const NQ &nq, int col) {
+                                                              const float4 &np, const NQ &nq, int col_address) {
     const float dot = np.x * nq.x + (np.y * nq.y + np.z * nq.z);                   // hpp:342
     float cosine = 1 - dot;
     int a, ap, bi, bp;
@@ -743,9 +742,7 @@ __device__ __forceinline__ Contribution neighbor_contribution(const FeatDesc &f,
     c.w01 = bw * (1 - aw);
     c.w10 = (1 - bw) * aw;
     c.w11 = bw * aw;
-    c.same_a = ap == a;
-    c.same_b = bp == bi;
-    const int row_bytes = f.B * (kCols * 4), lane_bytes = col * 4;
+    const int row_bytes = f.B * (kCols * 4), lane_bytes = col_address;      // LDS address of H[0 * kCols + point]
     const int ra = __mul24(a, row_bytes) + lane_bytes, rap = __mul24(ap, row_bytes) + lane_bytes;
     const int cb = bi * (kCols * 4), cbp = bp * (kCols * 4);
     c.c0 = ra + cb;
@@ -755,8 +752,13 @@ __device__ __forceinline__ Contribution neighbor_contribution(const FeatDesc &f,
     return c;
 }
 
-__device__ __forceinline__ float &hist_at(float *H, int byte_offset) {
-    return *reinterpret_cast<float *>(reinterpret_cast<char *>(H) + byte_offset);
+// LDS by address: the cells of a Contribution are LDS ADDRESSES (the base of H is folded into the point's
+// column address once per kernel: added per access it was four `v_add_u32 v, 0, v` per round, the base
+// being a link-time 0 the compiler cannot fold)
+typedef __attribute__((address_space(3))) float lds_float;
+__device__ __forceinline__ int lds_address(const float *p) { return (int)(size_t)(const lds_float *)p; }
+__device__ __forceinline__ lds_float &hist_at(int lds_byte_address) {
+    return *(lds_float *)(size_t)(unsigned)lds_byte_address;
 }
 
 // The 4 "+=" of one neighbor (hpp:350-355) may hit the same cell -- the pair index is clamped onto
@@ -764,8 +766,8 @@ __device__ __forceinline__ float &hist_at(float *H, int byte_offset) {
 // (request_cells), the adds are forwarded through registers in the reference's order and written
 // back in order (apply_contribution), so the float result is exactly the one the sequential chain
 // gives and only one LDS round trip sits on the critical path.
-// Which cells coincide follows from the two clamp flags: c1 == c0 and c3 == c2 iff same_b,
-// c2 == c0 and c3 == c1 iff same_a.
+// Which cells coincide follows from two facts: c1 == c0 and c3 == c2 iff the bin pair was clamped onto the
+// bin, c2 == c0 and c3 == c1 iff the annulus pair was clamped onto the annulus.
 // (Four ds_add_f32 give the same bits -- the LDS adder rounds like v_add_f32 and one wave's DS
 // instructions execute in order -- but LDS float atomics run at a fraction of the plain read /
 // write rate: the kernel took 2.3x as long with them, profiles/r02_notes.md.)
@@ -773,25 +775,28 @@ struct Cells {
     float v0, v1, v2, v3;
 };
 
-__device__ __forceinline__ Cells request_cells(float *H, const Contribution &c) {
+__device__ __forceinline__ Cells request_cells(const Contribution &c) {
     Cells v;
-    v.v0 = hist_at(H, c.c0);
-    v.v1 = hist_at(H, c.c1);
-    v.v2 = hist_at(H, c.c2);
-    v.v3 = hist_at(H, c.c3);
+    v.v0 = hist_at(c.c0);
+    v.v1 = hist_at(c.c1);
+    v.v2 = hist_at(c.c2);
+    v.v3 = hist_at(c.c3);
     return v;
 }
 
-__device__ __forceinline__ void apply_contribution(float *H, const Contribution &c, const Cells &v) {
-    const bool both = c.same_a & c.same_b;
+__device__ __forceinline__ void apply_contribution(const Contribution &c, const Cells &v) {
+    // (the clamp flags, re-derived from the cells here: carried as booleans across the branch around the
+    // contribution they cost eight instructions per round to unpack)
+    const bool same_b = c.c1 == c.c0, same_a = c.c2 == c.c0;
+    const bool both = same_a & same_b;
     const float x0 = v.v0 + c.w00;                                                 // hpp:350
-    const float x1 = (c.same_b ? x0 : v.v1) + c.w01;                               // hpp:351
-    const float x2 = (both ? x1 : c.same_a ? x0 : v.v2) + c.w10;                   // hpp:354
-    const float x3 = (c.same_b ? x2 : c.same_a ? x1 : v.v3) + c.w11;               // hpp:355
-    hist_at(H, c.c0) = x0;
-    hist_at(H, c.c1) = x1;
-    hist_at(H, c.c2) = x2;
-    hist_at(H, c.c3) = x3;
+    const float x1 = (same_b ? x0 : v.v1) + c.w01;                               // hpp:351
+    const float x2 = (both ? x1 : same_a ? x0 : v.v2) + c.w10;                   // hpp:354
+    const float x3 = (same_b ? x2 : same_a ? x1 : v.v3) + c.w11;               // hpp:355
+    hist_at(c.c0) = x0;
+    hist_at(c.c1) = x1;
+    hist_at(c.c2) = x2;
+    hist_at(c.c3) = x3;
 }
 
 // 12-byte / 4-byte loads addressed by a 32-bit byte offset from a wave-uniform base (one shift
@@ -938,6 +943,7 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts, co
     int kf = 0;
     const int ent_last = (ecap - 1) * kPts + pi;
     const int nib_shift = 4 * (G - 1 - gq);
+    const int col_address = lds_address(H + pi);
     for (;;) {
         // ================= search: accept words of the point (identical in the lanes of the group) =================
         int ecnt = 0;
@@ -1025,9 +1031,9 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts, co
         take(nxt);                                                                                 \
         const bool has_ = now.valid & (now.n.x == now.n.x);                         /* hpp:338 */  \
         Contribution c_;                                                                           \
-        if (has_) c_ = neighbor_contribution<kPts>(f, dist2(p.x, p.y, p.z, now.q), np, now.n, pi); \
+        if (has_) c_ = neighbor_contribution<kPts>(f, dist2(p.x, p.y, p.z, now.q), np, now.n, col_address); \
         _Pragma("unroll") for (int sub_ = 0; sub_ < G; ++sub_) {                                   \
-            if (has_ & (gq == sub_)) apply_contribution(H, c_, request_cells(H, c_));              \
+            if (has_ & (gq == sub_)) apply_contribution(c_, request_cells(c_));                    \
             wave_lds_fence();                                                                      \
         }                                                                                          \
         now.valid = false;                                                                         \
