@@ -234,9 +234,18 @@ __global__ __launch_bounds__(kScanBlock) void scan_sums_kernel(ScanJobs jobs) {
     if ((int)blockIdx.x * kScanChunk >= job.len && blockIdx.x > 0) return;   // beyond this view's launch bound
     const int base = blockIdx.x * kScanChunk + threadIdx.x * kScanPerThread;
     int s = 0;
+    if (base + kScanPerThread <= len) {            // the thread's 16 values as four 16-byte loads (64-byte aligned)
+        const int4 *q = reinterpret_cast<const int4 *>(in + base);
 #pragma unroll
-    for (int k = 0; k < kScanPerThread; ++k)
-        if (base + k < len) s += scan_value(in[base + k], match);
+        for (int k = 0; k < kScanPerThread / 4; ++k) {
+            const int4 x = q[k];
+            s += scan_value(x.x, match) + scan_value(x.y, match) + scan_value(x.z, match) + scan_value(x.w, match);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < kScanPerThread; ++k)
+            if (base + k < len) s += scan_value(in[base + k], match);
+    }
     int tot;
     block_exclusive_scan(s, &tot);
     if (threadIdx.x == 0) sums[blockIdx.x] = tot;
@@ -271,21 +280,52 @@ __global__ __launch_bounds__(kScanBlock) void scan_apply_kernel(ScanJobs jobs) {
     const int base = blockIdx.x * kScanChunk + threadIdx.x * kScanPerThread;
     int v[kScanPerThread];
     int s = 0;
+    const bool whole = base + kScanPerThread <= len;      // 16 values = four 16-byte loads / stores (64-byte aligned)
+    if (whole) {
+        int4 *q = reinterpret_cast<int4 *>(in + base);
 #pragma unroll
-    for (int k = 0; k < kScanPerThread; ++k) {
-        v[k] = base + k < len ? scan_value(in[base + k], match) : 0;
-        if (zero_in && base + k < len) in[base + k] = 0;
-        s += v[k];
+        for (int k = 0; k < kScanPerThread / 4; ++k) {
+            const int4 x = q[k];
+            v[4 * k] = scan_value(x.x, match);
+            v[4 * k + 1] = scan_value(x.y, match);
+            v[4 * k + 2] = scan_value(x.z, match);
+            v[4 * k + 3] = scan_value(x.w, match);
+            if (zero_in) q[k] = make_int4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < kScanPerThread; ++k) s += v[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < kScanPerThread; ++k) {
+            v[k] = base + k < len ? scan_value(in[base + k], match) : 0;
+            if (zero_in && base + k < len) in[base + k] = 0;
+            s += v[k];
+        }
     }
     int tot;
     int run = block_exclusive_scan(s, &tot) + sums[blockIdx.x];
+    if (whole) {
+        int4 *o = reinterpret_cast<int4 *>(out + base), *o2 = out2 ? reinterpret_cast<int4 *>(out2 + base) : nullptr;
 #pragma unroll
-    for (int k = 0; k < kScanPerThread; ++k) {
-        if (base + k < len) {
-            out[base + k] = run;
-            if (out2) out2[base + k] = run;
+        for (int k = 0; k < kScanPerThread / 4; ++k) {
+            int4 r;
+            r.x = run;
+            r.y = r.x + v[4 * k];
+            r.z = r.y + v[4 * k + 1];
+            r.w = r.z + v[4 * k + 2];
+            run = r.w + v[4 * k + 3];
+            o[k] = r;
+            if (o2) o2[k] = r;
         }
-        run += v[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < kScanPerThread; ++k) {
+            if (base + k < len) {
+                out[base + k] = run;
+                if (out2) out2[base + k] = run;
+            }
+            run += v[k];
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         out[len] = sums[nb];
