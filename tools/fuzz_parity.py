@@ -1,5 +1,6 @@
 """Randomised parity soak: random small clouds, radii, histogram shapes, forests, thresholds and NMS modes through
-libkpl and through the oracle; every score must match bit for bit and every keypoint list exactly.
+libkpl and through the oracle; every score must match bit for bit and every keypoint list exactly.  Every 25th case also
+runs a random organized depth image (steps, holes, non-finite x) through the integral-image normal estimation.
     python tools/fuzz_parity.py [seconds] [seed]
 """
 import importlib
@@ -71,6 +72,35 @@ def batch_case(kpl, rng):
         if not (helpers.same_bits(ds.cpu().numpy()[:n], o_sc) and np.array_equal(dk[1:1 + cnt].cpu().numpy(), o_kp)):
             return False
     return True
+
+
+def organized_case(det, rng):
+    """a random depth image (smooth surface + random steps, NaN holes, NaN columns) through
+    kpl_estimate_normals_organized and through the oracle's pcl::IntegralImageNormalEstimation restatement"""
+    W, H = int(rng.integers(1, 180)), int(rng.integers(1, 140))
+    v, u = np.mgrid[0:H, 0:W].astype(np.float32)
+    z = (rng.uniform(0.5, 5.0) + rng.uniform(-0.01, 0.01) * u + rng.uniform(-0.01, 0.01) * v +
+         rng.uniform(0, 0.2) * np.sin(u / rng.uniform(2, 12)) * np.cos(v / rng.uniform(2, 12))).astype(np.float32)
+    for _ in range(int(rng.integers(0, 4))):           # depth steps
+        c = int(rng.integers(0, max(W, 1)))
+        z[:, c:] += np.float32(rng.uniform(-1.0, 1.0))
+    xyz = np.stack([(u - W / 2) * z / 300.0, (v - H / 2) * z / 300.0, z], -1).astype(np.float32)
+    for _ in range(int(rng.integers(0, 30))):          # holes
+        r, c = int(rng.integers(0, H)), int(rng.integers(0, W))
+        xyz[r:r + int(rng.integers(1, 5)), c:c + int(rng.integers(1, 5))] = np.nan
+    if rng.random() < 0.2:
+        xyz[:, :, 0] = np.where(rng.random((H, W)) < 0.02, np.inf, xyz[:, :, 0])      # x not finite, z finite
+    xyz = xyz.reshape(-1, 3)
+    smoothing = float(rng.choice([2.5, 3.5, 5.0, 7.0, 10.0]))
+    vp = tuple(float(x) for x in rng.uniform(-3, 3, size=3)) if rng.random() < 0.5 else (0.0, 0.0, 0.0)
+    nrm, curv = det.estimateNormalsOrganized(xyz, W, H, smoothing, vp)
+    o_nrm, _ = kplo.integral_image_normals(xyz, W, H, smoothing, vp)
+    nan_a, nan_b = np.isnan(nrm), np.isnan(o_nrm)
+    ok = np.array_equal(nan_a, nan_b) and np.array_equal(nrm.view(np.uint32)[~nan_a], o_nrm.view(np.uint32)[~nan_b]) and \
+        bool(np.isnan(curv).all())
+    if not ok:
+        np.savez("fuzz_failure.npz", xyz=xyz, W=W, H=H, smoothing=smoothing, vp=np.float32(vp))
+    return ok
 
 
 def main():
@@ -152,6 +182,9 @@ def main():
                 np.savez("fuzz_failure.npz", xyz=xyz, k=k, r=r)
                 print("MISMATCH in normals / resolution: case %d kind %d n %d k %d r %g -> fuzz_failure.npz" % (cases, kind, n, k, r))
                 return 1
+        if cases % 25 == 24 and not organized_case(det, rng):
+            print("MISMATCH in the normals of an organized cloud after case %d -> fuzz_failure.npz" % cases)
+            return 1
         if cases % 40 == 39 and not batch_case(kpl, rng):
             print("MISMATCH in a batched call after case %d" % cases)
             return 1
