@@ -60,6 +60,15 @@ def build(force=False, verbose=False):
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
+    # stand-alone HIP diagnostics (not part of libkpl): the VALU issue-ceiling microbenchmark behind bench.py's
+    # `valu_issue_frac` (tools/valu_ceiling.hip -> profiles/*_valu_ceiling.json)
+    vsrc = os.path.join(HERE, "..", "tools", "valu_ceiling.hip")
+    vexe = os.path.join(HERE, "..", "tools", "valu_ceiling")
+    if os.path.exists(vsrc) and (force or _stale(vexe, [vsrc])):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-o", vexe, vsrc]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
     return LIB
 
 

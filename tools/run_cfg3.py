@@ -37,6 +37,9 @@ def main():
     ap.add_argument("--rounds", type=int, default=20, help="timed repetitions of the whole 64-view job")
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--parity-all", action="store_true", help="rank 0 checks ALL its views against the oracle, not the first 4")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="world size 1: create the process group anyway, so that the all-gather (RCCL) runs on one GPU")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -45,8 +48,13 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
     if not torch.cuda.is_available():
         raise SystemExit("needs a HIP device (no CPU fallback)")
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
@@ -86,7 +94,7 @@ def main():
                                      [packed[i, 1:].data_ptr() for i in idx], [n] * len(idx),
                                      [packed[i, 0:1].data_ptr() for i in idx], st.cuda_stream)
         torch.cuda.synchronize()
-        if world > 1:                        # the one exchange step: every rank's packed lists, one all-gather
+        if use_dist:                         # the one exchange step: every rank's packed lists, one all-gather
             send = packed[:, :cap + 1].contiguous().view(-1)
             gathered[0] = kd.gather_keypoints(send if args.backend == "nccl" else send.cpu())
 
@@ -100,23 +108,23 @@ def main():
         from tools import forest_yaml
         of = helpers.oracle_forest(forest_yaml.load_forest(FOREST))
         ok = True
-        for i, (xyz, nrm, mr) in enumerate(host[:4]):
+        for i, (xyz, nrm, mr) in enumerate(host if args.parity_all else host[:4]):
             o_sc, o_kp = kplo.detect(xyz, nrm, A, B, float(np.float32(6 * mr)), float(np.float32(4 * mr)), thr, of,
                                      threads=helpers.usable_cores())
             ok &= bool(np.array_equal(bufs[i][2].cpu().numpy().view(np.uint32), o_sc.view(np.uint32)))
             ok &= bool(np.array_equal(packed[i, 1:1 + int(packed[i, 0])].cpu().numpy(), o_kp))
         parity = ok
         assert ok, "PARITY FAILURE vs oracle"
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.rounds):
         job()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     el = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([el], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
@@ -129,8 +137,10 @@ def main():
                           "makespan_ms_per_job": round(el * 1e3 / args.rounds, 4),
                           "Mpoints_per_s": round(args.views * n * args.rounds / el / 1e6, 2),
                           "views_per_rank": len(mine), "exchange": "one all-gather of %d x %d int32 per job" %
-                          (world * len(mine), cap + 1) if world > 1 else "none", "parity_first_4_views_rank0": parity}))
-    if world > 1:
+                          (world * len(mine), cap + 1) if use_dist else "none", "backend": args.backend if use_dist else None,
+                          "parity_first_4_views_rank0": parity,
+                          "views_checked_against_oracle": (len(host) if args.parity_all else min(4, len(host))) if parity is not None else 0}))
+    if use_dist:
         dist.destroy_process_group()
 
 
