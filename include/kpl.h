@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define KPL_VERSION 120
+#define KPL_VERSION 130
 
 typedef enum kpl_status {
     KPL_OK = 0,
@@ -58,7 +58,23 @@ typedef struct kpl_params {
     int non_maxima_draws_remove;      /* setNonMaximaDrawsRemove, default 1                   */
     float non_maxima_draws_threshold; /* setNonMaximaDrawsThreshold (uninitialised in the
                                          reference ctor; 0 here)                              */
+    int neighbor_order;               /* pcl::Keypoint::setSearchMethod (inherited,
+                                         /root/reference/include/KeypointLearning.h:56): the order in which
+                                         the feature loop (impl/KeypointLearning.hpp:334-359) meets the
+                                         neighbors; element 0 of it is dropped (:336).  See below.        */
 } kpl_params;
+
+/* kpl_params::neighbor_order.  The neighbor SET is the same in both (strict d2 < (float)(r*r)); the order
+ * decides which neighbor hpp:336 drops and the order of the float additions of the histogram.
+ *   CANONICAL  ascending (grid cell id, point index): this engine's deterministic stand-in for the traversal
+ *              order of the default pcl::search::KdTree(false) -> FLANN, which cannot be reproduced without
+ *              FLANN.  Default.
+ *   SORTED     ascending (squared distance, point index): exactly what a caller gets who passes a
+ *              pcl::search::KdTree constructed with sorted = true to setSearchMethod (FLANN sorts its radius
+ *              result set by (distance, index)).  Element 0 is then the query itself (or a duplicate of it with a
+ *              lower index).  This is the order in which results can be compared bit for bit with a PCL build of
+ *              the reference.  About 2-3x the cost of CANONICAL (per-point sort of the neighbor list). */
+enum { KPL_NEIGHBORS_CANONICAL = 0, KPL_NEIGHBORS_SORTED = 1 };
 
 /* Counters for the algorithmic-bytes model of SURVEY.md 8(d), filled by kpl_collect_stats. */
 typedef struct kpl_stats {

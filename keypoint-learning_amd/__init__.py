@@ -19,6 +19,9 @@ OK, ERR_INVALID_ARG, ERR_NO_FOREST, ERR_FOREST_PARSE, ERR_VAR_COUNT, ERR_GRID_TO
     ERR_CAPACITY, ERR_DEVICE, ERR_UNSUPPORTED, ERR_IO, ERR_NO_CLOUD, ERR_RETRY = range(12)
 
 
+NEIGHBORS_CANONICAL, NEIGHBORS_SORTED = 0, 1      # kpl_params.neighbor_order
+
+
 class KplError(RuntimeError):
     def __init__(self, status, message):
         super().__init__("kpl status %d: %s" % (status, message))
@@ -29,7 +32,7 @@ class Params(C.Structure):
     _fields_ = [("n_annulus", C.c_int), ("n_bins", C.c_int), ("radius_search", C.c_double),
                 ("non_max_radius", C.c_double), ("prediction_th", C.c_double),
                 ("non_maxima", C.c_int), ("non_maxima_draws_remove", C.c_int),
-                ("non_maxima_draws_threshold", C.c_float)]
+                ("non_maxima_draws_threshold", C.c_float), ("neighbor_order", C.c_int)]
 
 
 class ForestSummary(C.Structure):
@@ -251,6 +254,11 @@ class KeypointLearningDetector:
 
     def setRadiusSearch(self, r):
         self._p.radius_search = r
+
+    def setSortedSearch(self, on=True):
+        """pcl::Keypoint::setSearchMethod with a pcl::search::KdTree(sorted = on): the feature loop meets the
+        neighbors in ascending (squared distance, index) order instead of the engine's canonical order."""
+        self._p.neighbor_order = NEIGHBORS_SORTED if on else NEIGHBORS_CANONICAL
 
     def loadForest(self, path):
         rc = self._lib.kpl_load_forest_file(self._h, os.fsencode(path))

@@ -149,6 +149,7 @@ FeatDesc make_feat(const kpl_params &p) {
     f.bin_rdim = 1.0f / f.bin_dim;
     f.r2 = (float)(p.radius_search * p.radius_search);
     f.rr = (float)(p.radius_search * (1.0 + 1.0 / 1024.0));
+    f.sorted = p.neighbor_order == KPL_NEIGHBORS_SORTED ? 1 : 0;
     return f;
 }
 
@@ -174,6 +175,8 @@ int check_params_for_compute(kpl_detector *h, bool need_forest) {
         return fail(h, KPL_ERR_UNSUPPORTED, "n_annulus * n_bins must be <= 255");
     if (!(p.non_max_radius >= 0.0) || !std::isfinite(p.non_max_radius))
         return fail(h, KPL_ERR_INVALID_ARG, "non_max_radius must be >= 0");
+    if (p.neighbor_order != KPL_NEIGHBORS_CANONICAL && p.neighbor_order != KPL_NEIGHBORS_SORTED)
+        return fail(h, KPL_ERR_INVALID_ARG, "neighbor_order must be KPL_NEIGHBORS_CANONICAL or KPL_NEIGHBORS_SORTED");
     if (need_forest) {
         if (!h->has_forest) return fail(h, KPL_ERR_NO_FOREST, "no forest loaded");
         if (p.n_annulus * p.n_bins != h->flat.var_count)
@@ -583,6 +586,7 @@ void kpl_default_params(kpl_params *p) {
     p->non_maxima = 1;
     p->non_maxima_draws_remove = 1;
     p->non_maxima_draws_threshold = 0.0f;
+    p->neighbor_order = KPL_NEIGHBORS_CANONICAL;
 }
 
 int kpl_create(kpl_detector **out, int device) {
@@ -816,8 +820,8 @@ int kpl_compute_features_device(kpl_detector *h, const int *d_indices, int m, fl
     hipStream_t st = (hipStream_t)stream;
     rc = ensure_index(h, st);
     if (rc) return rc;
-    launch_features(h->pts.as<float4>(), h->nrm.as<float4>(), h->cell_start.as<int>(), h->pos_of.as<int>(),
-                    h->dstate.as<DevState>(), make_feat(h->prm), d_indices, m, h->n, d_features, st);
+    launch_features(h->pts.as<float4>(), h->nrm.as<float4>(), h->d_nrm, (unsigned)h->ns, h->cell_start.as<int>(),
+                    h->pos_of.as<int>(), h->dstate.as<DevState>(), make_feat(h->prm), d_indices, m, h->n, d_features, st);
     KPL_HIP(h, hipGetLastError());
     return KPL_OK;
 }

@@ -37,6 +37,7 @@ struct FeatDesc {
     float bin_rdim;
     float r2;        // (float)(r*r), product in double -- KdTreeFLANN::radiusSearch
     float rr;        // (float)(r*(1+2^-10)): half width of the cell box that is searched
+    int sorted;      // neighbor order of the feature loop: 0 = canonical (cell id, index), 1 = ascending (d2, index)
 };
 
 struct NmsDesc {
@@ -151,7 +152,8 @@ size_t feat_bytes(int n, int F);
 // consecutive candidates from one address, so the array carries that many elements of tail
 size_t pts_bytes(int n);
 // features of listed points -> out[m*F]
-void launch_features(const float4 *pts, const float4 *nrm, const int *cell_start,
+// (nrmsrc / ns: the caller's normals in original point order and their byte stride -- read by the sorted-search mode)
+void launch_features(const float4 *pts, const float4 *nrm, const char *nrmsrc, unsigned ns, const int *cell_start,
                      const int *pos_of, const DevState *ds, FeatDesc f, const int *query, int m, int n,
                      float *out, hipStream_t st);
 

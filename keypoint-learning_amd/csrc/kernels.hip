@@ -1102,6 +1102,332 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts, co
     return kf;
 }
 
+// ---------------------------------------------------------------------------------------------
+// SORTED-search mode (FeatDesc::sorted): computePointFeatures with the neighbors in ascending (squared
+// distance, index) order -- what the feature loop (hpp:334-359) sees when the caller has handed a
+// pcl::search::KdTree constructed with sorted = true to the inherited pcl::Keypoint::setSearchMethod
+// (/root/reference/include/KeypointLearning.h:56): KdTreeFLANN asks FLANN for sorted results, FLANN sorts its
+// RadiusResultSet with DistanceIndex::operator< (distance, then index).  Element 0 of that order -- the query
+// itself unless a duplicate of it has a lower index -- is dropped by hpp:336.  It is the one neighbor order
+// that is defined without FLANN's tree layout, i.e. the one order in which this engine can be compared bit for
+// bit with a PCL run.  The neighbor SET is the canonical mode's; only the order of the float additions differs.
+//
+// kSortGroup = 4 lanes per point, 16 points per wave.  Per wave and pass:
+//   search   as in point_features: accept words of 32 candidates -> the point's small word list in LDS
+//   collect  every accepted neighbor's key (d2 bits << 32 | original index: d2 >= +0, so the unsigned order of
+//            the keys IS ascending (d2, index)) -> the point's key list in LDS, lcap keys per point
+//   sort     bitonic network over the key lists, all comparators ascending (the first step of a merge pairs
+//            i with its mirror image), so that the virtual padding of a list to the power of two above the
+//            longest list of the wave never moves: comparators that touch it are skipped
+//   add      the keys in order, 4 per round: normal of the neighbor from the caller's array (by original
+//            index), contribution from the d2 in the key, the 4 histogram updates lane after lane (hpp:350-355)
+// A neighborhood with more than lcap points takes several passes, each over a window [lo, hi) of keys: when a
+// list is full it is sorted, its smaller half kept and hi lowered to the first key dropped; the pass then ends
+// with exactly the keys of [lo, hi), they are added, and the next pass starts at lo = last key + 1.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSortGroup = 4;
+constexpr int kSortWords = 8;        // accept words per point between two collect rounds
+
+template <int G>
+__host__ __device__ inline size_t sorted_lds_bytes(int F, int ecap, int lcap) {
+    return (sizeof(float) * (size_t)F + sizeof(uint2) * (size_t)ecap + sizeof(unsigned long long) * (size_t)lcap) * (size_t)(kLanes / G);
+}
+
+// the rows of cells of a point's search box, walked by the G lanes of its group together (the search phase of
+// point_features as an object: the sorted mode restarts it for every pass)
+template <int G>
+struct RowSearch {
+    static constexpr int kStepBits = kStepW * G, kSteps = 32 / kStepBits;
+    const float4 *__restrict__ pts;
+    const int *__restrict__ cell_start;
+    const GridDesc *g;
+    CellBox b;
+    int ny, nz, wny, wnz, t_max, mine, nib_shift;
+    float4 p;
+    float r2;
+    int ky, kz, n0, n1, t, t1;
+    bool slots_left;
+    Cand pre;
+
+    __device__ __forceinline__ void row_range(int ky_, int kz_, int &r0, int &r1) const {
+        const bool valid = (ky_ < ny) & (kz_ < nz);
+        const int row = valid ? ((b.lo[2] + kz_) * g->dims[1] + b.lo[1] + ky_) * g->dims[0] : 0;
+        const int x = ld4(cell_start, row + (valid ? b.lo[0] : 0));
+        const int y = ld4(cell_start, row + (valid ? b.hi[0] + 1 : 0));
+        r0 = valid ? x : 0;
+        r1 = valid ? y : 0;
+    }
+    __device__ __forceinline__ void init(const float4 *pts_, const int *cell_start_, const GridDesc &g_, float4 p_, float rr,
+                                         float r2_, bool active, int gq) {
+        pts = pts_;
+        cell_start = cell_start_;
+        g = &g_;
+        p = p_;
+        r2 = r2_;
+        b = make_box(g_, p.x, p.y, p.z, rr);
+        b.hi[1] = min(b.hi[1], b.lo[1] + 3);
+        b.hi[2] = min(b.hi[2], b.lo[2] + 3);
+        ny = active ? b.hi[1] - b.lo[1] + 1 : 0;
+        nz = active ? b.hi[2] - b.lo[2] + 1 : 0;
+        wny = __any(ny > 3) ? 4 : __any(ny > 2) ? 3 : __any(ny > 1) ? 2 : __any(ny > 0) ? 1 : 0;
+        wnz = __any(nz > 3) ? 4 : __any(nz > 2) ? 3 : __any(nz > 1) ? 2 : __any(nz > 0) ? 1 : 0;
+        t_max = max(cell_start[g_.ncells] - 1, 0);
+        mine = kStepW * gq;
+        nib_shift = 4 * (G - 1 - gq);
+        restart();
+    }
+    __device__ __forceinline__ void restart() {
+        ky = kz = 0;
+        slots_left = wny > 0 && wnz > 0;
+        n0 = n1 = 0;
+        if (slots_left) row_range(0, 0, n0, n1);
+        t = t1 = 0;
+        pre = load_cand(pts, 0);
+    }
+    __device__ __forceinline__ bool exhausted() const { return !slots_left && !__any(t < t1); }
+    // the next 32 candidates of the point's rows: position of the first one and the accept bits (first candidate
+    // = highest bit; 0 where the row had ended for this point); false when every point's rows are used up
+    __device__ __forceinline__ bool next_word(int &wbase, unsigned &w) {
+        while (!__any(t < t1)) {
+            if (!slots_left) return false;
+            t = n0;
+            t1 = n1;
+            pre = load_cand(pts, min(t + mine, t_max));
+            if (++ky == wny) {
+                ky = 0;
+                ++kz;
+            }
+            slots_left = kz < wnz;
+            if (slots_left) row_range(ky, kz, n0, n1);
+        }
+        wbase = t;
+        w = 0u;
+#pragma unroll
+        for (int r = 0; r < kSteps / 2; ++r) {
+            Cand nxt = load_cand(pts, min(t + kStepBits + mine, t_max));
+            w = (w << kStepBits) | group_or<G>(search_step(0u, p, pre, r2) << nib_shift);
+            pre = load_cand(pts, min(t + 2 * kStepBits + mine, t_max));
+            w = (w << kStepBits) | group_or<G>(search_step(0u, p, nxt, r2) << nib_shift);
+            t += 2 * kStepBits;
+            if (r + 1 < kSteps / 2 && !__any(t < t1)) {
+                w <<= 32 - 2 * kStepBits * (r + 1);
+                break;
+            }
+        }
+        const int nv = min(max(t1 - wbase, 0), 32);
+        w = nv > 0 ? (w & (0xffffffffu << ((32 - nv) & 31))) : 0u;
+        return true;
+    }
+};
+
+// ascending sort of every point's key list (keys[e * kPts + point], cnt keys) by the G lanes of its group;
+// nmax = a power of two >= the longest list of the wave
+template <int G>
+__device__ __forceinline__ void sort_key_lists(unsigned long long *keys, int pi, int gq, int cnt, int nmax) {
+    constexpr int kPts = kLanes / G;
+    auto exchange = [&](int i, int l) {          // i < l; a comparator that touches the padding (l >= cnt) is a no-op
+        if (l < cnt) {
+            const unsigned long long a = keys[i * kPts + pi], c = keys[l * kPts + pi];
+            if (c < a) {
+                keys[i * kPts + pi] = c;
+                keys[l * kPts + pi] = a;
+            }
+        }
+    };
+    wave_lds_fence();
+    for (int k = 2; k <= nmax; k <<= 1) {
+        const int half = k >> 1;
+        for (int pr = gq; pr < nmax / 2; pr += G) {              // merge step 1: i against its mirror image in the block of k
+            const int blk = pr / half * k, off = pr & (half - 1);
+            exchange(blk + off, blk + k - 1 - off);
+        }
+        wave_lds_fence();
+        for (int j = half >> 1; j > 0; j >>= 1) {
+            for (int pr = gq; pr < nmax / 2; pr += G) {
+                const int i = ((pr & ~(j - 1)) << 1) | (pr & (j - 1));
+                exchange(i, i + j);
+            }
+            wave_lds_fence();
+        }
+    }
+}
+
+template <int G>
+__device__ __forceinline__ int point_features_sorted(const float4 *__restrict__ pts, const char *__restrict__ nrmsrc,
+                                                     unsigned ns, const int *__restrict__ cell_start, const GridDesc &g,
+                                                     const FeatDesc &fin, float4 p, float4 np, float *H, uint2 *ent, int ecap,
+                                                     unsigned long long *keys, int lcap, bool active) {
+    constexpr int kPts = kLanes / G;
+    const int tid = threadIdx.x, pi = tid / G, gq = tid % G;
+    FeatDesc f;
+    f.A = pin_i(fin.A);
+    f.B = pin_i(fin.B);
+    f.F = pin_i(fin.F);
+    f.support = fin.support;
+    f.ann_dim = pin_f(fin.ann_dim);
+    f.ann_half = pin_f(fin.ann_half);
+    f.ann_rdim = pin_f(fin.ann_rdim);
+    f.bin_dim = pin_f(fin.bin_dim);
+    f.bin_half = pin_f(fin.bin_half);
+    f.bin_rdim = pin_f(fin.bin_rdim);
+    f.r2 = pin_f(fin.r2);
+    f.rr = fin.rr;
+    for (int c = gq; c < f.F; c += G) H[c * kPts + pi] = 0.0f;                     // hpp:325
+    RowSearch<G> rs;
+    rs.init(pts, cell_start, g, p, f.rr, f.r2, active, gq);
+    const int ent_last = (ecap - 1) * kPts + pi;
+    const int col_address = lds_address(H + pi);
+    const unsigned group_shift = (unsigned)(tid & ~(G - 1));
+    unsigned long long lo = 0ull, hi = ~0ull;      // this pass collects the keys of [lo, hi)
+    int kf = 0;
+    for (int pass = 0;; ++pass) {
+        int cnt = 0;                               // keys in the point's list (the same in the lanes of the group)
+        bool trunc = false;                        // the list was cut: keys >= hi are left for the next pass
+        rs.restart();
+        for (;;) {
+            // ---- search: accept words of the point
+            int ecnt = 0;
+            bool full = false;
+            while (!full) {
+                int wbase;
+                unsigned w;
+                if (!rs.next_word(wbase, w)) break;
+                if (pass == 0) kf += __popc(w);
+                if (w != 0u) {
+                    if (gq == 0) ent[ecnt * kPts + pi] = make_uint2((unsigned)wbase, w);
+                    ++ecnt;
+                }
+                full = __any(ecnt == ecap);
+            }
+            // ---- collect: G accepted neighbors of the point per round -> keys
+            if (__any(ecnt > 0)) {
+                wave_lds_fence();
+                int e = 0;
+                unsigned w = 0u;
+                int wbase = 0;
+                uint2 nw = ent[pi];
+                struct Taken {
+                    bool valid;
+                    float4 q;
+                };
+                auto take = [&](Taken &slot) {
+                    const bool refill = (w == 0u) & (e < ecnt);
+                    w = refill ? nw.y : w;
+                    wbase = refill ? (int)nw.x : wbase;
+                    e += refill ? 1 : 0;
+                    nw = ent[min(e * kPts + pi, ent_last)];
+                    const unsigned c1 = drop_first_bit(w), c2 = drop_first_bit(c1), c3 = drop_first_bit(c2);
+                    unsigned m;
+                    if (G == 2) {
+                        m = gq == 0 ? w : c1;
+                        w = c2;
+                    } else {
+                        m = gq == 0 ? w : gq == 1 ? c1 : gq == 2 ? c2 : c3;
+                        w = drop_first_bit(c3);
+                    }
+                    slot.valid = m != 0u;
+                    const int tt = slot.valid ? wbase + (__clz((int)m) & 31) : 0;
+                    slot.q = pts[tt];
+                };
+                auto collect = [&](Taken &now) {
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(dist2(p.x, p.y, p.z, now.q)) << 32) |
+                                                   (unsigned long long)(unsigned)__float_as_int(now.q.w);
+                    bool app = now.valid & (key >= lo) & (key < hi);
+                    unsigned gb = (unsigned)(__ballot(app) >> group_shift) & ((1u << G) - 1u);
+                    while (__any(cnt + __popc(gb) > lcap)) {
+                        // a list is full: sort, keep the smaller half, lower hi to the first key that is dropped
+                        sort_key_lists<G>(keys, pi, gq, cnt, lcap);
+                        if (cnt + __popc(gb) > lcap) {
+                            cnt = lcap / 2;
+                            hi = keys[cnt * kPts + pi];
+                            trunc = true;
+                        }
+                        app = app & (key < hi);
+                        gb = (unsigned)(__ballot(app) >> group_shift) & ((1u << G) - 1u);
+                        wave_lds_fence();
+                    }
+                    if (app) keys[(cnt + __popc(gb & ((1u << gq) - 1u))) * kPts + pi] = key;
+                    cnt += __popc(gb);
+                    now.valid = false;
+                };
+                Taken pa, pb;
+                pa.valid = pb.valid = false;
+                pa.q = pb.q = make_float4(0.f, 0.f, 0.f, 0.f);
+                do {
+                    take(pb);
+                    collect(pa);
+                    take(pa);
+                    collect(pb);
+                } while (__any((w != 0u) | (e < ecnt) | pa.valid | pb.valid));
+            }
+            if (rs.exhausted()) break;
+        }
+        // ---- sort the lists; nmax = power of two >= the longest list of the wave
+        int nmax = 2;
+        while (__any(nmax < cnt)) nmax <<= 1;
+        sort_key_lists<G>(keys, pi, gq, cnt, nmax);
+        // ---- add the neighbors in order, G per round; hpp:336: element 0 of the whole order is dropped
+        {
+            struct Next {
+                bool valid;
+                float d2;
+                f32x3 n;
+            };
+            int k = pass == 0 ? 1 : 0;
+            const int key_last = (lcap - 1) * kPts + pi;
+            auto take = [&](Next &slot) {
+                const int idx = k + gq;
+                slot.valid = idx < cnt;
+                const unsigned long long key = keys[min(idx * kPts + pi, key_last)];
+                k += G;
+                slot.d2 = __uint_as_float((unsigned)(key >> 32));
+                const unsigned orig = slot.valid ? (unsigned)key : 0u;
+                slot.n = *reinterpret_cast<const f32x3 *>(nrmsrc + (size_t)orig * ns);
+            };
+            Next pa, pb;
+            pa.valid = pb.valid = false;
+            pa.d2 = pb.d2 = 0.f;
+            pa.n = pb.n = f32x3{0.f, 0.f, 0.f};
+#define KPL_SORTED_ROUND(now, nxt)                                                                 \
+    {                                                                                              \
+        take(nxt);                                                                                 \
+        const bool has_ = now.valid & finite3(now.n.x, now.n.y, now.n.z);          /* hpp:338 */  \
+        Contribution c_;                                                                           \
+        if (has_) c_ = neighbor_contribution<kPts>(f, now.d2, np, now.n, col_address);             \
+        _Pragma("unroll") for (int sub_ = 0; sub_ < G; ++sub_) {                                   \
+            if (has_ & (gq == sub_)) apply_contribution(c_, request_cells(c_));                    \
+            wave_lds_fence();                                                                      \
+        }                                                                                          \
+        now.valid = false;                                                                         \
+    }
+            do {
+                KPL_SORTED_ROUND(pa, pb)
+                KPL_SORTED_ROUND(pb, pa)
+            } while (__any((k - G < cnt) | pa.valid | pb.valid));
+#undef KPL_SORTED_ROUND
+        }
+        if (!__any(trunc)) break;
+        // the next pass: the keys above the last one added; a point that is done collects nothing any more
+        lo = trunc ? keys[(cnt - 1) * kPts + pi] + 1ull : ~0ull;
+        hi = ~0ull;
+        wave_lds_fence();
+    }
+    wave_lds_fence();
+    for (int a = gq; a < f.A; a += G) {                                            // hpp:360-370, one row per lane
+        float *h = H + (a * f.B) * kPts + pi;
+        float s = 0.0f;
+        for (int k = 0; k < f.B; ++k) {
+            float v = h[k * kPts];
+            s += v * v;
+        }
+        const float nr = sqrtf(s);
+        if (nr > 0)
+            for (int k = 0; k < f.B; ++k) h[k * kPts] = h[k * kPts] / nr;
+    }
+    wave_lds_fence();
+    return kf;
+}
+
 // runForest, hpp:267-296 + cv::ml::RTrees::predict(PREDICT_SUM) restated (hpp:281): per tree
 // walk "val <= thr ? left : right", double sum of leaf values in tree order, (float)sum,
 // score = 1 - sum / (T * 1.0f).  Several trees are walked at once per lane so that several
@@ -1400,6 +1726,7 @@ __global__ __launch_bounds__(kLanes) void feature_kernel(Batch b, int maxF, int 
     extern __shared__ float H[];
     constexpr int kPts = kLanes / kGroup;
     const ViewDev &v = b.view[blockIdx.y];
+    if (v.f.sorted) return;                                           // scored by feature_sorted_kernel
     const int chunk = blockIdx.x / kGroup, pi = threadIdx.x / kGroup, gq = threadIdx.x % kGroup;
     const int col = (blockIdx.x % kGroup) * kPts + pi;                // the point's column of the chunk's F x 64 block
     if (chunk * kLanes + col - pi >= v.n) return;
@@ -1411,6 +1738,27 @@ __global__ __launch_bounds__(kLanes) void feature_kernel(Batch b, int maxF, int 
     if (STATS && w.scoreable && gq == 0) atomicAdd(&v.stats->sum_kf, (unsigned long long)kf);
     float *o = v.feat + (size_t)chunk * v.f.F * kLanes + col;
     for (int c = gq; c < v.f.F; c += kGroup) o[c * kLanes] = H[c * kPts + pi];
+}
+
+// the same for the views in sorted-search mode: kSortGroup lanes per point, 64 / kSortGroup points per wave
+//   LDS: [H: maxF x 16 floats][accept words: ecap x 16 uint2][key lists: lcap x 16 keys of 8 bytes]
+template <bool STATS>
+__global__ __launch_bounds__(kLanes) void feature_sorted_kernel(Batch b, int maxF, int ecap, int lcap) {
+    extern __shared__ float H[];
+    constexpr int G = kSortGroup, kPts = kLanes / G;
+    const ViewDev &v = b.view[blockIdx.y];
+    if (!v.f.sorted) return;
+    const int chunk = blockIdx.x / G, pi = threadIdx.x / G, gq = threadIdx.x % G;
+    const int col = (blockIdx.x % G) * kPts + pi;
+    if (chunk * kLanes + col - pi >= v.n) return;
+    const WavePoint w = wave_point(v, chunk, col, true);
+    uint2 *ent = reinterpret_cast<uint2 *>(H + maxF * kPts);
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(ent + ecap * kPts);
+    const int kf = point_features_sorted<G>(v.pts, v.nrmsrc, v.ns, v.cell_start, v.ds->grid, v.f, w.p, w.np, H, ent, ecap,
+                                            keys, lcap, w.scoreable);
+    if (STATS && w.scoreable && gq == 0) atomicAdd(&v.stats->sum_kf, (unsigned long long)kf);
+    float *o = v.feat + (size_t)chunk * v.f.F * kLanes + col;
+    for (int c = gq; c < v.f.F; c += G) o[c * kLanes] = H[c * kPts + pi];
 }
 
 // Persistent workgroups of several waves: the workgroup stages the first nlds nodes of its view's
@@ -1571,6 +1919,35 @@ __global__ __launch_bounds__(kLanes) void features_kernel(const float4 *__restri
     if (qi >= m) return;
     float *o = out + (size_t)qi * f.F;
     for (int c = gq; c < f.F; c += kGroup) o[c] = s >= 0 ? H[c * kPts + pi] : NAN;
+}
+
+// the same in sorted-search mode (nrmsrc: the caller's normals in original order, byte stride ns)
+__global__ __launch_bounds__(kLanes) void features_sorted_kernel(const float4 *__restrict__ pts,
+                                                                 const float4 *__restrict__ nrm,
+                                                                 const char *__restrict__ nrmsrc, unsigned ns,
+                                                                 const int *__restrict__ cell_start,
+                                                                 const int *__restrict__ pos_of,
+                                                                 const DevState *__restrict__ ds, FeatDesc f,
+                                                                 const int *__restrict__ query, int m,
+                                                                 int n, int ecap, int lcap, float *__restrict__ out) {
+    extern __shared__ float H[];
+    constexpr int G = kSortGroup, kPts = kLanes / G;
+    uint2 *ent = reinterpret_cast<uint2 *>(H + f.F * kPts);
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(ent + ecap * kPts);
+    const GridDesc g = ds->grid;
+    const int pi = threadIdx.x / G, gq = threadIdx.x % G;
+    const int qi = blockIdx.x * kPts + pi;
+    int s = -1;
+    if (qi < m) {
+        const int i = query[qi];
+        s = (i >= 0 && i < n) ? pos_of[i] : -1;
+    }
+    const float4 p = s >= 0 ? pts[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 np = s >= 0 ? nrm[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+    point_features_sorted<G>(pts, nrmsrc, ns, cell_start, g, f, p, np, H, ent, ecap, keys, lcap, s >= 0);
+    if (qi >= m) return;
+    float *o = out + (size_t)qi * f.F;
+    for (int c = gq; c < f.F; c += G) o[c] = s >= 0 ? H[c * kPts + pi] : NAN;
 }
 
 // detectKeypoints, hpp:197-256 with draws_remove == false (order-independent predicate):
@@ -2249,6 +2626,14 @@ static int accept_words(int F) {
     return e;
 }
 
+// Keys per point of the sorted-search mode (a power of two; longer neighborhoods take several passes): 128 keys
+// = 16 KB per wave of 16 points, 7-8 waves per CU next to the histograms; 64 for the largest histograms
+static int sorted_list_keys(int F) {
+    int l = 128;
+    while (l > 32 && sorted_lds_bytes<kSortGroup>(F, kSortWords, l) * 6 > (size_t)kLdsPerCu) l >>= 1;
+    return l;
+}
+
 // Geometry of the forest kernel: one workgroup per CU; LDS = the top of the forest (at most
 // kForestNodeBytes) + one F x 64 float slice per wave, as many waves as then fit (2..16).
 constexpr size_t kForestLds = 156 * 1024, kForestNodeBytes = 64 * 1024;
@@ -2284,11 +2669,22 @@ void launch_feature_stage(const Batch &b, hipStream_t st) {
         maxF = b.view[v].f.F > maxF ? b.view[v].f.F : maxF;
         stats |= b.view[v].stats != nullptr;
     }
-    const int ecap = accept_words(maxF);
-    const size_t lds = feature_lds_bytes<kGroup>(maxF, ecap);
-    const dim3 grid(div_up(n, kLanes) * kGroup, b.nviews);
-    if (stats) feature_kernel<true><<<grid, kLanes, lds, st>>>(b, maxF, ecap);
-    else feature_kernel<false><<<grid, kLanes, lds, st>>>(b, maxF, ecap);
+    bool canonical = false, sorted = false;
+    for (int v = 0; v < b.nviews; ++v) (b.view[v].f.sorted ? sorted : canonical) = true;
+    if (canonical) {
+        const int ecap = accept_words(maxF);
+        const size_t lds = feature_lds_bytes<kGroup>(maxF, ecap);
+        const dim3 grid(div_up(n, kLanes) * kGroup, b.nviews);
+        if (stats) feature_kernel<true><<<grid, kLanes, lds, st>>>(b, maxF, ecap);
+        else feature_kernel<false><<<grid, kLanes, lds, st>>>(b, maxF, ecap);
+    }
+    if (sorted) {       // the views in sorted-search mode (each kernel skips the views of the other mode)
+        const int lcap = sorted_list_keys(maxF);
+        const size_t lds = sorted_lds_bytes<kSortGroup>(maxF, kSortWords, lcap);
+        const dim3 grid(div_up(n, kLanes) * kSortGroup, b.nviews);
+        if (stats) feature_sorted_kernel<true><<<grid, kLanes, lds, st>>>(b, maxF, kSortWords, lcap);
+        else feature_sorted_kernel<false><<<grid, kLanes, lds, st>>>(b, maxF, kSortWords, lcap);
+    }
 }
 
 // second kernel: feat -> forest response (score_sorted, scores) and the NMS candidates
@@ -2334,10 +2730,16 @@ void launch_forest_stage(const Batch &b, hipStream_t st) {
     else forest_kernel<false><<<fgrid, fl.waves * kLanes, fl.lds, st>>>(b, maxF, fl.nlds_cap);
 }
 
-void launch_features(const float4 *pts, const float4 *nrm, const int *cell_start,
+void launch_features(const float4 *pts, const float4 *nrm, const char *nrmsrc, unsigned ns, const int *cell_start,
                      const int *pos_of, const DevState *ds, FeatDesc f, const int *query, int m, int n,
                      float *out, hipStream_t st) {
     if (m <= 0) return;
+    if (f.sorted) {
+        const int lcap = sorted_list_keys(f.F);
+        features_sorted_kernel<<<div_up(m, kLanes / kSortGroup), kLanes, sorted_lds_bytes<kSortGroup>(f.F, kSortWords, lcap), st>>>(
+            pts, nrm, nrmsrc, ns, cell_start, pos_of, ds, f, query, m, n, kSortWords, lcap, out);
+        return;
+    }
     const int ecap = accept_words(f.F);
     features_kernel<<<div_up(m, kLanes / kGroup), kLanes, feature_lds_bytes<kGroup>(f.F, ecap), st>>>(pts, nrm, cell_start, pos_of, ds,
                                                                                                       f, query, m, n, ecap, out);

@@ -231,13 +231,93 @@ int kplo_radius_search(const kplo_grid *g, const float *xyz, int i, double radiu
     return cnt;
 }
 
+/* The same search with SORTED results: what the caller of the inherited
+ * pcl::Keypoint::setSearchMethod gets from a pcl::search::KdTree constructed with sorted = true
+ * (include/KeypointLearning.h:56 inherits the setter; call sites include/impl/KeypointLearning.hpp:213,
+ * :334).  KdTreeFLANN::radiusSearch then asks FLANN for sorted results, and FLANN (absent from
+ * /root/reference; published source, flann/util/result_set.h) sorts its RadiusResultSet with
+ * DistanceIndex::operator<: ascending distance, ties by ascending index.  The set is the same as in
+ * canonical order (strict d2 < r2, dist2() above); only the order differs.  This is the one neighbor
+ * order that is fully defined without FLANN's tree layout. */
+typedef struct {
+    float d2;
+    int idx;
+} sorted_item;
+
+static int sorted_item_cmp(const void *a, const void *b)
+{
+    const sorted_item *x = (const sorted_item *)a, *y = (const sorted_item *)b;
+    if (x->d2 < y->d2) return -1;
+    if (x->d2 > y->d2) return 1;
+    return (x->idx > y->idx) - (x->idx < y->idx);
+}
+
+/* all neighbors of point i, ascending (d2, index); *items is grown with realloc */
+static int sorted_neighbors(const kplo_grid *g, const float *xyz, int i, double radius,
+                            sorted_item **items, int *cap)
+{
+    const float *p = xyz + 3 * (size_t)i;
+    search_box b;
+    make_box(g, p, radius, &b);
+    int cnt = 0;
+    FOR_EACH_CANDIDATE(g, b, j, {
+        float d2 = dist2(p, xyz + 3 * (size_t)j);
+        if (d2 < b.r2) {
+            if (cnt == *cap) {
+                *cap = *cap ? *cap * 2 : 256;
+                *items = (sorted_item *)realloc(*items, sizeof(sorted_item) * (size_t)*cap);
+            }
+            (*items)[cnt].d2 = d2;
+            (*items)[cnt].idx = j;
+            ++cnt;
+        }
+    })
+    qsort(*items, (size_t)cnt, sizeof(sorted_item), sorted_item_cmp);
+    return cnt;
+}
+
+int kplo_radius_search_sorted(const kplo_grid *g, const float *xyz, int i, double radius,
+                              int *out_idx, float *out_d2, int cap)
+{
+    const float *p = xyz + 3 * (size_t)i;
+    if (!finite3(p) || g->ncells == 0) return 0;
+    sorted_item *items = NULL;
+    int icap = 0;
+    const int cnt = sorted_neighbors(g, xyz, i, radius, &items, &icap);
+    for (int k = 0; k < cnt && k < cap; ++k) {
+        if (out_idx) out_idx[k] = items[k].idx;
+        if (out_d2) out_d2[k] = items[k].d2;
+    }
+    free(items);
+    return cnt;
+}
+
+/* what one neighbor adds to the histogram, include/impl/KeypointLearning.hpp:338-355 */
+static inline void add_neighbor(const float *np, const float *nq, float d2, int A, int B, float support, float *H)
+{
+    if (!finite3(nq)) return;                  /* :338 */
+    /* :342  Eigen Vector3f::dot, unrolled as x + (y + z) */
+    float dot = np[0] * nq[0] + (np[1] * nq[1] + np[2] * nq[2]);
+    float cosine = 1 - dot;
+    int a, ap, bi, bp;
+    float aw, bw;
+    kplo_find_annulus_pair(A, sqrtf(d2), support, &a, &ap, &aw);   /* :345 */
+    kplo_find_bin_pair(B, cosine, &bi, &bp, &bw);                  /* :348 */
+    H[a * B + bi] += ((1 - bw) * (1 - aw));                        /* :350 */
+    H[a * B + bp] += ((bw) * (1 - aw));                            /* :351 */
+    H[ap * B + bi] += ((1 - bw) * (aw));                           /* :354 */
+    H[ap * B + bp] += ((bw) * (aw));                               /* :355 */
+}
+
 /* ------------------------------------------------------------------------------------------
  * computePointFeatures, include/impl/KeypointLearning.hpp:321-376.
  * H is A x B row-major (the reference's Eigen matrix is column-major; only (row, col)
  * addressing matters).  Returns K_f (neighbors found, including the dropped first one).
+ * order: KPLO_ORDER_CANONICAL = neighbors in the grid's canonical order, KPLO_ORDER_SORTED = ascending
+ * (d2, index).  Either way the loop starts at the SECOND neighbor (:336).
  * ---------------------------------------------------------------------------------------- */
 static int point_features(const kplo_grid *g, const float *xyz, const float *nrm, int i,
-                          int A, int B, double r_feat, float *H /* A*B */)
+                          int A, int B, double r_feat, int order, float *H /* A*B */)
 {
     const int F = A * B;
     for (int c = 0; c < F; ++c) H[c] = 0.0f;                       /* :325 */
@@ -247,26 +327,23 @@ static int point_features(const kplo_grid *g, const float *xyz, const float *nrm
     search_box b;
     make_box(g, p, r_feat, &b);
     int seen = 0;
+    if (order == KPLO_ORDER_SORTED) {
+        sorted_item *items = NULL;
+        int icap = 0;
+        seen = sorted_neighbors(g, xyz, i, r_feat, &items, &icap);            /* :334 */
+        for (int k = 1; k < seen; ++k)                                         /* :336 */
+            add_neighbor(np, nrm + 3 * (size_t)items[k].idx, items[k].d2, A, B, support, H);
+        free(items);
+    } else {
     FOR_EACH_CANDIDATE(g, b, j, {
         const float *q = xyz + 3 * (size_t)j;
         float d2 = dist2(p, q);
         if (d2 < b.r2) {
             if (seen++ == 0) continue;                 /* :336 loop starts at neigh_indx = 1 */
-            const float *nq = nrm + 3 * (size_t)j;
-            if (!finite3(nq)) continue;                /* :338 */
-            /* :342  Eigen Vector3f::dot, unrolled as x + (y + z) */
-            float dot = np[0] * nq[0] + (np[1] * nq[1] + np[2] * nq[2]);
-            float cosine = 1 - dot;
-            int a, ap, bi, bp;
-            float aw, bw;
-            kplo_find_annulus_pair(A, sqrtf(d2), support, &a, &ap, &aw);   /* :345 */
-            kplo_find_bin_pair(B, cosine, &bi, &bp, &bw);                  /* :348 */
-            H[a * B + bi] += ((1 - bw) * (1 - aw));                        /* :350 */
-            H[a * B + bp] += ((bw) * (1 - aw));                            /* :351 */
-            H[ap * B + bi] += ((1 - bw) * (aw));                           /* :354 */
-            H[ap * B + bp] += ((bw) * (aw));                               /* :355 */
+            add_neighbor(np, nrm + 3 * (size_t)j, d2, A, B, support, H);
         }
     })
+    }
     for (int a = 0; a < A; ++a) {                                          /* :360-370 */
         float s = 0.0f;
         for (int k = 0; k < B; ++k) s += H[a * B + k] * H[a * B + k];
@@ -281,6 +358,13 @@ void kplo_features(const kplo_grid *g, const float *xyz, const float *nrm, int n
                    int n_annulus, int n_bins, double r_feat,
                    const int *query, int m, float *feat_out)
 {
+    kplo_features_ordered(g, xyz, nrm, n, n_annulus, n_bins, r_feat, KPLO_ORDER_CANONICAL, query, m, feat_out);
+}
+
+void kplo_features_ordered(const kplo_grid *g, const float *xyz, const float *nrm, int n,
+                           int n_annulus, int n_bins, double r_feat, int order,
+                           const int *query, int m, float *feat_out)
+{
     (void)n;
     const int F = n_annulus * n_bins;
     for (int q = 0; q < m; ++q) {
@@ -290,7 +374,7 @@ void kplo_features(const kplo_grid *g, const float *xyz, const float *nrm, int n
             for (int c = 0; c < F; ++c) out[c] = NAN;
             continue;
         }
-        point_features(g, xyz, nrm, i, n_annulus, n_bins, r_feat, out);
+        point_features(g, xyz, nrm, i, n_annulus, n_bins, r_feat, order, out);
     }
 }
 
@@ -324,6 +408,13 @@ void kplo_scores(const kplo_grid *g, const float *xyz, const float *nrm, int n,
                  int n_annulus, int n_bins, double r_feat, const kplo_forest *f,
                  float *scores, int n_threads)
 {
+    kplo_scores_ordered(g, xyz, nrm, n, n_annulus, n_bins, r_feat, KPLO_ORDER_CANONICAL, f, scores, n_threads);
+}
+
+void kplo_scores_ordered(const kplo_grid *g, const float *xyz, const float *nrm, int n,
+                         int n_annulus, int n_bins, double r_feat, int order, const kplo_forest *f,
+                         float *scores, int n_threads)
+{
     const int F = n_annulus * n_bins;
     const int forest_size = f->ntrees;                                   /* :271 */
 #ifdef _OPENMP
@@ -340,7 +431,7 @@ void kplo_scores(const kplo_grid *g, const float *xyz, const float *nrm, int n,
                 scores[i] = NAN;
                 continue;
             }
-            point_features(g, xyz, nrm, i, n_annulus, n_bins, r_feat, H);  /* :279 */
+            point_features(g, xyz, nrm, i, n_annulus, n_bins, r_feat, order, H);  /* :279 */
             const float sum = kplo_forest_predict_sum(f, H, NULL);         /* :281 */
             scores[i] = 1 - (sum / (forest_size * 1.0f));                  /* :287 */
         }
@@ -452,10 +543,19 @@ int kplo_detect(const float *xyz, const float *nrm, int n,
                 int non_maxima, int draws_remove, float draws_threshold,
                 const kplo_forest *f, float *scores_out, int *kp_out, int n_threads)
 {
+    return kplo_detect_ordered(xyz, nrm, n, n_annulus, n_bins, r_feat, r_nms, threshold, non_maxima, draws_remove,
+                               draws_threshold, KPLO_ORDER_CANONICAL, f, scores_out, kp_out, n_threads);
+}
+
+int kplo_detect_ordered(const float *xyz, const float *nrm, int n,
+                        int n_annulus, int n_bins, double r_feat, double r_nms, double threshold,
+                        int non_maxima, int draws_remove, float draws_threshold, int order,
+                        const kplo_forest *f, float *scores_out, int *kp_out, int n_threads)
+{
     kplo_grid *g = kplo_grid_create(xyz, n, r_feat);
     if (!g) return -1;
     float *scores = scores_out ? scores_out : (float *)malloc(sizeof(float) * (size_t)(n + 1));
-    kplo_scores(g, xyz, nrm, n, n_annulus, n_bins, r_feat, f, scores, n_threads);
+    kplo_scores_ordered(g, xyz, nrm, n, n_annulus, n_bins, r_feat, order, f, scores, n_threads);
     int count = 0;
     if (!non_maxima) {
         /* :189-196: every response point is a keypoint.  In input index space that is every
@@ -481,7 +581,7 @@ void kplo_alg_counters(const kplo_grid *g, const float *xyz, const float *nrm, i
     int64_t kf = 0, kn = 0, dp = 0, ns = 0, nt = 0;
     for (int i = 0; i < n; ++i) {
         if (!(finite3(xyz + 3 * (size_t)i) && finite3(nrm + 3 * (size_t)i))) continue;
-        kf += point_features(g, xyz, nrm, i, n_annulus, n_bins, r_feat, H);
+        kf += point_features(g, xyz, nrm, i, n_annulus, n_bins, r_feat, KPLO_ORDER_CANONICAL, H);
         int d;
         float sum = kplo_forest_predict_sum(f, H, &d);
         dp += d;

@@ -58,10 +58,26 @@ void kplo_grid_sorted_indices(const kplo_grid *g, int *out);
 int kplo_radius_search(const kplo_grid *g, const float *xyz, int i, double radius,
                        int *out_idx, float *out_d2, int cap);
 
+/* Neighbor order of the feature loop (include/impl/KeypointLearning.hpp:334-359; element 0 is dropped, :336):
+ *   CANONICAL  the grid's canonical order -- stands in for the unknowable FLANN
+ *              traversal order of the default pcl::search::KdTree(false);
+ *   SORTED     ascending (squared distance, index): what pcl::search::KdTree(true), handed to the inherited
+ *              pcl::Keypoint::setSearchMethod, returns (FLANN sorts with DistanceIndex::operator<). */
+#define KPLO_ORDER_CANONICAL 0
+#define KPLO_ORDER_SORTED 1
+
+/* radius search with sorted results: ascending (d2, index); same set as kplo_radius_search */
+int kplo_radius_search_sorted(const kplo_grid *g, const float *xyz, int i, double radius,
+                              int *out_idx, float *out_d2, int cap);
+
 /* include/impl/KeypointLearning.hpp:321-376 for each query index; feat_out[m * A*B]. */
 void kplo_features(const kplo_grid *g, const float *xyz, const float *nrm, int n,
                    int n_annulus, int n_bins, double r_feat,
                    const int *query, int m, float *feat_out);
+
+void kplo_features_ordered(const kplo_grid *g, const float *xyz, const float *nrm, int n,
+                           int n_annulus, int n_bins, double r_feat, int order,
+                           const int *query, int m, float *feat_out);
 
 /* cv::ml::RTrees::predict(..., PREDICT_SUM) restated; returns (float)sum of leaf values. */
 float kplo_forest_predict_sum(const kplo_forest *f, const float *x, int *depth_sum);
@@ -71,6 +87,10 @@ float kplo_forest_predict_sum(const kplo_forest *f, const float *x, int *depth_s
 void kplo_scores(const kplo_grid *g, const float *xyz, const float *nrm, int n,
                  int n_annulus, int n_bins, double r_feat, const kplo_forest *f,
                  float *scores, int n_threads);
+
+void kplo_scores_ordered(const kplo_grid *g, const float *xyz, const float *nrm, int n,
+                         int n_annulus, int n_bins, double r_feat, int order, const kplo_forest *f,
+                         float *scores, int n_threads);
 
 /* include/impl/KeypointLearning.hpp:197-261.  Returns number of keypoints written to kp_out
  * (ascending index; capacity n). */
@@ -83,6 +103,11 @@ int kplo_detect(const float *xyz, const float *nrm, int n,
                 int n_annulus, int n_bins, double r_feat, double r_nms, double threshold,
                 int non_maxima, int draws_remove, float draws_threshold,
                 const kplo_forest *f, float *scores_out, int *kp_out, int n_threads);
+
+int kplo_detect_ordered(const float *xyz, const float *nrm, int n,
+                        int n_annulus, int n_bins, double r_feat, double r_nms, double threshold,
+                        int non_maxima, int draws_remove, float draws_threshold, int order,
+                        const kplo_forest *f, float *scores_out, int *kp_out, int n_threads);
 
 /* Algorithmic-bytes counters of SURVEY.md 8(d): sum K_f, sum K_n over thresholded points,
  * sum of visited forest nodes. */

@@ -28,6 +28,10 @@ class _Forest(C.Structure):
                 ("right", C.POINTER(C.c_int)), ("value", C.POINTER(C.c_double))]
 
 
+# neighbor order of the feature loop (kpl_oracle.h): canonical grid order, or ascending (d2, index) = what a
+# sorted pcl::search::KdTree handed to setSearchMethod returns
+ORDER_CANONICAL, ORDER_SORTED = 0, 1
+
 _lib = None
 
 
@@ -57,6 +61,18 @@ def lib():
     L.kplo_features.argtypes = [C.c_void_p, fp, fp, C.c_int, C.c_int, C.c_int, C.c_double,
                                 ip, C.c_int, fp]
     L.kplo_features.restype = None
+    L.kplo_radius_search_sorted.argtypes = [C.c_void_p, fp, C.c_int, C.c_double, ip, fp, C.c_int]
+    L.kplo_radius_search_sorted.restype = C.c_int
+    L.kplo_features_ordered.argtypes = [C.c_void_p, fp, fp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
+                                        ip, C.c_int, fp]
+    L.kplo_features_ordered.restype = None
+    L.kplo_scores_ordered.argtypes = [C.c_void_p, fp, fp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
+                                      C.POINTER(_Forest), fp, C.c_int]
+    L.kplo_scores_ordered.restype = None
+    L.kplo_detect_ordered.argtypes = [fp, fp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                                      C.c_double, C.c_int, C.c_int, C.c_float, C.c_int, C.POINTER(_Forest),
+                                      fp, ip, C.c_int]
+    L.kplo_detect_ordered.restype = C.c_int
     L.kplo_forest_predict_sum.argtypes = [C.POINTER(_Forest), fp, ip]
     L.kplo_forest_predict_sum.restype = C.c_float
     L.kplo_scores.argtypes = [C.c_void_p, fp, fp, C.c_int, C.c_int, C.c_int, C.c_double,
@@ -189,27 +205,28 @@ class Grid:
         lib().kplo_grid_sorted_indices(self.h, _p(out, C.c_int))
         return out[:nf]
 
-    def radius_search(self, i, radius, cap=None):
+    def radius_search(self, i, radius, cap=None, sorted_results=False):
         cap = self.n if cap is None else cap
         idx = np.empty(max(cap, 1), dtype=np.int32)
         d2 = np.empty(max(cap, 1), dtype=np.float32)
-        k = lib().kplo_radius_search(self.h, _p(self.xyz, C.c_float), int(i), float(radius),
+        fn = lib().kplo_radius_search_sorted if sorted_results else lib().kplo_radius_search
+        k = fn(self.h, _p(self.xyz, C.c_float), int(i), float(radius),
                                      _p(idx, C.c_int), _p(d2, C.c_float), cap)
         return idx[:min(k, cap)].copy(), d2[:min(k, cap)].copy(), k
 
-    def features(self, nrm, A, B, r_feat, query):
+    def features(self, nrm, A, B, r_feat, query, order=ORDER_CANONICAL):
         nrm = _f32(nrm).reshape(-1, 3)
         query = _i32(query)
         out = np.empty((len(query), A * B), dtype=np.float32)
-        lib().kplo_features(self.h, _p(self.xyz, C.c_float), _p(nrm, C.c_float), self.n, A, B,
-                            float(r_feat), _p(query, C.c_int), len(query), _p(out, C.c_float))
+        lib().kplo_features_ordered(self.h, _p(self.xyz, C.c_float), _p(nrm, C.c_float), self.n, A, B,
+                                    float(r_feat), int(order), _p(query, C.c_int), len(query), _p(out, C.c_float))
         return out
 
-    def scores(self, nrm, A, B, r_feat, forest, threads=1):
+    def scores(self, nrm, A, B, r_feat, forest, threads=1, order=ORDER_CANONICAL):
         nrm = _f32(nrm).reshape(-1, 3)
         out = np.empty(max(self.n, 1), dtype=np.float32)
-        lib().kplo_scores(self.h, _p(self.xyz, C.c_float), _p(nrm, C.c_float), self.n, A, B,
-                          float(r_feat), C.byref(forest.c), _p(out, C.c_float), threads)
+        lib().kplo_scores_ordered(self.h, _p(self.xyz, C.c_float), _p(nrm, C.c_float), self.n, A, B,
+                                  float(r_feat), int(order), C.byref(forest.c), _p(out, C.c_float), threads)
         return out[:self.n]
 
     def nms(self, scores, r_nms, threshold, draws_remove=False, draws_threshold=0.0, threads=1):
@@ -231,17 +248,17 @@ class Grid:
 
 
 def detect(xyz, nrm, A, B, r_feat, r_nms, threshold, forest, non_maxima=True,
-           draws_remove=False, draws_threshold=0.0, threads=1):
+           draws_remove=False, draws_threshold=0.0, threads=1, order=ORDER_CANONICAL):
     """Whole path.  Returns (scores[n] float32, keypoint indices int32 ascending)."""
     xyz = _f32(xyz).reshape(-1, 3)
     nrm = _f32(nrm).reshape(-1, 3)
     n = xyz.shape[0]
     scores = np.empty(max(n, 1), dtype=np.float32)
     kp = np.empty(max(n, 1), dtype=np.int32)
-    k = lib().kplo_detect(_p(xyz, C.c_float), _p(nrm, C.c_float), n, A, B, float(r_feat),
-                          float(r_nms), float(threshold), int(non_maxima), int(draws_remove),
-                          float(draws_threshold), C.byref(forest.c), _p(scores, C.c_float),
-                          _p(kp, C.c_int), threads)
+    k = lib().kplo_detect_ordered(_p(xyz, C.c_float), _p(nrm, C.c_float), n, A, B, float(r_feat),
+                                  float(r_nms), float(threshold), int(non_maxima), int(draws_remove),
+                                  float(draws_threshold), int(order), C.byref(forest.c), _p(scores, C.c_float),
+                                  _p(kp, C.c_int), threads)
     if k < 0:
         raise MemoryError("oracle grid too large")
     return scores[:n], kp[:k].copy()

@@ -26,7 +26,7 @@ def test_header_symbols_are_exported_and_bound(kpl):
 
 def test_version_and_status_strings(kpl):
     lib = kpl.load_library()
-    assert lib.kpl_version() == 120
+    assert lib.kpl_version() == 130
     assert lib.kpl_status_string(0) == b"ok"
     assert b"forest" in lib.kpl_status_string(kpl.ERR_NO_FOREST)
 
@@ -37,6 +37,7 @@ def test_default_params_match_the_reference_ctor(kpl):
     kpl.load_library().kpl_default_params(C.byref(p))
     assert (p.n_annulus, p.n_bins, p.non_maxima, p.non_maxima_draws_remove) == (5, 10, 1, 1)
     assert p.prediction_th == 0.5 and p.non_max_radius == 0.0 and p.radius_search == 0.0
+    assert p.neighbor_order == kpl.NEIGHBORS_CANONICAL
 
 
 def test_null_handles_do_not_crash(kpl):

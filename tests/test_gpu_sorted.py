@@ -1,0 +1,156 @@
+"""Sorted-search mode (kpl_params.neighbor_order = KPL_NEIGHBORS_SORTED) on the GPU against the oracle's sorted
+mode: features, scores and keypoint lists bit for bit -- exact ties, duplicated points, non-finite inputs,
+neighborhoods longer than the per-point key list (several passes), batches that mix both modes."""
+import numpy as np
+import pytest
+
+from tests.test_oracle_sorted import lattice
+
+pytestmark = pytest.mark.gpu
+
+
+def make_det(kpl, A, B, r_feat, r_nms, thr, fa=None, sorted_search=True, draws_remove=False):
+    det = kpl.KeypointLearningDetector()
+    det.setNAnnulus(A)
+    det.setNBins(B)
+    det.setNonMaxima(True)
+    det.setNonMaxRadius(r_nms)
+    det.setNonMaximaDrawsRemove(draws_remove)
+    det.setPredictionThreshold(thr)
+    det.setRadiusSearch(r_feat)
+    det.setSortedSearch(sorted_search)
+    if fa is not None:
+        from tests.helpers import load_arrays
+        load_arrays(det, fa)
+    return det
+
+
+@pytest.mark.parametrize("A,B", [(5, 6), (5, 10), (8, 10), (1, 1), (3, 2)])
+def test_sorted_features_bit_exact(kpl, oracle, cases, A, B):
+    xyz, nrm = cases.cloud(nan_points=20, nan_normals=30)
+    r = float(np.float32(6 * cases.resolution()))
+    det = make_det(kpl, A, B, r, 0.0, 0.5)
+    det.setInputCloud(xyz)
+    det.setNormals(nrm)
+    # every point whose own normal is finite (the reference does arithmetic on a NaN query normal and casts the
+    # result to int, hpp:332-348: undefined); neighbors with NaN normals and queries with NaN xyz stay in
+    q = np.flatnonzero(np.isfinite(nrm).all(axis=1)).astype(np.int32)
+    got = det.computePointsForTrainingFeatures(q)
+    g = oracle.Grid(xyz, r)
+    want = g.features(nrm, A, B, r, q, order=oracle.ORDER_SORTED)
+    assert cases.same_bits(got, want)
+    if A * B > 1:
+        assert not cases.same_bits(got, g.features(nrm, A, B, r, q))        # and it is not the canonical order
+    q2 = q[[5, 0, len(q) - 1, 5, 17, 1234]]
+    assert cases.same_bits(det.computePointsForTrainingFeatures(q2), want[[5, 0, len(q) - 1, 5, 17, 1234]])
+    det.setSortedSearch(False)                                              # the same handle, back to canonical
+    assert cases.same_bits(det.computePointsForTrainingFeatures(q), g.features(nrm, A, B, r, q))
+
+
+def test_sorted_ties_and_duplicates(kpl, oracle, cases):
+    """regular lattice + exact duplicates: hundreds of equal distances per neighborhood, broken by index"""
+    xyz, nrm = lattice(40, 36, dup=40)
+    for r in (2.1, 3.3, 5.01):
+        det = make_det(kpl, 5, 6, r, 0.0, 0.5)
+        det.setInputCloud(xyz)
+        det.setNormals(nrm)
+        q = np.arange(len(xyz), dtype=np.int32)
+        want = oracle.Grid(xyz, r).features(nrm, 5, 6, r, q, order=oracle.ORDER_SORTED)
+        assert cases.same_bits(det.computePointsForTrainingFeatures(q), want), r
+
+
+@pytest.mark.parametrize("thr", [0.0, 0.5, 0.85])
+def test_sorted_detect_matches_oracle(kpl, oracle, cases, thr):
+    A, B = 5, 6
+    xyz, nrm = cases.cloud(nan_points=10, nan_normals=10)
+    mr = cases.resolution()
+    r, rn = float(np.float32(6 * mr)), float(np.float32(4 * mr))
+    fa = cases.trained_forest(A, B)
+    det = make_det(kpl, A, B, r, rn, float(np.float32(thr)), fa)
+    det.setInputCloud(xyz)
+    det.setNormals(nrm)
+    _, scores = det.compute()
+    o_scores, o_kp = oracle.detect(xyz, nrm, A, B, r, rn, float(np.float32(thr)), cases.oracle_forest(fa),
+                                   order=oracle.ORDER_SORTED)
+    assert cases.same_bits(scores, o_scores)
+    assert np.array_equal(det.getKeypointsIndices(), o_kp) and len(o_kp) > 0
+    # PCL layouts (16-byte points, 32-byte normals): the sorted mode reads the caller's normal array by index
+    x16 = np.zeros((len(xyz), 4), np.float32); x16[:, :3] = xyz
+    n32 = np.full((len(xyz), 8), 7.0, np.float32); n32[:, :3] = nrm
+    det.setInputCloud(x16)
+    det.setNormals(n32)
+    _, scores2 = det.compute()
+    assert cases.same_bits(scores2, o_scores) and np.array_equal(det.getKeypointsIndices(), o_kp)
+
+
+@pytest.mark.parametrize("rmul", [9.0, 13.0])
+def test_sorted_neighborhoods_longer_than_the_key_list(kpl, oracle, cases, rmul):
+    """K_f of a few hundred: more neighbors than a point's key list holds -> windows of keys, several passes"""
+    from tools import synth
+    xyz, nrm = synth.make_cloud(120, 90, seed=9, overlap_layers=2)
+    xyz, nrm = synth.shuffle_cloud(xyz, nrm, 1009)
+    mr = oracle.cloud_resolution(xyz)
+    r = float(np.float32(rmul * mr))
+    det = make_det(kpl, 5, 6, r, 0.0, 0.5)
+    det.setInputCloud(xyz)
+    det.setNormals(nrm)
+    q = np.arange(0, len(xyz), 3, dtype=np.int32)
+    g = oracle.Grid(xyz, r)
+    assert max(g.radius_search(int(i), r)[2] for i in q[::200]) > 300
+    assert cases.same_bits(det.computePointsForTrainingFeatures(q), g.features(nrm, 5, 6, r, q, order=oracle.ORDER_SORTED))
+
+
+def test_sorted_config2_full_size(kpl, oracle, cases):
+    """BASELINE.json configs[1] (200 k points) in sorted-search mode"""
+    from tools import forest_yaml, synth
+    import os
+    forest = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data", "forests", "synth200k_a5b6_t10.yaml.gz")
+    xyz, nrm = synth.make_cloud(500, 400, seed=1)
+    xyz, nrm = synth.shuffle_cloud(xyz, nrm, 1001)
+    mr = oracle.cloud_resolution(xyz)
+    r, rn, thr = float(np.float32(6 * mr)), float(np.float32(4 * mr)), float(np.float32(0.85))
+    det = make_det(kpl, 5, 6, r, rn, thr)
+    assert det.loadForest(forest)
+    det.setInputCloud(xyz)
+    det.setNormals(nrm)
+    _, scores = det.compute()
+    fa = forest_yaml.load_forest(forest)
+    o_scores, o_kp = oracle.detect(xyz, nrm, 5, 6, r, rn, thr, cases.oracle_forest(fa), threads=cases.usable_cores(),
+                                   order=oracle.ORDER_SORTED)
+    assert cases.same_bits(scores, o_scores) and np.array_equal(det.getKeypointsIndices(), o_kp)
+    c_scores, _ = oracle.detect(xyz, nrm, 5, 6, r, rn, thr, cases.oracle_forest(fa), threads=cases.usable_cores())
+    assert not cases.same_bits(c_scores, o_scores)          # some votes do change with the order
+    assert np.mean(c_scores != o_scores) < 0.25
+
+
+def test_batch_mixes_both_orders(kpl, oracle, cases):
+    import torch
+    from tools import forest_yaml
+    import os
+    forest = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data", "forests", "synth200k_a5b6_t10.yaml.gz")
+    fa = forest_yaml.load_forest(forest)
+    of = cases.oracle_forest(fa)
+    dev = torch.device("cuda", 0)
+    dets, bufs, views = [], [], []
+    for k, srt in enumerate([True, False, True, False, False]):
+        xyz, nrm = cases.cloud(60 + 9 * k, 50, seed=80 + k)
+        mr = oracle.cloud_resolution(xyz)
+        r, rn, thr = float(np.float32(6 * mr)), float(np.float32(4 * mr)), float(np.float32(0.85))
+        det = make_det(kpl, 5, 6, r, rn, thr, sorted_search=srt)
+        assert det.loadForest(forest)
+        n = len(xyz)
+        dx, dn = torch.from_numpy(xyz.copy()).to(dev), torch.from_numpy(nrm.copy()).to(dev)
+        ds = torch.empty(n, dtype=torch.float32, device=dev)
+        dk = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+        det.bindCloudDevice(dx.data_ptr(), 12, dn.data_ptr(), 12, n)
+        dets.append(det); bufs.append((dx, dn, ds, dk)); views.append((xyz, nrm, r, rn, thr, srt))
+    for rep in range(2):
+        kpl.compute_batch_device(dets, [b[2].data_ptr() for b in bufs], [b[3][1:].data_ptr() for b in bufs],
+                                 [len(b[2]) for b in bufs], [b[3][0:1].data_ptr() for b in bufs], None)
+        torch.cuda.synchronize()
+        for (xyz, nrm, r, rn, thr, srt), det, (dx, dn, ds, dk) in zip(views, dets, bufs):
+            assert det.syncStatus(None) == kpl.OK
+            o_sc, o_kp = oracle.detect(xyz, nrm, 5, 6, r, rn, thr, of,
+                                       order=oracle.ORDER_SORTED if srt else oracle.ORDER_CANONICAL)
+            assert cases.same_bits(ds.cpu().numpy(), o_sc)
+            assert np.array_equal(dk[1:1 + int(dk[0].item())].cpu().numpy(), o_kp)
