@@ -40,6 +40,7 @@ REPEATS = 5         # timed repetitions of the K-step loop; the median one is re
 KERNEL_SOURCES = ("keypoint-learning_amd/csrc/kernels.hip", "keypoint-learning_amd/csrc/kernels.h")
 A, B = 5, 6
 HBM_PEAK = 8.0e12   # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
+LDS_PEAK = 75.0e12  # B/s, MI355X_MICROARCH.md "LDS": ~75 TB/s aggregate for ds_read_b32 with every CU streaming (b64: ~150)
 try:                # the metric's name is BASELINE.json's, verbatim
     METRIC = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
 except (OSError, ValueError, KeyError):
@@ -432,15 +433,35 @@ def main():
     iso_ms = max(t_iso["feature_ms"] / max(t_iso["calls"], 1), 1e-9) if t_iso else None
     # measured counters of exactly these kernels (rocprofv3, profiles/counters.json) -- or null
     prof, why_not = load_profile(nb)
-    traffic = valu_busy = ta_busy = hbm_counter_frac = waves_per_simd = None
+    traffic = valu_busy = ta_busy = hbm_counter_frac = waves_per_simd = valu_issue_frac = valu_model = None
+    forest_prof = None
     if prof:
         pk = prof["kernels"].get("feature_kernel", {})
         traffic = pk.get("hbm_bytes")
         valu_busy = pk.get("valu_busy")
         ta_busy = pk.get("ta_busy")
         waves_per_simd = pk.get("waves_per_simd")
+        valu_issue_frac = pk.get("valu_issue_frac")
+        valu_model = pk.get("valu_model")
+        forest_prof = prof["kernels"].get("forest_kernel")
         if traffic and feat_ms > 0:
             hbm_counter_frac = round(traffic / (feat_ms * 1e-3) / HBM_PEAK, 5)
+    # what limits the dominant kernel, decided by the counters (never by opinion): VALU issue if the instructions
+    # it executes need >= 70 % of its cycles at the MEASURED issue ceilings of this chip (tools/valu_ceiling.hip ->
+    # tools/valu_model.py), the texture path if that is busier, else latency
+    if valu_issue_frac is None:
+        bound = "unknown (no matching counter profile)"
+    elif valu_issue_frac >= 0.70 and valu_issue_frac >= (ta_busy or 0.0):
+        bound = "valu"
+    elif (ta_busy or 0.0) >= 0.70:
+        bound = "texture-path"
+    else:
+        bound = "latency"
+    # the forest kernel (nodes in LDS): LDS pipe, VALU issue, or the latency of its dependent LDS round trips
+    forest_bound = "unknown (no matching counter profile)"
+    if forest_prof and forest_prof.get("valu_issue_frac") is not None:
+        fv, fl = forest_prof["valu_issue_frac"], forest_prof.get("lds_busy") or 0.0
+        forest_bound = "lds" if fl >= 0.70 and fl >= fv else "valu" if fv >= 0.70 else "latency (dependent LDS reads)"
 
     # ---- CPU baseline: the oracle, timed on the host cores, bounded sample --------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -488,24 +509,37 @@ def main():
                        "exchange": ("one all-gather of the packed keypoint lists per step (%s)" %
                                     ("RCCL" if args.backend == "nccl" else args.backend)) if use_dist else "none (one rank)"},
             "repeats": {"n": repeats, "reported": "median", "ms_per_step": [round(x * 1e3 / args.steps, 5) for x in rep_s]},
-            # SURVEY 8(d) contract figure: gather-model bytes of the dominant kernel / its launch time / 8 TB/s.
-            # What actually limits that kernel is VALU issue (valu_busy: SQ_ACTIVE_INST_VALU x 4 cycles, an upper
-            # bound) together with the texture path (ta_busy), its HBM traffic is a tenth of peak
-            # (hbm_counter_frac); all three come from rocprofv3 counters of exactly these kernel sources
-            # (profiles/counters.json, matched by hash) and are null when the profile is stale.
-            "roofline": {"bound": "valu", "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9,
+            # SURVEY 8(d) contract figure: gather-model bytes of the dominant kernel / its launch time / 8 TB/s (most of
+            # those bytes are L1 / L2 hits: the HBM traffic by counters is hbm_counter_frac of peak).  `bound` is set from
+            # counters of exactly these kernel sources (profiles/counters.json, matched by hash; null when stale):
+            # valu_issue_frac = the SIMD cycles the kernel's instructions need at the issue ceilings measured on this
+            # chip / the kernel's cycles; ta_busy = the texture path; valu_busy = the old 4-cycles-per-instruction
+            # upper bound, kept for comparison with earlier rounds.
+            "roofline": {"bound": bound, "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 5), "traffic": traffic,
                          "kernel": "feature_kernel (histogram features, %d view(s) per launch)" % nb,
                          "kernel_ms": round(feat_ms, 5), "alg_bytes_per_launch": int(b_alg_feat),
+                         "valu_issue_frac": valu_issue_frac,
+                         "valu_issue_model": {k: valu_model[k] for k in ("valu_issue_frac_bounds", "class_cycles_per_instruction",
+                                                                         "avg_cycles_per_instruction_at_ceiling", "static_fast_share")}
+                         if valu_model else None,
                          "valu_busy": valu_busy, "ta_busy": ta_busy, "hbm_counter_frac": hbm_counter_frac,
                          "waves_per_simd": waves_per_simd,
                          "counters": {"file": "profiles/counters.json", "source_sha256": kernel_source_sha256()[:16],
                                       "matches_these_kernels": prof is not None, "note": why_not},
                          "alone_on_gpu": {"kernel_ms": round(iso_ms, 5),
                                           "frac": round(b_alg_feat / (iso_ms * 1e-3) / HBM_PEAK, 5)} if iso_ms else None,
-                         "forest_kernel": {"kernel_ms": round(forest_ms, 5), "alg_bytes_per_launch": int(b_alg_forest),
-                                           "frac": round(b_alg_forest / (forest_ms * 1e-3) / HBM_PEAK, 5) if forest_ms > 0 else None,
-                                           "counters": prof["kernels"].get("forest_kernel") if prof else None}},
+                         # the forest kernel walks nodes that it has staged in LDS: its node bytes never come from HBM, so
+                         # no fraction of the HBM peak is quoted for them.  LDS side: bytes the walk reads from LDS (8-byte node
+                         # + 4-byte feature per visited node) against the guide's aggregate ds_read rate (~75 TB/s for b32,
+                         # ~150 TB/s for b64 with every CU streaming); lds_busy / bank conflicts from counters.
+                         "forest_kernel": {"kernel_ms": round(forest_ms, 5), "bound": forest_bound,
+                                           "lds_bytes_per_launch": int(12 * sum(st["sum_depth"] for st in stats)),
+                                           "lds_TBps": round(12 * sum(st["sum_depth"] for st in stats) / (forest_ms * 1e-3) / 1e12, 2) if forest_ms > 0 else None,
+                                           "lds_peak_TBps": LDS_PEAK / 1e12,
+                                           "lds_frac": round(12 * sum(st["sum_depth"] for st in stats) / (forest_ms * 1e-3) / LDS_PEAK, 4) if forest_ms > 0 else None,
+                                           "hbm_bytes_by_counters": forest_prof.get("hbm_bytes") if forest_prof else None,
+                                           "counters": forest_prof}},
             "cpu_baseline": cpu,
             "phases_ms": per(timing),
             "single_view": {"compute_ms": round(single_ms, 5), "Mpoints_per_s": round(n / single_ms / 1e3, 2),

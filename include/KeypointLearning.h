@@ -13,10 +13,16 @@
 // Without them a minimal in-repo shim (kpl_pcl_shim.h) and kpl::FeatureMatrix are used.
 //
 // Differences to the reference, all documented in DESIGN.md:
-//   * without setNormals the normals are estimated on the device with the radius search the
-//     reference's initCompute uses (impl/KeypointLearning.hpp:125-148, kpl_estimate_normals);
-//     for ORGANIZED clouds the reference switches to IntegralImageNormalEstimation, which is not
-//     provided: call setNormals for those;
+//   * without setNormals the normals are estimated on the device the way the reference's initCompute
+//     does (impl/KeypointLearning.hpp:125-148): pcl::NormalEstimation with the feature radius for an
+//     unorganized cloud (kpl_estimate_normals), pcl::IntegralImageNormalEstimation (SIMPLE_3D_GRADIENT,
+//     smoothing 5) for an organized one (kpl_estimate_normals_organized); both flip towards the cloud's
+//     sensor origin, like PCL's estimators do by default;
+//   * no search tree is ever built on the host: the engine has its own spatial index on the device.  A tree
+//     handed to the inherited setSearchMethod is only asked whether it returns SORTED results
+//     (pcl::search::KdTree's constructor default!): if so the feature loop meets the neighbors in FLANN's
+//     sorted order, ascending (squared distance, index) -- kpl_params::neighbor_order -- otherwise in the
+//     engine's canonical order; setSortedSearch(bool) overrides the tree;
 //   * only radius search with search surface == input is supported (the reference's k-search mode
 //     divides by a zero support, hpp:345; a separate surface mixes index spaces, hpp:332 vs :149);
 //   * points with non-finite xyz or normal get score NaN and keep their input index (the
@@ -79,6 +85,7 @@ public:
 #endif
     typedef typename Keypoint<PointInT, PointOutT>::PointCloudIn PointCloudIn;
     typedef typename Keypoint<PointInT, PointOutT>::PointCloudOut PointCloudOut;
+    typedef typename Keypoint<PointInT, PointOutT>::KdTree KdTree;           // reference KeypointLearning.h:66
     typedef typename PointCloudIn::ConstPtr PointCloudInConstPtr;
     typedef pcl::PointCloud<NormalT> PointCloudN;
     typedef typename PointCloudN::Ptr PointCloudNPtr;
@@ -157,16 +164,39 @@ public:
     // keypoints alone come back from the device (no reference counterpart: the reference keeps the
     // responses in a temporary cloud, hpp:182-187)
     void setKeepScores(bool keep) { keep_scores_ = keep; }
-    const std::vector<float> &getScores() const { return scores_; }
+    const std::vector<float> &getScores() const {
+        if (!keep_scores_)
+            PCL_ERROR("[pcl::%s::getScores] empty: call setKeepScores(true) before compute() to keep the response of every point\n",
+                      this->name_.c_str());
+        return scores_;
+    }
+
+    // Neighbor order of the feature loop (hpp:334-359).  By default it follows the search method: a tree set
+    // with the inherited setSearchMethod whose getSortedResults() is true (a default-constructed
+    // pcl::search::KdTree) selects FLANN's sorted order, no tree (pcl::Keypoint then makes an UNSORTED one,
+    // whose traversal order cannot be reproduced) the engine's canonical order.  setSortedSearch overrides it.
+    void setSortedSearch(bool sorted) { sorted_search_ = sorted ? 1 : 0; }
+    bool getSortedSearch() const { return sorted_search_ >= 0 ? sorted_search_ != 0 : (this->tree_ && this->tree_->getSortedResults()); }
     const char *lastError() const { return handle_ ? kpl_last_error(handle_) : kpl_status_string(create_status_); }
 
 protected:
     bool initCompute() {                                                     // hpp:116-156
         if (!handle_) return report("initCompute", create_status_);
-        if (!Keypoint<PointInT, PointOutT>::initCompute()) {
+        // pcl::Keypoint::initCompute (hpp:119) restated WITHOUT its search tree: PCL's version allocates a
+        // pcl::search::KdTree and builds a FLANN index over the whole cloud on the host at every compute() --
+        // tens of milliseconds that this engine, which searches its own index on the device, would never use.
+        if (!this->input_) {
             PCL_ERROR("[pcl::%s::initCompute] init failed!\n", this->name_.c_str());
             return false;
         }
+        if (!this->surface_) this->surface_ = this->input_;
+        if (this->search_radius_ != 0.0 && this->k_ != 0) {
+            PCL_ERROR("[pcl::%s::initCompute] Both radius (%f) and K (%d) defined! Set one of them to zero first and then re-run compute ().\n",
+                      this->name_.c_str(), this->search_radius_, this->k_);
+            return false;
+        }
+        this->keypoints_indices_.reset(new pcl::PointIndices);
+        this->keypoints_indices_->indices.reserve(this->input_->size());
         if (this->surface_ != this->input_) {
             PCL_ERROR("[pcl::%s::initCompute] a search surface different from the input is not supported\n", this->name_.c_str());
             return false;
@@ -183,17 +213,26 @@ protected:
             normals->width = this->surface_->width;
             normals->height = this->surface_->height;
             int rc;
+            // both PCL estimators flip the normals towards the sensor origin of their input cloud by default
+            // (use_sensor_origin_ = true; pcl::PointCloud::sensor_origin_, the VIEWPOINT of a PCD file)
+            const float viewpoint[3] = {this->surface_->sensor_origin_.coeff(0), this->surface_->sensor_origin_.coeff(1),
+                                        this->surface_->sensor_origin_.coeff(2)};
+            if (this->surface_->isOrganized() &&
+                (size_t)this->surface_->width * (size_t)this->surface_->height != this->surface_->points.size()) {
+                PCL_ERROR("[pcl::%s::initCompute] organized cloud with width * height != number of points\n", this->name_.c_str());
+                return false;
+            }
             if (!this->surface_->isOrganized()) {                            // hpp:129-136: pcl::NormalEstimation, radius search
                 normals->width = (uint32_t)n;
                 normals->height = 1;
                 rc = kpl_estimate_normals(handle_, n ? &this->surface_->points[0].x : nullptr, sizeof(PointInT), n, 0,
-                                          this->search_radius_, nullptr,
+                                          this->search_radius_, viewpoint,
                                           n ? &normals->points[0].normal_x : nullptr, sizeof(NormalT),
                                           n ? &normals->points[0].curvature : nullptr, sizeof(NormalT));
             } else {                                                         // hpp:138-145: IntegralImageNormalEstimation,
                                                                              // SIMPLE_3D_GRADIENT, smoothing size 5.0
                 rc = kpl_estimate_normals_organized(handle_, n ? &this->surface_->points[0].x : nullptr, sizeof(PointInT),
-                                                    (int)this->surface_->width, (int)this->surface_->height, 5.0f, nullptr,
+                                                    (int)this->surface_->width, (int)this->surface_->height, 5.0f, viewpoint,
                                                     n ? &normals->points[0].normal_x : nullptr, sizeof(NormalT),
                                                     n ? &normals->points[0].curvature : nullptr, sizeof(NormalT));
             }
@@ -214,6 +253,7 @@ protected:
         p.non_maxima = non_maxima_ ? 1 : 0;
         p.non_maxima_draws_remove = non_maxima_draws_remove_ ? 1 : 0;
         p.non_maxima_draws_threshold = non_maxima_draws_threshold_;
+        p.neighbor_order = getSortedSearch() ? KPL_NEIGHBORS_SORTED : KPL_NEIGHBORS_CANONICAL;
         int rc = kpl_set_params(handle_, &p);
         return rc == KPL_OK || report("initCompute", rc);
     }
@@ -336,6 +376,7 @@ protected:
     std::vector<int> kp_idx_;            // grow-only landing buffers of detectKeypoints
     std::vector<float> kp_score_;
     bool keep_scores_ = false;
+    int sorted_search_ = -1;             // -1: follow the search method (tree_), 0 / 1: setSortedSearch
     kpl_detector *handle_ = nullptr;
     int create_status_ = KPL_OK;
 };

@@ -12,6 +12,12 @@
  * never throws; kpl_last_error() gives the message of the last failure on that handle.  A
  * handle is not thread safe; distinct handles are independent (one handle per view/stream).
  * All arrays are caller owned; the handle owns its forest and (grow-only) device scratch.
+ * Streams: the host-buffer entry points (kpl_detect, kpl_detect_keypoints, kpl_compute_features,
+ * kpl_estimate_normals*, kpl_cloud_resolution) run on a private non-blocking stream of the handle and
+ * return when their results are in the caller's buffers; the *_device entry points only enqueue on the
+ * stream they are given.  Both kinds use the handle's scratch: before mixing them on ONE handle, wait for
+ * the stream of the earlier *_device call (kpl_sync_status or hipStreamSynchronize) -- nothing orders them
+ * implicitly, not even the null stream.
  * There is NO CPU fallback: without a usable HIP device every compute call fails with
  * KPL_ERR_DEVICE.
  */

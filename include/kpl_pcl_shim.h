@@ -48,6 +48,13 @@ inline bool isFinite<Normal>(const Normal &n) {
     return std::isfinite(n.normal_x) && std::isfinite(n.normal_y) && std::isfinite(n.normal_z);
 }
 
+// pcl::PointCloud::sensor_origin_ is an Eigen::Vector4f; the drop-in class reads it with coeff(i) only
+struct SensorOrigin {
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    float coeff(int i) const { return v[i]; }
+    float &operator[](int i) { return v[i]; }
+};
+
 template <typename PointT>
 class PointCloud {
 public:
@@ -56,6 +63,7 @@ public:
     std::vector<PointT> points;
     uint32_t width = 0, height = 0;
     bool is_dense = true;
+    SensorOrigin sensor_origin_;          // the VIEWPOINT of a PCD file: where normal estimation flips to
     size_t size() const { return points.size(); }
     bool empty() const { return points.empty(); }
     void push_back(const PointT &p) {
@@ -81,20 +89,51 @@ struct PointIndices {
 typedef PointIndices::Ptr PointIndicesPtr;
 typedef PointIndices::ConstPtr PointIndicesConstPtr;
 
+// pcl::search::Search / pcl::search::KdTree as far as setSearchMethod needs them here: the engine searches
+// its own index on the device and only asks a tree whether its results are sorted (PCL 1.8:
+// pcl::search::KdTree<PointT>(bool sorted = true); pcl::Keypoint makes a KdTree(false) when none is set)
+namespace search {
+template <typename PointT>
+class Search {
+public:
+    typedef std::shared_ptr<Search<PointT>> Ptr;
+    typedef std::shared_ptr<const Search<PointT>> ConstPtr;
+    explicit Search(const std::string &name = "", bool sorted = false) : sorted_results_(sorted), name_(name) {}
+    virtual ~Search() {}
+    virtual void setSortedResults(bool sorted_results) { sorted_results_ = sorted_results; }
+    virtual bool getSortedResults() { return sorted_results_; }
+
+protected:
+    bool sorted_results_;
+    std::string name_;
+};
+template <typename PointT>
+class KdTree : public Search<PointT> {
+public:
+    typedef std::shared_ptr<KdTree<PointT>> Ptr;
+    typedef std::shared_ptr<const KdTree<PointT>> ConstPtr;
+    explicit KdTree(bool sorted = true) : Search<PointT>("KdTree", sorted) {}
+};
+}  // namespace search
+
 // pcl::Keypoint as far as the detector and TestDetector use it
-// (setInputCloud / setSearchSurface / setRadiusSearch / setKSearch / compute / getKeypointsIndices).
+// (setInputCloud / setSearchSurface / setSearchMethod / setRadiusSearch / setKSearch / compute / getKeypointsIndices).
 template <typename PointInT, typename PointOutT>
 class Keypoint {
 public:
     typedef PointCloud<PointInT> PointCloudIn;
     typedef typename PointCloudIn::ConstPtr PointCloudInConstPtr;
     typedef PointCloud<PointOutT> PointCloudOut;
+    typedef pcl::search::Search<PointInT> KdTree;
+    typedef typename KdTree::Ptr KdTreePtr;
 
     Keypoint() : keypoints_indices_(new PointIndices) {}
     virtual ~Keypoint() {}
 
     virtual void setInputCloud(const PointCloudInConstPtr &cloud) { input_ = cloud; }
     virtual void setSearchSurface(const PointCloudInConstPtr &cloud) { surface_ = cloud; }
+    void setSearchMethod(const KdTreePtr &tree) { tree_ = tree; }
+    KdTreePtr getSearchMethod() { return tree_; }
     void setRadiusSearch(double radius) { search_radius_ = radius; }
     double getRadiusSearch() const { return search_radius_; }
     void setKSearch(int k) { k_ = k; }
@@ -129,6 +168,7 @@ protected:
 
     std::string name_;
     PointCloudInConstPtr input_, surface_;
+    KdTreePtr tree_;
     double search_radius_ = 0.0;
     int k_ = 0;
     PointIndicesPtr keypoints_indices_;

@@ -1035,12 +1035,15 @@ int kpl_estimate_normals_organized(kpl_detector *h, const void *xyz, size_t xyz_
     if (rc) return rc;
     if (n == 0) return KPL_OK;
     const size_t nn = (size_t)n;
+    const bool staged_view = h->bound && h->d_xyz == h->stage_xyz.as<char>();   // a bound HOST view lives in stage_xyz
     KPL_HIP(h, h->stage_xyz.ensure(nn * xyz_stride));
     KPL_HIP(h, h->stage_feat.ensure(sizeof(float) * 4 * nn));       // (nx, ny, nz, curvature) per pixel
     hipStream_t st = h->stream;
     KPL_HIP(h, hipMemcpyAsync(h->stage_xyz.p, xyz, (nn - 1) * xyz_stride + 12, hipMemcpyHostToDevice, st));
-    h->bound = false;                       // the staging buffer of a bound host view was just overwritten
-    h->index_valid = false;
+    if (staged_view) {                  // its staging buffer was just overwritten (a view bound with
+        h->bound = false;               // kpl_bind_cloud_device is the caller's memory: untouched)
+        h->index_valid = false;
+    }
     rc = organized_normals_on_device(h, h->stage_xyz.p, xyz_stride, width, height, normal_smoothing_size, viewpoint,
                                      h->stage_feat.p, 16, (char *)h->stage_feat.p + 12, 16, st);
     if (rc) return rc;

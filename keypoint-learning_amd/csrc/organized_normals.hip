@@ -143,7 +143,7 @@ __global__ __launch_bounds__(kRows) void on_integral_kernel(OrganizedView v) {
                 for (int a = 0; a < 3; ++a) prev_n[a] = j == 0 ? prev[3 * (size_t)(c + 1) + a] : ring[j - 1][c & 1][a];
                 const float *e = pixel(v, (size_t)r * (size_t)W + (size_t)c);
                 const float ex = e[0], ey = e[1], ez = e[2];
-                const bool fin = isfinite((ex + ey) + ez);
+                const bool fin = isfinite(ex + (ey + ez));        // Eigen's Vector3f::sum(): x + (y + z)
                 for (int a = 0; a < 3; ++a) {
                     out[a] = (prev_n[a] + cur_c[a]) - prev_c[a];
                     if (fin) out[a] += (double)(a == 0 ? ex : a == 1 ? ey : ez);
@@ -225,7 +225,9 @@ void launch_organized_normals(OrganizedView v, void *scratch, hipStream_t st) {
     p += align256(sizeof(float) * n);
     v.ii = reinterpret_cast<double *>(p);
     const unsigned blocks = (unsigned)((n + 255) / 256);
-    on_init_kernel<<<blocks, 256, 0, st>>>(v);
+    // row 0 of the integral image (3 (W + 1) doubles) is cleared by the same launch: the grid covers both extents
+    const size_t row0 = (size_t)3 * (size_t)(v.W + 1);
+    on_init_kernel<<<(unsigned)(((n > row0 ? n : row0) + 255) / 256), 256, 0, st>>>(v);
     const int border = (int)v.smoothing;
     if (border < 0 || v.W <= 2 * border || v.H <= 2 * border) return;       // nothing but NaN
     on_change_kernel<<<dim3((unsigned)((v.W + 255) / 256), (unsigned)v.H), 256, 0, st>>>(v);

@@ -57,6 +57,7 @@ inline bool load_pcd(const std::string &path, pcl::PointCloud<PointInT> &cloud, 
     std::vector<int> sizes, counts;
     std::vector<char> types;
     size_t npoints = 0, width = 0, height = 0;
+    float viewpoint[3] = {0.f, 0.f, 0.f};
     std::string data_kind, line;
     while (std::getline(f, line)) {
         if (!line.empty() && line.back() == '\r') line.pop_back();
@@ -70,6 +71,10 @@ inline bool load_pcd(const std::string &path, pcl::PointCloud<PointInT> &cloud, 
         else if (key == "WIDTH") ls >> width;
         else if (key == "HEIGHT") ls >> height;
         else if (key == "POINTS") ls >> npoints;
+        else if (key == "VIEWPOINT") {                // tx ty tz qw qx qy qz: the translation is the sensor origin
+            float t[3] = {0.f, 0.f, 0.f};
+            if (ls >> t[0] >> t[1] >> t[2]) { viewpoint[0] = t[0]; viewpoint[1] = t[1]; viewpoint[2] = t[2]; }
+        }
         else if (key == "DATA") { ls >> data_kind; break; }
     }
     if (counts.empty()) counts.assign(fields.size(), 1);
@@ -133,6 +138,7 @@ inline bool load_pcd(const std::string &path, pcl::PointCloud<PointInT> &cloud, 
     }
     cloud.is_dense = true;
     for (auto &p : cloud.points) if (!pcl::isFinite(p)) cloud.is_dense = false;
+    for (int k = 0; k < 3; ++k) cloud.sensor_origin_[k] = viewpoint[k];    // pcl::PCDReader: sensor_origin_ = VIEWPOINT translation
     if (height > 1 && width * height == npoints) {      // an organized cloud keeps its image shape, as with pcl::PCDReader
         cloud.width = (uint32_t)width;
         cloud.height = (uint32_t)height;

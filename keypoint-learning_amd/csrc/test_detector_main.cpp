@@ -59,10 +59,12 @@ const char *kUsage =
     "  --json                        print one JSON line with counts and timings.\n"
     "  --printResolution             print the cloud resolution (mean 2nd-NN distance) and exit.\n"
     "  --detectorNormals             do not pass normals: the detector estimates them itself (radius search\n"
-    "                                with radiusFeatures, as the reference's initCompute does).\n";
+    "                                with radiusFeatures, as the reference's initCompute does).\n"
+    "  --sortedSearch                hand the detector a sorted search tree (setSearchMethod(pcl::search::KdTree(true))):\n"
+    "                                neighbors in ascending (distance, index) order instead of the engine's canonical order.\n";
 
 bool parse(int argc, char **argv, Options &o) {
-    static const char *flags[] = {"help", "flipNormals", "subSampling", "radiusInMr", "json", "printResolution", "detectorNormals", "checkProtected"};
+    static const char *flags[] = {"help", "flipNormals", "subSampling", "radiusInMr", "json", "printResolution", "detectorNormals", "checkProtected", "sortedSearch"};
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         if (a == "-h") a = "--help";
@@ -107,14 +109,16 @@ struct Prep {
         if (rc != KPL_OK) fprintf(stderr, "cloud resolution: %s\n", kpl_last_error(h));
         return rc == KPL_OK;
     }
-    // pcl::NormalEstimation with setKSearch(10), viewpoint (0,0,0) -- main_test_detector.cpp:162-169
+    // pcl::NormalEstimation with setKSearch(10) -- main_test_detector.cpp:162-169; flipped towards the sensor
+    // origin of the cloud (the PCD's VIEWPOINT; NormalEstimation::setInputCloud takes it over by default)
     bool normals(const pcl::PointCloud<PointInT> &cloud, int k, pcl::PointCloud<PointNormalT> &out) const {
         const int n = (int)cloud.size();
         out.clear();
         out.points.resize((size_t)n);
         out.width = (uint32_t)n;
         out.height = 1;
-        int rc = kpl_estimate_normals(h, n ? &cloud.points[0].x : nullptr, sizeof(PointInT), n, k, 0.0, nullptr,
+        const float viewpoint[3] = {cloud.sensor_origin_.coeff(0), cloud.sensor_origin_.coeff(1), cloud.sensor_origin_.coeff(2)};
+        int rc = kpl_estimate_normals(h, n ? &cloud.points[0].x : nullptr, sizeof(PointInT), n, k, 0.0, viewpoint,
                                       n ? &out.points[0].normal_x : nullptr, sizeof(PointNormalT),
                                       n ? &out.points[0].curvature : nullptr, sizeof(PointNormalT));
         if (rc != KPL_OK) fprintf(stderr, "normal estimation: %s\n", kpl_last_error(h));
@@ -139,6 +143,7 @@ void uniform_sampling(pcl::PointCloud<PointInT> &cloud, double leaf) {
     std::sort(keep.begin(), keep.end());
     pcl::PointCloud<PointInT> out;
     for (int i : keep) out.push_back(cloud[i]);
+    out.sensor_origin_ = cloud.sensor_origin_;
     cloud = out;
 }
 
@@ -262,6 +267,8 @@ int main(int argc, char **argv) {
 
     detector->setNonMaxRadius(radius_nms);
     detector->setRadiusSearch(radius_features);
+    if (vm.has("sortedSearch"))          // the inherited pcl::Keypoint::setSearchMethod; KdTree's constructor default is sorted = true
+        detector->setSearchMethod(pcl::search::KdTree<PointInT>::Ptr(new pcl::search::KdTree<PointInT>(true)));
     detector->setInputCloud(cloud);
     if (!own_normals) detector->setNormals(normals);          // else: impl/KeypointLearning.hpp:125-148
 

@@ -857,7 +857,7 @@ void kplo_estimate_normals(const float *xyz, int n, int k, double radius, const 
  *      width - 1 and reads previous_row[ci + 1], i.e. the first pixel of the current row at the
  *      right edge; the second reads next_row[ci - 1] at ci = 0.  Neither reaches a pixel that is
  *      kept: the 5-pixel border is set to NaN and values >= 5 are clipped to 5
- *   3. first-order integral image of (x, y, z) in double, points whose x + y + z (float) is not
+ *   3. first-order integral image of (x, y, z) in double, points whose x + (y + z) (float) is not
  *      finite counted as zero: cur[c + 1] = prev[c + 1] + cur[c] - prev[c] (+ point)
  *   4. per kept pixel with finite z: s = min(distance, 5); s > 2 -> rectangle (int)s x (int)s:
  *      gx = column sum at x + w/2 minus column sum at x - w/2, gy = row sum at y + h/2 minus row sum
@@ -939,7 +939,7 @@ void kplo_integral_image_normals(const float *xyz, int width, int height, float 
         for (int c = 0; c < W; ++c) {
             const float *e = xyz + 3 * ((size_t)r * (size_t)W + (size_t)c);
             for (int a = 0; a < 3; ++a) cur[3 * (c + 1) + a] = (prev[3 * (c + 1) + a] + cur[3 * c + a]) - prev[3 * c + a];
-            const float s = (e[0] + e[1]) + e[2];
+            const float s = e[0] + (e[1] + e[2]);     /* Eigen's fixed-size Vector3f::sum() reduces as x + (y + z) */
             if (isfinite(s))
                 for (int a = 0; a < 3; ++a) cur[3 * (c + 1) + a] += (double)e[a];
         }

@@ -295,3 +295,65 @@ def test_cli_organized_cloud_without_normals(tmp_path):
     kp = np.loadtxt(out, skiprows=11, dtype=np.float32).reshape(-1, 4)
     assert info["points"] == len(xyz) and info["keypoints"] == len(o_kp) > 0
     assert np.array_equal(kp[:, :3], xyz[o_kp]) and np.array_equal(kp[:, 3], o_sc[o_kp])
+
+
+def test_cli_sorted_search_method(tmp_path):
+    """--sortedSearch: the C++ class is handed pcl::search::KdTree(true) through the inherited setSearchMethod and
+    scores with the neighbors in FLANN's sorted order: same keypoints and responses as the oracle's sorted mode
+    (and not those of the canonical order)."""
+    from oracle import kplo
+    from tests import helpers
+    from tools import forest_yaml
+    z = np.load(os.path.join(GOLD, "cheff000.npz"))
+    n = 30000
+    xyz, nrm = np.ascontiguousarray(z["xyz"][:n]), np.ascontiguousarray(z["nrm"][:n])
+    pcd, out = tmp_path / "view.pcd", tmp_path / "kp.pcd"
+    write_pcd(pcd, xyz, nrm, True)
+    forest = os.path.join(ROOT, "data", "forests", "synth200k_a5b6_t10.yaml.gz")
+    r, rn, thr = float(z["r_feat"]), float(z["r_nms"]), float(np.float32(0.85))
+    cmd = [EXE, "--pathCloud", str(pcd), "--pathRF", forest, "--pathKP=%s" % out, "--radiusFeatures", "%.9g" % r,
+           "--radiusNMS", "%.9g" % rn, "-t", "0.85", "--annuli", "5", "--bins", "6", "--json", "--sortedSearch"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    of = helpers.oracle_forest(forest_yaml.load_forest(forest))
+    r32, rn32 = float(np.float32(r)), float(np.float32(rn))         # the CLI parses its radii as float
+    s_sc, s_kp = kplo.detect(xyz, nrm, 5, 6, r32, rn32, thr, of, order=kplo.ORDER_SORTED, threads=helpers.usable_cores())
+    c_sc, c_kp = kplo.detect(xyz, nrm, 5, 6, r32, rn32, thr, of, threads=helpers.usable_cores())
+    kp = np.loadtxt(out, skiprows=11, dtype=np.float32).reshape(-1, 4)
+    assert len(kp) == len(s_kp) > 0
+    assert np.array_equal(kp[:, :3], xyz[s_kp]) and np.array_equal(kp[:, 3], s_sc[s_kp])
+    assert not np.array_equal(s_sc, c_sc)
+
+
+def test_cli_normals_flip_towards_the_pcd_viewpoint(tmp_path):
+    """A PCD whose VIEWPOINT is not the origin: pcl::PCDReader puts it into sensor_origin_, and both PCL normal
+    estimators flip towards it by default.  TestDetector's own k = 10 normals and the detector's fallback
+    (--detectorNormals) must do the same: the run equals the oracle pipeline with that viewpoint, and differs from
+    the one with the viewpoint at the origin."""
+    from oracle import kplo
+    from tests import helpers
+    from tools import forest_yaml
+    z = np.load(os.path.join(GOLD, "small_case.npz"))
+    xyz = np.ascontiguousarray(z["xyz"][np.isfinite(z["xyz"]).all(axis=1)])
+    vp = (float(xyz[:, 0].mean()), float(xyz[:, 1].mean()), float(xyz[:, 2].max() + 50.0))    # above the surface (the origin is below most of it)
+    pcd, out = tmp_path / "small.pcd", tmp_path / "kp.pcd"
+    write_pcd(pcd, xyz, None, True)
+    raw = open(pcd, "rb").read().replace(b"VIEWPOINT 0 0 0 1 0 0 0", b"VIEWPOINT %.9g %.9g %.9g 1 0 0 0" % vp)
+    open(pcd, "wb").write(raw)
+    vp32 = tuple(float(np.float32(float("%.9g" % v))) for v in vp)
+    forest = os.path.join(GOLD, "small_forest.yaml.gz")
+    fa = forest_yaml.load_forest(forest)
+    mr = kplo.cloud_resolution(xyz)
+    r, rn = float(np.float32(6 * mr)), float(np.float32(4 * mr))
+    base = [EXE, "--pathCloud", str(pcd), "--pathRF", forest, "--radiusFeatures", "6", "--pathKP=%s" % out,
+            "--radiusNMS", "4", "--radiusInMr", "--annuli", "5", "--bins", "6", "-t", "0.5", "--json"]
+    for extra, kw in (([], dict(k=10)), (["--detectorNormals"], dict(k=0, radius=r))):
+        res = subprocess.run(base + extra, capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, res.stderr
+        nrm, _ = kplo.estimate_normals(xyz, viewpoint=vp32, **kw)
+        nrm0, _ = kplo.estimate_normals(xyz, viewpoint=(0, 0, 0), **kw)
+        assert np.mean(np.sign(nrm[:, 2]) != np.sign(nrm0[:, 2])) > 0.2          # the viewpoint does flip many of them
+        o_sc, o_kp = kplo.detect(xyz, nrm, 5, 6, r, rn, float(np.float32(0.5)), helpers.oracle_forest(fa))
+        kp = np.loadtxt(out, skiprows=11, dtype=np.float32).reshape(-1, 4)
+        assert len(kp) == len(o_kp) > 0
+        assert np.array_equal(kp[:, :3], xyz[o_kp]) and np.array_equal(kp[:, 3], o_sc[o_kp])

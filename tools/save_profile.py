@@ -18,6 +18,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from pmc_summary import summarize  # noqa: E402
+import valu_model  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SIMDS = 256 * 4
@@ -47,12 +48,14 @@ def main():
                     avg_ns[k] = float(r["AverageNs"])
                     calls[k] = int(r["Calls"])
     pmc = {}
-    for suffix in ("fetch", "write", "sq", "ta"):
+    for suffix in ("fetch", "write", "sq", "ta", "valu", "lds"):
         agg, meta = summarize(os.path.join(out_dir, "pmc_%s_%s" % (tag, suffix)))
         for k, counters in agg.items():
             for c, vals in counters.items():
                 pmc.setdefault(k, {})[c] = mean(vals)
                 pmc[k]["launches_" + c] = len(vals)
+                if c == "GRBM_GUI_ACTIVE":                       # every pass has its own clock: keep them apart
+                    pmc[k]["GRBM_GUI_ACTIVE_" + suffix] = mean(vals)
             pmc[k]["vgpr/agpr/sgpr/lds/scratch/wg/grid"] = meta[k]
     json.dump(pmc, open(os.path.join(prof, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
     bench_json = os.path.join(out_dir, tag + "_bench.json")
@@ -60,6 +63,11 @@ def main():
     if os.path.exists(bench_json) and os.path.getsize(bench_json) > 0:
         shutil.copy(bench_json, os.path.join(prof, tag + "_bench.json"))
         views = json.load(open(bench_json))["config"].get("views_per_launch")
+    ceiling = None
+    cpath = os.path.join(out_dir, tag + "_valu_ceiling.json")
+    if os.path.exists(cpath) and os.path.getsize(cpath) > 0:
+        shutil.copy(cpath, os.path.join(prof, tag + "_valu_ceiling.json"))
+        ceiling = json.load(open(cpath))
     kernels = {}
     for k in ("feature_kernel<false>", "forest_kernel<false>"):
         c = pmc.get(k)
@@ -78,16 +86,27 @@ def main():
                 e["waves_per_simd"] = round(c["SQ_WAVE_CYCLES"] * 4.0 / (SIMDS * cycles), 3)
             if c.get("TA_BUSY_avr") is not None:       # (its own pass: cycles of that pass)
                 e["ta_busy"] = round(c["TA_BUSY_avr"] / cycles, 4)
-            for name in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "SQ_INSTS_VMEM_RD"):
+            for name in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS",
+                         "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"):
                 if c.get(name) is not None:
                     e[name] = round(c[name], 1)
+            # VALU issue model: instructions by class x the issue ceilings measured on this box
+            if ceiling and c.get("SQ_INSTS_VALU_ADD_F32") is not None:
+                mangled = {"feature_kernel<false>": "feature_kernelILb0", "forest_kernel<false>": "forest_kernelILb0"}[k]
+                e["valu_model"] = valu_model.model(c, c.get("GRBM_GUI_ACTIVE_valu", c["GRBM_GUI_ACTIVE"]) / XCDS, ceiling, mangled)
+                e["valu_issue_frac"] = e["valu_model"]["valu_issue_frac"]
+            if c.get("SQ_LDS_BANK_CONFLICT") is not None and c.get("SQ_ACTIVE_INST_LDS"):
+                # SQ_ACTIVE_INST_LDS / SQ_LDS_BANK_CONFLICT count quad-cycles summed over the SIMDs (MI355X_MICROARCH.md)
+                e["lds_busy"] = round(c["SQ_ACTIVE_INST_LDS"] * 4.0 / (SIMDS * c.get("GRBM_GUI_ACTIVE_lds", c["GRBM_GUI_ACTIVE"]) / XCDS), 4)
+                e["lds_bank_conflict_share"] = round(c["SQ_LDS_BANK_CONFLICT"] / max(c["SQ_ACTIVE_INST_LDS"], 1.0), 4)
         kernels[k.split("<")[0]] = e
     json.dump({"tag": tag, "source_sha256": sha, "views_per_launch": views, "kernels": kernels,
                "formulas": {"hbm_bytes": "(2*FETCH_SIZE + WRITE_SIZE) KiB * 1024, separate rocprofv3 --pmc passes",
-                            "valu_busy": "SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * GRBM_GUI_ACTIVE / 8)",
+                            "valu_busy": "SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * GRBM_GUI_ACTIVE / 8): an UPPER bound (4 cycles per instruction)",
+                            "valu_issue_frac": "tools/valu_model.py: sum over instruction classes of count x measured issue cycles (tools/valu_ceiling.hip on this box) / (1024 SIMDs x kernel cycles)",
                             "waves_per_simd": "SQ_WAVE_CYCLES * 4 / (1024 SIMDs * GRBM_GUI_ACTIVE / 8)",
                             "ta_busy": "TA_BUSY_avr / (GRBM_GUI_ACTIVE / 8): the texture-addresser's busy cycles, average over its instances"},
-               "files": [tag + "_kernel_stats.csv", tag + "_pmc.json", tag + "_bench.json"]},
+               "files": [tag + "_kernel_stats.csv", tag + "_pmc.json", tag + "_bench.json", tag + "_valu_ceiling.json"]},
               open(os.path.join(prof, "counters.json"), "w"), indent=1)
     print("saved", tag, "->", prof, "kernels:", sorted(kernels))
 
