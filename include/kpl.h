@@ -186,6 +186,14 @@ int kpl_compute_features_device(kpl_detector *h, const int *d_indices, int m,
 int kpl_compute_batch_device(kpl_detector *const *handles, int count, float *const *d_scores,
                              int *const *d_kp_idx, const int *kp_caps, int *const *d_kp_counts,
                              void *stream);
+/* The same batch for a caller that wants what detectKeypoints() leaves behind and nothing else (the device
+ * counterpart of kpl_detect_keypoints): per view the keypoint indices, the forest response OF THE KEYPOINTS
+ * (d_kp_scores[v][j] belongs to d_kp_idx[v][j]; the array or single entries may be NULL) and the count.  The
+ * three outputs of a view may be one packed buffer [count][indices][responses] -- what a multi-GPU caller
+ * contributes to its all-gather as it stands (csrc/batch_views_main.cpp). */
+int kpl_compute_batch_keypoints_device(kpl_detector *const *handles, int count, int *const *d_kp_idx,
+                                       float *const *d_kp_scores, const int *kp_caps, int *const *d_kp_counts,
+                                       void *stream);
 /* The device entry points never wait for the GPU: the grid descriptor is computed on the device.
  * Two conditions can therefore only be seen afterwards -- a view that needs more than 2^28 grid
  * cells, or more cells than the handle's tables currently hold (they start at 8*n + 65536 cells).

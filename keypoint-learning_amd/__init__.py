@@ -82,6 +82,7 @@ SYMBOLS = {
     "kpl_compute_device": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
     "kpl_compute_features_device": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),
     "kpl_compute_batch_device": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
+    "kpl_compute_batch_keypoints_device": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "kpl_sync_status": (C.c_int, [_vp, _vp]),
     "kpl_enable_timing": (C.c_int, [_vp, C.c_int]),
     "kpl_get_timing": (C.c_int, [_vp, C.POINTER(Timing)]),

@@ -55,8 +55,9 @@ def build(force=False, verbose=False):
             # own device buffers)
             cmd = ["g++", "-O2", "-std=c++14", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(HERE, "..", "include"),
                    "-I", "/opt/rocm/include"] + tpaths + \
-                  ["-o", exe, "-L", HERE, "-lkpl", "-L", "/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,$ORIGIN",
-                   "-Wl,-rpath,/opt/rocm/lib"]
+                  ["-o", exe, "-L", HERE, "-lkpl", "-L", "/opt/rocm/lib", "-lamdhip64"] + \
+                  (["-lrccl", "-pthread"] if name == "DetectViews" else []) + \
+                  ["-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

@@ -809,6 +809,30 @@ int kpl_compute_batch_device(kpl_detector *const *handles, int count, float *con
     return run_batch(handles, count, d_scores, d_kp_idx, kp_caps, d_kp_counts, nullptr, true, (hipStream_t)stream);
 }
 
+int kpl_compute_batch_keypoints_device(kpl_detector *const *handles, int count, int *const *d_kp_idx,
+                                       float *const *d_kp_scores, const int *kp_caps, int *const *d_kp_counts, void *stream) {
+    if (!handles || count <= 0 || !d_kp_idx || !kp_caps || !d_kp_counts) return KPL_ERR_INVALID_ARG;
+    for (int k = 0; k < count; ++k)
+        if (!handles[k]) return KPL_ERR_INVALID_ARG;
+    kpl_detector *h0 = handles[0];
+    if (count > kMaxBatch) return fail(h0, KPL_ERR_INVALID_ARG, "at most %d views per batch", kMaxBatch);
+    int rc = use_device(h0);
+    if (rc) return rc;
+    float *scratch[kMaxBatch];               // the response of every point stays in a scratch array of the handle
+    for (int k = 0; k < count; ++k) {
+        kpl_detector *h = handles[k];
+        if (h->device != h0->device) return fail(h0, KPL_ERR_INVALID_ARG, "all views of a batch must live on one device");
+        for (int j = 0; j < k; ++j)
+            if (handles[j] == h) return fail(h0, KPL_ERR_INVALID_ARG, "a handle appears twice in the batch");
+        if (h->out_scores.cap < sizeof(float) * (size_t)(h->n > 0 ? h->n : 1)) {
+            KPL_HIP(h0, hipDeviceSynchronize());         // (grow-only; an earlier call may still write the old array)
+            KPL_HIP(h0, h->out_scores.ensure(sizeof(float) * (size_t)(h->n > 0 ? h->n : 1)));
+        }
+        scratch[k] = h->out_scores.as<float>();
+    }
+    return run_batch(handles, count, scratch, d_kp_idx, kp_caps, d_kp_counts, nullptr, true, (hipStream_t)stream, d_kp_scores);
+}
+
 int kpl_compute_features_device(kpl_detector *h, const int *d_indices, int m, float *d_features, void *stream) {
     if (!h) return KPL_ERR_INVALID_ARG;
     if (m < 0 || (m > 0 && (!d_indices || !d_features))) return fail(h, KPL_ERR_INVALID_ARG, "null index or feature buffer");

@@ -247,7 +247,7 @@ def test_detect_views_batches_like_single_runs(tmp_path):
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
     rows = [json.loads(ln) for ln in res.stdout.strip().splitlines()]
-    assert len(rows) == 3
+    assert len(rows) == 4 and rows[-1]["devices"] == 1 and rows[-1]["views"] == 3       # per view + the summary line
     for row, (n, kp) in zip(rows, expect):
         assert row["points"] == n and row["keypoints"] == len(kp) > 0 and row["index_checksum"] == int(kp.astype(np.int64).sum())
     assert os.path.exists(tmp_path / "kp2.pcd")
@@ -357,3 +357,35 @@ def test_cli_normals_flip_towards_the_pcd_viewpoint(tmp_path):
         kp = np.loadtxt(out, skiprows=11, dtype=np.float32).reshape(-1, 4)
         assert len(kp) == len(o_kp) > 0
         assert np.array_equal(kp[:, :3], xyz[o_kp]) and np.array_equal(kp[:, 3], o_sc[o_kp])
+
+
+def test_detect_views_all_devices_equals_test_detector(tmp_path):
+    """DetectViews --devices all: the C++ multi-GPU runner (one host thread per device, views dealt round robin,
+    results gathered with ONE ncclAllGather of the packed [count][indices][responses] buffers, written out from
+    device 0's copy).  On this box "all" is one device, RCCL still runs.  Every keypoint file must equal, byte for
+    byte, the one TestDetector writes for the same view -- in the canonical and in the sorted neighbor order."""
+    from tools import synth
+    exe = os.path.join(ROOT, "keypoint-learning_amd", "DetectViews")
+    forest = os.path.join(ROOT, "data", "forests", "synth200k_a5b6_t10.yaml.gz")
+    files = []
+    for k, (nx, ny) in enumerate([(60, 50), (45, 70), (80, 30), (64, 64), (33, 90), (70, 41), (52, 52), (48, 60), (90, 25), (40, 40), (75, 44)]):
+        xyz, nrm = synth.make_cloud(nx, ny, seed=160 + k)
+        pcd = tmp_path / ("v%02d.pcd" % k)
+        write_pcd(pcd, xyz, nrm if k % 3 else None, True)            # every third file without normals: estimated (k = 10)
+        files.append(str(pcd))
+    common = ["--pathRF", forest, "--radiusFeatures", "6", "--radiusNMS", "4", "--radiusInMr", "--annuli", "5", "--bins", "6", "-t", "0.85"]
+    for extra in ([], ["--sortedSearch"]):
+        res = subprocess.run([exe] + common + extra + ["--devices", "all", "--rounds", "3", "--pathKP", str(tmp_path / "multi")] + files,
+                             capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stdout + res.stderr
+        rows = [json.loads(ln) for ln in res.stdout.strip().splitlines()]
+        summary = rows[-1]
+        assert len(rows) == len(files) + 1 and summary["views"] == len(files) and summary["devices"] >= 1
+        assert "ncclAllGather" in summary["exchange"] and summary["Mpoints_per_s"] > 0
+        for k, f in enumerate(files):
+            out = tmp_path / "single.pcd"
+            one = subprocess.run([EXE, "--pathCloud", f, "--pathKP=%s" % out, "--json"] + common + extra, capture_output=True, text=True, timeout=300)
+            assert one.returncode == 0, one.stderr
+            info = json.loads(one.stdout.strip().splitlines()[-1])
+            assert rows[k]["keypoints"] == info["keypoints"] > 0 and rows[k]["points"] == info["points"]
+            assert open(out).read() == open(str(tmp_path / "multi") + "%d.pcd" % k).read(), (k, extra)

@@ -36,11 +36,28 @@ def main():
     ap.add_argument("--ny", type=int, default=250)
     ap.add_argument("--rounds", type=int, default=20, help="timed repetitions of the whole 64-view job")
     ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--write-pcd", metavar="DIR", default=None,
+                    help="only write the views as binary .pcd files (x y z normal_x normal_y normal_z) into DIR and exit: the "
+                         "input of the C++ runner, keypoint-learning_amd/DetectViews --devices all DIR/view*.pcd")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--parity-all", action="store_true", help="rank 0 checks ALL its views against the oracle, not the first 4")
     ap.add_argument("--force-dist", action="store_true",
                     help="world size 1: create the process group anyway, so that the all-gather (RCCL) runs on one GPU")
     args = ap.parse_args()
+    if args.write_pcd:
+        from tools import synth
+        os.makedirs(args.write_pcd, exist_ok=True)
+        for v in range(args.views):
+            xyz, nrm = synth.make_cloud(args.nx, args.ny, seed=100 + v)
+            xyz, nrm = synth.shuffle_cloud(xyz, nrm, 1100 + v)
+            arr = np.concatenate([xyz, nrm], axis=1).astype(np.float32)
+            with open(os.path.join(args.write_pcd, "view%02d.pcd" % v), "wb") as f:
+                f.write(("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z normal_x normal_y normal_z\n"
+                         "SIZE 4 4 4 4 4 4\nTYPE F F F F F F\nCOUNT 1 1 1 1 1 1\nWIDTH %d\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\n"
+                         "POINTS %d\nDATA binary\n" % (len(arr), len(arr))).encode())
+                f.write(arr.tobytes())
+        print(json.dumps({"wrote": args.views, "dir": args.write_pcd, "points_per_view": args.nx * args.ny}))
+        return
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
