@@ -246,7 +246,7 @@ def test_detect_views_batches_like_single_runs(tmp_path):
            "-t", "0.85", "--flipNormals", "--pathKP", str(tmp_path / "kp")] + files
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
-    rows = [json.loads(ln) for ln in res.stdout.strip().splitlines()]
+    rows = [json.loads(ln) for ln in res.stdout.strip().splitlines() if ln.startswith("{")]     # (RCCL prints a banner)
     assert len(rows) == 4 and rows[-1]["devices"] == 1 and rows[-1]["views"] == 3       # per view + the summary line
     for row, (n, kp) in zip(rows, expect):
         assert row["points"] == n and row["keypoints"] == len(kp) > 0 and row["index_checksum"] == int(kp.astype(np.int64).sum())
@@ -378,7 +378,7 @@ def test_detect_views_all_devices_equals_test_detector(tmp_path):
         res = subprocess.run([exe] + common + extra + ["--devices", "all", "--rounds", "3", "--pathKP", str(tmp_path / "multi")] + files,
                              capture_output=True, text=True, timeout=600)
         assert res.returncode == 0, res.stdout + res.stderr
-        rows = [json.loads(ln) for ln in res.stdout.strip().splitlines()]
+        rows = [json.loads(ln) for ln in res.stdout.strip().splitlines() if ln.startswith("{")]
         summary = rows[-1]
         assert len(rows) == len(files) + 1 and summary["views"] == len(files) and summary["devices"] >= 1
         assert "ncclAllGather" in summary["exchange"] and summary["Mpoints_per_s"] > 0
