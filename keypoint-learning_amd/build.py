@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libkpl.so")
 SOURCES = ["kernels.hip", "organized_normals.hip", "api.cpp", "forest.cpp"]
-HEADERS = ["kernels.h", "organized_normals.h", "forest.h", os.path.join("..", "..", "include", "kpl.h")]
+HEADERS = ["kernels.h", "exact_math.h", "organized_normals.h", "forest.h", os.path.join("..", "..", "include", "kpl.h")]
 TOOLS = {"TestDetector": ["test_detector_main.cpp"], "DetectViews": ["batch_views_main.cpp"]}
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -67,6 +67,14 @@ def build(force=False, verbose=False):
     vexe = os.path.join(HERE, "..", "tools", "valu_ceiling")
     if os.path.exists(vsrc) and (force or _stale(vexe, [vsrc])):
         cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-o", vexe, vsrc]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    # exhaustive device-side check of exact_math.h's sqrt_rn against sqrtf (tests/test_gpu_exact_math.py)
+    csrc_ = os.path.join(HERE, "..", "tools", "check_exact_math.hip")
+    cexe = os.path.join(HERE, "..", "tools", "check_exact_math")
+    if os.path.exists(csrc_) and (force or _stale(cexe, [csrc_, os.path.join(CSRC, "exact_math.h")])):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-I", CSRC, "-o", cexe, csrc_]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

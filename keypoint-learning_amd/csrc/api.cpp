@@ -140,6 +140,8 @@ FeatDesc make_feat(const kpl_params &p) {
     f.A = p.n_annulus;
     f.B = p.n_bins;
     f.F = p.n_annulus * p.n_bins;
+    f.A1f = (float)(f.A - 1);
+    f.B1f = (float)(f.B - 1);
     f.support = (float)p.radius_search;       // double search_radius_ -> float `support`
     f.ann_dim = f.support / (float)f.A;       // cpp:43
     f.ann_half = f.ann_dim / 2;               // cpp:52

@@ -28,6 +28,7 @@ struct GridDesc {
 
 struct FeatDesc {
     int A, B, F;
+    float A1f, B1f;  // (float)(A - 1), (float)(B - 1): the clamp of the soft-assignment index in the float domain
     float support;   // (float)radius_search, the `support` argument of findAnnulusPair
     float ann_dim;   // support / A
     float ann_half;  // ann_dim / 2

@@ -7,6 +7,7 @@
 // Path: /root/reference/include/impl/KeypointLearning.hpp:179-376 and
 // /root/reference/src/KeypointLearning.cpp:41-92; per-kernel citations below.
 #include "kernels.h"
+#include "exact_math.h"
 
 #ifdef KPL_ABLATE
 #error "KPL_ABLATE timing experiments are not part of libkpl: build them from a scratch copy of this file"
@@ -696,25 +697,17 @@ __global__ __launch_bounds__(256) void pos_of_kernel(Batch b) {
 // RN(1/dim) are per-launch constants computed on the host with float operations.  The
 // reference's assert on the index range is replaced by a clamp (no effect on in-range values).
 //
-// div_rn(a, b, rb) returns the correctly rounded float quotient a / b, bit-identical to the IEEE
-// division the reference performs, in 3 instructions instead of hipcc's ~11-instruction
-// expansion: with rb = RN(1/b), q = RN(a*rb) is within one ulp of a/b, r = a - q*b is exact in
-// one FMA, and RN(q + r*rb) is the correctly rounded quotient (Markstein's division theorem;
-// b is a positive normal constant here and a/b stays far from overflow; a quotient that
-// underflows is only ever floored to 0).  The FMAs are explicit, -ffp-contract=off stays in force
-// for everything else.  tests/test_division.py checks it against true division.
+// div_rn(a, b, rb) = the correctly rounded quotient a / b in 3 instructions, sqrt_rn(x) = the correctly rounded
+// square root in 9: exact_math.h.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float div_rn(float a, float b, float rb) {
-    const float q = a * rb;
-    const float r = __builtin_fmaf(-q, b, a);
-    return __builtin_fmaf(r, rb, q);
-}
-
-__device__ __forceinline__ void soft_pair(int n, float v, float dim, float half_dim, float rdim,
+__device__ __forceinline__ void soft_pair(int n, float nm1, float v, float dim, float half_dim, float rdim,
                                           int &k, int &p, float &w) {
-    k = (int)floorf(div_rn(v, dim, rdim));
-    k = min(max(k, 0), n - 1);            // includes "if (k == n) k--" (cpp:47-48, :78-79): n -> n - 1
-    float center = ((float)k * dim) + half_dim;
+    // k = (int)floor(v / dim) and "if (k == n) k--" (cpp:45-48, :76-79).  v >= 0 here (a square root; a cosine
+    // clamped to [0, 2]), so k >= 0, and the floor -- an integer-valued float far below 2^24 -- clamped to
+    // nm1 = (float)(n - 1) IS the (float)k of cpp:52 / :83: no round trip through the integer
+    const float kf = fminf(floorf(div_rn(v, dim, rdim)), nm1);
+    k = (int)kf;
+    float center = (kf * dim) + half_dim;
     float wt = v - center;
     wt = div_rn(wt, dim, rdim);
     p = (wt > 0) ? k + 1 : k - 1;
@@ -774,9 +767,9 @@ __device__ __forceinline__ Contribution neighbor_contribution(const FeatDesc &f,
     float cosine = 1 - dot;
     int a, ap, bi, bp;
     float aw, bw;
-    soft_pair(f.A, sqrtf(d2), f.ann_dim, f.ann_half, f.ann_rdim, a, ap, aw);       // hpp:345
+    soft_pair(f.A, f.A1f, sqrt_rn(d2), f.ann_dim, f.ann_half, f.ann_rdim, a, ap, aw);   // hpp:345
     cosine = fminf(fmaxf(cosine, 0.0f), 2.0f);                                     // cpp:70-73
-    soft_pair(f.B, cosine, f.bin_dim, f.bin_half, f.bin_rdim, bi, bp, bw);         // hpp:348
+    soft_pair(f.B, f.B1f, cosine, f.bin_dim, f.bin_half, f.bin_rdim, bi, bp, bw);          // hpp:348
     Contribution c;
     c.w00 = (1 - bw) * (1 - aw);
     c.w01 = bw * (1 - aw);
@@ -931,6 +924,13 @@ __device__ __forceinline__ unsigned group_or(unsigned v) {
 
 // x without its highest set bit (0 stays 0)
 __device__ __forceinline__ unsigned drop_first_bit(unsigned x) { return x & (0x7fffffffu >> (__clz((int)x) & 31)); }
+// The accept words are BUILT with the first candidate in the highest bit (the sign bits are shifted in from the
+// right) and STORED bit-reversed, first candidate = bit 0: taking the next neighbor off a word is then x & (x - 1)
+// and its position a count of trailing zeros -- two full-rate instructions instead of four half-rate ones per taken
+// bit (tools/valu_ceiling.hip: v_add_u32 / v_and_b32 issue in 2.4 cycles, v_ffbh / v_min / v_lshrrev in 4.2).
+__device__ __forceinline__ unsigned drop_lowest_bit(unsigned x) { return x & (x - 1u); }
+// position of the lowest set bit of m (any value when m == 0: the callers discard it)
+__device__ __forceinline__ int lowest_bit_index(unsigned m) { return __builtin_ctz(m | 0x80000000u); }
 
 template <int G>
 __device__ __forceinline__ int point_features(const float4 *__restrict__ pts, const float4 *__restrict__ nrm,
@@ -947,6 +947,8 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts, co
     f.A = pin_i(fin.A);
     f.B = pin_i(fin.B);
     f.F = pin_i(fin.F);
+    f.A1f = pin_f(fin.A1f);
+    f.B1f = pin_f(fin.B1f);
     f.support = fin.support;
     f.ann_dim = pin_f(fin.ann_dim);
     f.ann_half = pin_f(fin.ann_half);
@@ -1025,7 +1027,7 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts, co
                 first_pending = false;
             }
             if (w != 0u) {
-                if (gq == 0) ent[ecnt * kPts + pi] = make_uint2((unsigned)wbase, w);
+                if (gq == 0) ent[ecnt * kPts + pi] = make_uint2((unsigned)wbase, __brev(w));     // first candidate = bit 0
                 ++ecnt;
             }
             full = __any(ecnt == ecap);
@@ -1050,16 +1052,16 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts, co
                 // the next G set bits of the word, one per lane (a round never spans two words)
                 unsigned m;
                 if (G == 2) {
-                    const unsigned c1 = drop_first_bit(w);
+                    const unsigned c1 = drop_lowest_bit(w);
                     m = gq == 0 ? w : c1;
-                    w = drop_first_bit(c1);
+                    w = drop_lowest_bit(c1);
                 } else {
-                    const unsigned c1 = drop_first_bit(w), c2 = drop_first_bit(c1), c3 = drop_first_bit(c2);
+                    const unsigned c1 = drop_lowest_bit(w), c2 = drop_lowest_bit(c1), c3 = drop_lowest_bit(c2);
                     m = gq == 0 ? w : gq == 1 ? c1 : gq == 2 ? c2 : c3;
-                    w = drop_first_bit(c3);
+                    w = drop_lowest_bit(c3);
                 }
                 slot.valid = m != 0u;
-                const int tt = slot.valid ? wbase + (__clz((int)m) & 31) : 0;
+                const int tt = slot.valid ? wbase + lowest_bit_index(m) : 0;
                 slot.q = ld12(pts, tt);
                 slot.n = ld12(nrm, tt);
             };
@@ -1263,6 +1265,8 @@ __device__ __forceinline__ int point_features_sorted(const float4 *__restrict__ 
     f.A = pin_i(fin.A);
     f.B = pin_i(fin.B);
     f.F = pin_i(fin.F);
+    f.A1f = pin_f(fin.A1f);
+    f.B1f = pin_f(fin.B1f);
     f.support = fin.support;
     f.ann_dim = pin_f(fin.ann_dim);
     f.ann_half = pin_f(fin.ann_half);
@@ -1294,7 +1298,7 @@ __device__ __forceinline__ int point_features_sorted(const float4 *__restrict__ 
                 if (!rs.next_word(wbase, w)) break;
                 if (pass == 0) kf += __popc(w);
                 if (w != 0u) {
-                    if (gq == 0) ent[ecnt * kPts + pi] = make_uint2((unsigned)wbase, w);
+                    if (gq == 0) ent[ecnt * kPts + pi] = make_uint2((unsigned)wbase, __brev(w));     // first candidate = bit 0
                     ++ecnt;
                 }
                 full = __any(ecnt == ecap);
@@ -1316,17 +1320,17 @@ __device__ __forceinline__ int point_features_sorted(const float4 *__restrict__ 
                     wbase = refill ? (int)nw.x : wbase;
                     e += refill ? 1 : 0;
                     nw = ent[min(e * kPts + pi, ent_last)];
-                    const unsigned c1 = drop_first_bit(w), c2 = drop_first_bit(c1), c3 = drop_first_bit(c2);
+                    const unsigned c1 = drop_lowest_bit(w), c2 = drop_lowest_bit(c1), c3 = drop_lowest_bit(c2);
                     unsigned m;
                     if (G == 2) {
                         m = gq == 0 ? w : c1;
                         w = c2;
                     } else {
                         m = gq == 0 ? w : gq == 1 ? c1 : gq == 2 ? c2 : c3;
-                        w = drop_first_bit(c3);
+                        w = drop_lowest_bit(c3);
                     }
                     slot.valid = m != 0u;
-                    const int tt = slot.valid ? wbase + (__clz((int)m) & 31) : 0;
+                    const int tt = slot.valid ? wbase + lowest_bit_index(m) : 0;
                     slot.q = pts[tt];
                 };
                 auto collect = [&](Taken &now) {
