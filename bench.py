@@ -95,6 +95,10 @@ def load_profile(views_per_launch):
     return prof, None
 
 
+def iso_ms_val(t):
+    return t["feature_ms"] / max(t["calls"], 1)
+
+
 def main():
     # the oracle's OpenMP workers must sleep, not spin, once the parity gate is done: spinning
     # workers would compete with the thread that enqueues the timed steps
@@ -371,6 +375,21 @@ def main():
             torch.cuda.synchronize()
             ts.append((time.perf_counter() - c0) * 1e3)
         h2d_ms = float(np.median(ts[2:]))
+        # the same view through PINNED staging buffers of the handle (kpl_host_staging, what the class does with
+        # setHostStaging(true)): packed 12-byte records filled by the caller beforehand, DMA uploads inside compute()
+        sx, sn = dets[0].hostStaging(n, 12, 12)
+        c0 = time.perf_counter()
+        sx[:, :3] = xyz0
+        sn[:, :3] = nrm0
+        fill_ms = (time.perf_counter() - c0) * 1e3
+        ts = []
+        for k in range(14):
+            c0 = time.perf_counter()
+            rc = lib.kpl_detect_keypoints_staged(hd, h_kp.ctypes.data, h_kps.ctypes.data, n, C.byref(h_cnt))
+            ts.append((time.perf_counter() - c0) * 1e3)
+            assert rc == 0, dets[0].lastError()
+        staged_ms = float(np.median(ts[3:]))
+        same_staged = bool(np.array_equal(h_kp[:h_cnt.value], d_kp[0][:int(d_cnt[0].item())].cpu().numpy()))
         extras["host_buffer_path"] = {
             "what": "KeypointLearningDetector.compute() on host arrays in PCL layouts (16-B points, 32-B normals, pageable), "
                     "%d points: upload + index + detect + keypoint list back" % n,
@@ -378,8 +397,38 @@ def main():
             "compute_ms_with_all_scores_back": round(host_ms["with_all_scores"], 4),
             "upload_bytes": int(pcl_xyz.nbytes + pcl_nrm.nbytes),
             "same_bytes_as_plain_pageable_copies_ms": round(h2d_ms, 4),
-            "keypoints_identical_to_device_path": same}
+            "keypoints_identical_to_device_path": same,
+            "pinned_staging": {"what": "kpl_host_staging + kpl_detect_keypoints_staged: packed 12-byte xyz / normals in pinned "
+                                       "buffers of the handle (filled beforehand, like setHostStaging(true) does in the setters), "
+                                       "DMA uploads, normals overlapped with the first index kernels",
+                               "compute_ms": round(staged_ms, 4), "Mpoints_per_s": round(n / staged_ms / 1e3, 1),
+                               "upload_bytes": int(2 * 12 * n), "fill_ms_outside_compute": round(fill_ms, 4),
+                               "keypoints_identical_to_device_path": same_staged}}
         dets[0].bindCloudDevice(d_in[0][0].data_ptr(), 12, d_in[0][1].data_ptr(), 12, n)   # back to the resident view
+
+        # ---- the same batch in SORTED-search mode (kpl_params.neighbor_order = KPL_NEIGHBORS_SORTED): neighbors in FLANN's
+        # sorted order, the one order a PCL build can be compared with bit for bit (tests/test_gpu_sorted.py holds the parity)
+        for d in dets[:nb]:
+            d.setSortedSearch(True)
+        for _ in range(3):
+            run_group(0)
+        torch.cuda.synchronize()
+        dets[0].enableTiming(True)
+        c0 = time.perf_counter()
+        for _ in range(20):
+            run_group(0)
+        torch.cuda.synchronize()
+        sorted_ms = (time.perf_counter() - c0) * 1e3 / 20
+        t_sorted = dets[0].getTiming()
+        dets[0].enableTiming(False)
+        for d in dets[:nb]:
+            d.setSortedSearch(False)
+        run_group(0)
+        torch.cuda.synchronize()
+        extras["sorted_search_mode"] = {"what": "one batch of %d views per step, one batch in flight, neighbor_order = sorted" % nb,
+                                        "ms_per_step": round(sorted_ms, 5), "Mpoints_per_s": round(n * nb / sorted_ms / 1e3, 1),
+                                        "feature_kernel_ms": round(t_sorted["feature_ms"] / max(t_sorted["calls"], 1), 5),
+                                        "canonical_feature_kernel_ms_same_conditions": round(iso_ms_val(t_iso), 5) if t_iso else None}
 
         # ---- configs[0]: one small view alone on the GPU (the parity anchor of config 1, tests/golden/cheff000.npz)
         gold = os.path.join(ROOT, "tests", "golden", "cheff000.npz")

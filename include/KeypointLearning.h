@@ -107,10 +107,30 @@ public:
     KeypointLearningDetector &operator=(const KeypointLearningDetector &) = delete;
 
     virtual void setInputCloud(const PointCloudInConstPtr &cloud) {        // hpp:49-57
-        if (normals_ && this->input_ && (cloud != this->input_)) normals_.reset();
+        if (normals_ && this->input_ && (cloud != this->input_)) {
+            normals_.reset();
+            staged_normals_ = false;
+        }
         this->input_ = cloud;
+        if (host_staging_) stage_points();
     }
-    virtual void setNormals(const PointCloudNConstPtr &normals) { normals_ = normals; }
+    virtual void setNormals(const PointCloudNConstPtr &normals) {
+        normals_ = normals;
+        if (host_staging_) stage_normals();
+    }
+
+    // Opt-in (no reference counterpart): copy the cloud and the normals into pinned staging buffers of the engine
+    // WHEN THEY ARE SET (packed 12-byte xyz / normals), so that compute() uploads them by DMA, half the bytes of the
+    // PCL records, the normals overlapped with the first index kernels (kpl_host_staging /
+    // kpl_detect_keypoints_staged).  The price: setInputCloud / setNormals become O(n) copies, and points or normals
+    // modified in place afterwards are not seen until they are set again -- which is why it is off by default (the
+    // reference's setters only keep a pointer).
+    void setHostStaging(bool on) {
+        host_staging_ = on;
+        staged_points_ = staged_normals_ = false;
+        if (on && this->input_) stage_points();
+        if (on && normals_) stage_normals();
+    }
     virtual void setNonMaxima(bool non_maxima) { non_maxima_ = non_maxima; }
     virtual void setNonMaximaDrawsRemove(bool v) { non_maxima_draws_remove_ = v; }
     virtual void setNonMaximaDrawsThreshold(float v) { non_maxima_draws_threshold_ = v; }
@@ -238,6 +258,7 @@ protected:
             }
             if (rc != KPL_OK) return report("initCompute", rc);
             normals_ = normals;
+            if (host_staging_) stage_normals();
         }
         if (normals_->size() != this->surface_->size()) {                   // hpp:149-153
             PCL_ERROR("[pcl::%s::initCompute] normals given, but the number of normals does not match the number of input points!\n", this->name_.c_str());
@@ -268,7 +289,10 @@ protected:
         }
         int count = 0;
         int rc;
-        if (keep_scores_) {
+        if (host_staging_ && staged_points_ && staged_normals_ && staged_n_ == n && !keep_scores_) {
+            scores_.clear();
+            rc = kpl_detect_keypoints_staged(handle_, kp_idx_.data(), kp_score_.data(), n, &count);
+        } else if (keep_scores_) {
             scores_.assign((size_t)n, 0.0f);
             rc = kpl_detect(handle_, n ? &this->input_->points[0].x : nullptr, sizeof(PointInT),
                             n ? &normals_->points[0].normal_x : nullptr, sizeof(NormalT), n, scores_.data(),
@@ -358,6 +382,39 @@ protected:
         return features;
     }
 
+    // setHostStaging: packed copies of the points / normals in the engine's pinned buffers
+    void stage_points() {
+        staged_points_ = staged_normals_ = false;
+        if (!handle_ || !this->input_) return;
+        const int n = (int)this->input_->points.size();
+        void *px = nullptr, *pn = nullptr;
+        if (kpl_host_staging(handle_, n, 12, 12, &px, &pn) != KPL_OK) return;
+        float *o = static_cast<float *>(px);
+        for (int i = 0; i < n; ++i, o += 3) {
+            const PointInT &p = this->input_->points[(size_t)i];
+            o[0] = p.x;
+            o[1] = p.y;
+            o[2] = p.z;
+        }
+        staged_n_ = n;
+        staged_points_ = true;
+        if (normals_) stage_normals();
+    }
+    void stage_normals() {
+        staged_normals_ = false;
+        if (!handle_ || !staged_points_ || !normals_ || (int)normals_->points.size() != staged_n_) return;
+        void *px = nullptr, *pn = nullptr;
+        if (kpl_host_staging(handle_, staged_n_, 12, 12, &px, &pn) != KPL_OK) return;      // (same size: the same buffers)
+        float *o = static_cast<float *>(pn);
+        for (int i = 0; i < staged_n_; ++i, o += 3) {
+            const NormalT &q = normals_->points[(size_t)i];
+            o[0] = q.normal_x;
+            o[1] = q.normal_y;
+            o[2] = q.normal_z;
+        }
+        staged_normals_ = true;
+    }
+
     bool report(const char *where, int rc) const {
         PCL_ERROR("[pcl::%s::%s] %s: %s\n", this->name_.c_str(), where, kpl_status_string(rc),
                   handle_ ? kpl_last_error(handle_) : "no HIP device (there is no CPU fallback)");
@@ -376,6 +433,8 @@ protected:
     std::vector<int> kp_idx_;            // grow-only landing buffers of detectKeypoints
     std::vector<float> kp_score_;
     bool keep_scores_ = false;
+    bool host_staging_ = false, staged_points_ = false, staged_normals_ = false;
+    int staged_n_ = 0;
     int sorted_search_ = -1;             // -1: follow the search method (tree_), 0 / 1: setSortedSearch
     kpl_detector *handle_ = nullptr;
     int create_status_ = KPL_OK;

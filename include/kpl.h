@@ -155,6 +155,16 @@ int kpl_detect_keypoints(kpl_detector *h, const void *xyz, size_t xyz_stride,
                          const void *normals, size_t normals_stride, int n,
                          int *kp_idx_out, float *kp_scores_out, int kp_cap, int *kp_count);
 
+/* The same for a caller that can put its view into PINNED host memory: kpl_host_staging returns two buffers of
+ * the handle (grow-only, valid until the next kpl_host_staging or kpl_destroy) for n points at the given strides
+ * (12 = packed xyz / normals; 16 and 32 = pcl::PointXYZ / pcl::Normal records, filled with one memcpy); the caller
+ * fills them -- include/KeypointLearning.h does in setInputCloud / setNormals when setHostStaging(true) -- and
+ * kpl_detect_keypoints_staged runs compute() on them: the uploads are true DMA copies on a stream of their own, the
+ * points first; the index kernels that read only points run while the normals are still in flight.  (Pageable
+ * memory, kpl_detect_keypoints: the runtime stages the copies through its own pinned buffer on the calling thread.) */
+int kpl_host_staging(kpl_detector *h, int n, size_t xyz_stride, size_t normals_stride, void **xyz, void **normals);
+int kpl_detect_keypoints_staged(kpl_detector *h, int *kp_idx_out, float *kp_scores_out, int kp_cap, int *kp_count);
+
 /* computePointsForTrainingFeatures (hpp:299-318): features of the listed points, m x
  * (n_annulus*n_bins) floats, row major.  A row of a point with non-finite xyz is NaN. */
 int kpl_compute_features(kpl_detector *h, const void *xyz, size_t xyz_stride,

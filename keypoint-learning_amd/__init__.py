@@ -74,6 +74,8 @@ SYMBOLS = {
                                            _vp, C.c_char_p, C.c_size_t]),
     "kpl_detect": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_int, _vp, _vp, C.c_int, _ip]),
     "kpl_detect_keypoints": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_int, _vp, _vp, C.c_int, _ip]),
+    "kpl_host_staging": (C.c_int, [_vp, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(_vp), C.POINTER(_vp)]),
+    "kpl_detect_keypoints_staged": (C.c_int, [_vp, _vp, _vp, C.c_int, _ip]),
     "kpl_compute_features": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_int, _vp,
                                        C.c_int, _vp]),
     "kpl_bind_cloud_device": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_int]),
@@ -330,6 +332,28 @@ class KeypointLearningDetector:
         self._check(rc)
         self.keypoints_indices = kp[:cnt.value].copy()
         return np.concatenate([xyz[self.keypoints_indices, :3], kps[:cnt.value, None]], axis=1), None
+
+    def hostStaging(self, n, xyz_stride=12, normals_stride=12):
+        """kpl_host_staging: two pinned host buffers of the handle as writable numpy views ([n, stride / 4] float32);
+        fill them (first three floats of a row = xyz resp. normal) and call computeStaged()."""
+        px, pn = _vp(), _vp()
+        self._check(self._lib.kpl_host_staging(self._h, int(n), xyz_stride, normals_stride, C.byref(px), C.byref(pn)))
+        mk = lambda p, stride: np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(max(n, 1), stride // 4))[:n]
+        self._stage_cap = max(int(n), 1)
+        return mk(px, xyz_stride), mk(pn, normals_stride)
+
+    def computeStaged(self):
+        """kpl_detect_keypoints_staged: compute() on the staged view.  Returns (indices, responses of the keypoints)."""
+        self._push()
+        cnt = C.c_int()
+        kp = np.empty(self._kp_cap_hint(), dtype=np.int32)
+        kps = np.empty(len(kp), dtype=np.float32)
+        self._check(self._lib.kpl_detect_keypoints_staged(self._h, kp.ctypes.data, kps.ctypes.data, len(kp), C.byref(cnt)))
+        self.keypoints_indices = kp[:cnt.value].copy()
+        return self.keypoints_indices, kps[:cnt.value].copy()
+
+    def _kp_cap_hint(self):
+        return max(getattr(self, "_stage_cap", 1), 1)
 
     def cloudResolution(self, cloud):
         """kpl::computeCloudResolution of the reference: mean distance to the second nearest neighbor."""

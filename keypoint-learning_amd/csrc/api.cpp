@@ -78,6 +78,12 @@ struct kpl_detector {
     DevState *h_state = nullptr;  // pinned copy of the device state (status read-back)
     int *h_count = nullptr;       // pinned
     hipStream_t stream = nullptr; // the host-buffer entry points enqueue here
+    // kpl_host_staging: pinned host buffers the caller fills, uploaded by DMA on a stream of their own
+    void *hs_xyz = nullptr, *hs_nrm = nullptr;
+    size_t hs_xyz_cap = 0, hs_nrm_cap = 0, hs_xs = 0, hs_ns = 0;
+    int hs_n = -1;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_xyz = nullptr, ev_nrm = nullptr;
     DevBuf out_kp_score;
     void *h_res = nullptr;        // pinned landing zone of the keypoint lists (host-buffer entry points)
     size_t h_res_cap = 0;
@@ -385,7 +391,7 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
 // once for the whole batch.  rebuild = always rebuild the index (compute), else only if stale.
 int run_batch(kpl_detector *const *handles, int count, float *const *d_scores, int *const *d_kp_idx,
               const int *kp_caps, int *const *d_kp_counts, StatsDev *d_stats, bool rebuild, hipStream_t st,
-              float *const *d_kp_scores = nullptr) {
+              float *const *d_kp_scores = nullptr, hipEvent_t normals_ready = nullptr) {
     kpl_detector *h0 = handles[0];
     Batch all{}, idx{}, fix{};
     bool rebuilt[kMaxBatch] = {};
@@ -409,7 +415,12 @@ int run_batch(kpl_detector *const *handles, int count, float *const *d_scores, i
     }
     all.nviews = count;
     const size_t ev0 = mark(h0, st);
-    if (idx.nviews) launch_index(idx, st);
+    if (idx.nviews) {
+        launch_index_points(idx, st);
+        // (staged host views: the normals arrive on the copy stream while the kernels above run)
+        if (normals_ready) KPL_HIP(h0, hipStreamWaitEvent(st, normals_ready, 0));
+        launch_index_records(idx, st);
+    }
     if (fix.nviews) launch_pos_of(fix, st);
     const size_t ev1 = mark(h0, st);
     launch_feature_stage(all, st);
@@ -493,7 +504,7 @@ int upload_view(kpl_detector *h, const void *xyz, size_t xs, const void *nrm, si
 // if asked for, its scores and / or the scores of all points) into the caller's buffers.  Two waits:
 // one for the count, one for the lists of exactly that length.
 int detect_staged(kpl_detector *h, int n, float *scores_out, int *kp_idx_out, float *kp_scores_out, int kp_cap,
-                  int *kp_count) {
+                  int *kp_count, hipEvent_t normals_ready = nullptr) {
     const size_t nn = (size_t)(n > 0 ? n : 1);
     const bool want_scores = scores_out != nullptr || kp_scores_out != nullptr;
     if (want_scores) KPL_HIP(h, h->out_scores.ensure(sizeof(float) * nn));
@@ -504,11 +515,37 @@ int detect_staged(kpl_detector *h, int n, float *scores_out, int *kp_idx_out, fl
     float *d_scores = want_scores ? h->out_scores.as<float>() : nullptr;
     int *d_kp = h->out_kp.as<int>(), *d_count = h->out_count.as<int>();
     float *d_kps = kp_scores_out ? h->out_kp_score.as<float>() : nullptr;
-    int rc = KPL_OK;
+    // The lists come back in ONE round trip: together with the count, the first `spec` entries of the index (and
+    // response) list are copied on speculation into the pinned landing buffer -- a 200 k-point view has ~22 k
+    // keypoints --; only a longer list costs a second copy and wait.
+    int spec = kp_cap < 32768 ? kp_cap : 32768;
+    if ((size_t)spec > nn) spec = (int)nn;                   // (the device lists hold n entries)
+    const size_t per = sizeof(int) + (kp_scores_out ? sizeof(float) : 0);
+    auto ensure_landing = [&](size_t entries) -> int {
+        const size_t need = entries * per;
+        if (need > h->h_res_cap) {
+            if (h->h_res) (void)hipHostFree(h->h_res);
+            h->h_res = nullptr;
+            h->h_res_cap = 0;
+            KPL_HIP(h, hipHostMalloc(&h->h_res, need + need / 2 + 4096, hipHostMallocDefault));
+            h->h_res_cap = need + need / 2 + 4096;
+        }
+        return KPL_OK;
+    };
+    int rc = ensure_landing((size_t)spec);
+    if (rc) return rc;
     for (int attempt = 0;; ++attempt) {
-        rc = run_batch(&h, 1, &d_scores, &d_kp, &n, &d_count, nullptr, true, st, &d_kps);
+        rc = run_batch(&h, 1, &d_scores, &d_kp, &n, &d_count, nullptr, true, st, &d_kps, attempt == 0 ? normals_ready : nullptr);
         if (rc) return rc;
         KPL_HIP(h, hipMemcpyAsync(h->h_count, h->out_count.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        if (spec > 0) {
+            KPL_HIP(h, hipMemcpyAsync(h->h_res, h->out_kp.p, sizeof(int) * (size_t)spec, hipMemcpyDeviceToHost, st));
+            if (kp_scores_out)
+                KPL_HIP(h, hipMemcpyAsync((char *)h->h_res + sizeof(int) * (size_t)spec, h->out_kp_score.p,
+                                          sizeof(float) * (size_t)spec, hipMemcpyDeviceToHost, st));
+        }
+        if (scores_out && n > 0)
+            KPL_HIP(h, hipMemcpyAsync(scores_out, h->out_scores.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, st));
         rc = sync_status(h, st);
         if (rc == KPL_ERR_RETRY && attempt == 0) continue;   // cell tables were grown: run again
         if (rc) return rc;
@@ -517,27 +554,19 @@ int detect_staged(kpl_detector *h, int n, float *scores_out, int *kp_idx_out, fl
     const int count = h->h_count[0];
     *kp_count = count;
     const int ncopy = count < kp_cap ? count : kp_cap;
-    // the lists land in one pinned buffer (true DMA, no staging by the runtime), then one memcpy each
-    const size_t need = (size_t)ncopy * (sizeof(int) + (kp_scores_out ? sizeof(float) : 0));
-    if (need > h->h_res_cap) {
-        if (h->h_res) (void)hipHostFree(h->h_res);
-        h->h_res = nullptr;
-        h->h_res_cap = 0;
-        KPL_HIP(h, hipHostMalloc(&h->h_res, need + need / 2 + 4096, hipHostMallocDefault));
-        h->h_res_cap = need + need / 2 + 4096;
-    }
-    if (ncopy > 0) {
+    if (ncopy > spec) {                                      // a list longer than the speculative copy: fetch all of it
+        rc = ensure_landing((size_t)ncopy);
+        if (rc) return rc;
         KPL_HIP(h, hipMemcpyAsync(h->h_res, h->out_kp.p, sizeof(int) * (size_t)ncopy, hipMemcpyDeviceToHost, st));
         if (kp_scores_out)
             KPL_HIP(h, hipMemcpyAsync((char *)h->h_res + sizeof(int) * (size_t)ncopy, h->out_kp_score.p,
                                       sizeof(float) * (size_t)ncopy, hipMemcpyDeviceToHost, st));
+        KPL_HIP(h, hipStreamSynchronize(st));
     }
-    if (scores_out && n > 0)
-        KPL_HIP(h, hipMemcpyAsync(scores_out, h->out_scores.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, st));
-    KPL_HIP(h, hipStreamSynchronize(st));
     if (ncopy > 0) {
+        const size_t stride = (size_t)(ncopy > spec ? ncopy : spec);
         memcpy(kp_idx_out, h->h_res, sizeof(int) * (size_t)ncopy);
-        if (kp_scores_out) memcpy(kp_scores_out, (char *)h->h_res + sizeof(int) * (size_t)ncopy, sizeof(float) * (size_t)ncopy);
+        if (kp_scores_out) memcpy(kp_scores_out, (char *)h->h_res + sizeof(int) * stride, sizeof(float) * (size_t)ncopy);
     }
     if (count > kp_cap) return fail(h, KPL_ERR_CAPACITY, "%d keypoints but capacity %d", count, kp_cap);
     return KPL_OK;
@@ -631,6 +660,11 @@ void kpl_destroy(kpl_detector *h) {
     if (h->h_state) (void)hipHostFree(h->h_state);
     if (h->h_count) (void)hipHostFree(h->h_count);
     if (h->h_res) (void)hipHostFree(h->h_res);
+    if (h->hs_xyz) (void)hipHostFree(h->hs_xyz);
+    if (h->hs_nrm) (void)hipHostFree(h->hs_nrm);
+    if (h->ev_xyz) (void)hipEventDestroy(h->ev_xyz);
+    if (h->ev_nrm) (void)hipEventDestroy(h->ev_nrm);
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     h->out_kp_score.release();
     delete h;
@@ -875,6 +909,75 @@ int kpl_detect_keypoints(kpl_detector *h, const void *xyz, size_t xyz_stride, co
     rc = upload_view(h, xyz, xyz_stride, normals, normals_stride, n);
     if (rc) return rc;
     return detect_staged(h, n, nullptr, kp_idx_out, kp_scores_out, kp_cap, kp_count);
+}
+
+int kpl_host_staging(kpl_detector *h, int n, size_t xyz_stride, size_t normals_stride, void **xyz, void **normals) {
+    if (!h || !xyz || !normals) return KPL_ERR_INVALID_ARG;
+    *xyz = *normals = nullptr;
+    if (n < 0) return fail(h, KPL_ERR_INVALID_ARG, "negative point count");
+    if (xyz_stride < 12 || normals_stride < 12 || (xyz_stride & 3) || (normals_stride & 3))
+        return fail(h, KPL_ERR_INVALID_ARG, "strides must be multiples of 4 and >= 12 bytes");
+    int rc = use_device(h);
+    if (rc) return rc;
+    const size_t nn = (size_t)(n > 0 ? n : 1), bx = nn * xyz_stride, bn = nn * normals_stride;
+    if (bx > h->hs_xyz_cap || bn > h->hs_nrm_cap) KPL_HIP(h, hipStreamSynchronize(h->copy_stream ? h->copy_stream : h->stream));
+    if (bx > h->hs_xyz_cap) {
+        if (h->hs_xyz) (void)hipHostFree(h->hs_xyz);
+        h->hs_xyz = nullptr;
+        h->hs_xyz_cap = 0;
+        KPL_HIP(h, hipHostMalloc(&h->hs_xyz, bx + bx / 4, hipHostMallocDefault));
+        h->hs_xyz_cap = bx + bx / 4;
+    }
+    if (bn > h->hs_nrm_cap) {
+        if (h->hs_nrm) (void)hipHostFree(h->hs_nrm);
+        h->hs_nrm = nullptr;
+        h->hs_nrm_cap = 0;
+        KPL_HIP(h, hipHostMalloc(&h->hs_nrm, bn + bn / 4, hipHostMallocDefault));
+        h->hs_nrm_cap = bn + bn / 4;
+    }
+    if (!h->copy_stream) {
+        KPL_HIP(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        KPL_HIP(h, hipEventCreateWithFlags(&h->ev_xyz, hipEventDisableTiming));
+        KPL_HIP(h, hipEventCreateWithFlags(&h->ev_nrm, hipEventDisableTiming));
+    }
+    h->hs_xs = xyz_stride;
+    h->hs_ns = normals_stride;
+    h->hs_n = n;
+    *xyz = h->hs_xyz;
+    *normals = h->hs_nrm;
+    return KPL_OK;
+}
+
+int kpl_detect_keypoints_staged(kpl_detector *h, int *kp_idx_out, float *kp_scores_out, int kp_cap, int *kp_count) {
+    if (!h) return KPL_ERR_INVALID_ARG;
+    if (!kp_count || kp_cap < 0 || (kp_cap > 0 && !kp_idx_out)) return fail(h, KPL_ERR_INVALID_ARG, "bad keypoint output buffers");
+    *kp_count = 0;
+    if (h->hs_n < 0) return fail(h, KPL_ERR_NO_CLOUD, "kpl_host_staging has not been called");
+    int rc = check_params_for_compute(h, true);
+    if (rc) return rc;
+    rc = use_device(h);
+    if (rc) return rc;
+    const int n = h->hs_n;
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    KPL_HIP(h, h->stage_xyz.ensure(nn * h->hs_xs));
+    KPL_HIP(h, h->stage_nrm.ensure(nn * h->hs_ns));
+    if (n > 0) {
+        // pinned memory: true DMA, asynchronous.  Points first, then the normals, both on the copy stream; the
+        // compute stream starts on the points as soon as they have landed and meets the normals at the scatter
+        KPL_HIP(h, hipMemcpyAsync(h->stage_xyz.p, h->hs_xyz, (size_t)(n - 1) * h->hs_xs + 12, hipMemcpyHostToDevice, h->copy_stream));
+        KPL_HIP(h, hipEventRecord(h->ev_xyz, h->copy_stream));
+        KPL_HIP(h, hipMemcpyAsync(h->stage_nrm.p, h->hs_nrm, (size_t)(n - 1) * h->hs_ns + 12, hipMemcpyHostToDevice, h->copy_stream));
+        KPL_HIP(h, hipEventRecord(h->ev_nrm, h->copy_stream));
+        KPL_HIP(h, hipStreamWaitEvent(h->stream, h->ev_xyz, 0));
+    }
+    h->d_xyz = h->stage_xyz.as<char>();
+    h->d_nrm = h->stage_nrm.as<char>();
+    h->xs = h->hs_xs;
+    h->ns = h->hs_ns;
+    h->n = n;
+    h->bound = true;
+    h->index_valid = false;
+    return detect_staged(h, n, nullptr, kp_idx_out, kp_scores_out, kp_cap, kp_count, n > 0 ? h->ev_nrm : nullptr);
 }
 
 int kpl_sync_status(kpl_detector *h, void *stream) {

@@ -133,6 +133,10 @@ void init_dev_state(DevState *host_copy);
 // ---- the three stages of compute(), each over every view of the batch ------------------------
 // index build ("initCompute"): needs the input + index fields of ViewDev
 void launch_index(const Batch &b, hipStream_t st);
+// the same in two halves: the kernels that read only the points, then those that also read the normals (a caller
+// that uploads the normals on another stream waits for them between the two)
+void launch_index_points(const Batch &b, hipStream_t st);
+void launch_index_records(const Batch &b, hipStream_t st);
 // pos_of[] of views indexed without it (want_pos_of must be set)
 void launch_pos_of(const Batch &b, hipStream_t st);
 // scoring ("runForest") in two kernels: features of every point -> feat (F x 64 blocks), then the

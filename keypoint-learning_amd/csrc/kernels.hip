@@ -1118,14 +1118,13 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts, co
 //   search   as in point_features: accept words of 32 candidates -> the point's small word list in LDS
 //   collect  every accepted neighbor's key (d2 bits << 32 | original index: d2 >= +0, so the unsigned order of
 //            the keys IS ascending (d2, index)) -> the point's key list in LDS, lcap keys per point
-//   sort     bitonic network over the key lists, all comparators ascending (the first step of a merge pairs
-//            i with its mirror image), so that the virtual padding of a list to the power of two above the
-//            longest list of the wave never moves: comparators that touch it are skipped
+//   sort     bitonic network over the key lists IN REGISTERS (sort_key_lists): lane g of the group holds a
+//            quarter of the list, comparators across lanes go through DPP
 //   add      the keys in order, 4 per round: normal of the neighbor from the caller's array (by original
 //            index), contribution from the d2 in the key, the 4 histogram updates lane after lane (hpp:350-355)
 // A neighborhood with more than lcap points takes several passes, each over a window [lo, hi) of keys: when a
-// list is full it is sorted, its smaller half kept and hi lowered to the first key dropped; the pass then ends
-// with exactly the keys of [lo, hi), they are added, and the next pass starts at lo = last key + 1.
+// list is about to run full, hi is lowered to a pivot inside the window (its middle in d2) and the list filtered;
+// the pass then ends with exactly the keys of [lo, hi), they are sorted and added, and the next pass starts at hi.
 // ---------------------------------------------------------------------------------------------
 constexpr int kSortGroup = 4;
 constexpr int kSortWords = 8;        // accept words per point between two collect rounds
@@ -1222,36 +1221,115 @@ struct RowSearch {
     }
 };
 
-// ascending sort of every point's key list (keys[e * kPts + point], cnt keys) by the G lanes of its group;
-// nmax = a power of two >= the longest list of the wave
-template <int G>
-__device__ __forceinline__ void sort_key_lists(unsigned long long *keys, int pi, int gq, int cnt, int nmax) {
-    constexpr int kPts = kLanes / G;
-    auto exchange = [&](int i, int l) {          // i < l; a comparator that touches the padding (l >= cnt) is a no-op
-        if (l < cnt) {
-            const unsigned long long a = keys[i * kPts + pi], c = keys[l * kPts + pi];
-            if (c < a) {
-                keys[i * kPts + pi] = c;
-                keys[l * kPts + pi] = a;
-            }
-        }
-    };
+// Ascending sort of every point's key list (keys[e * kPts + point], cnt <= G * E keys) by the G lanes of its group, in
+// REGISTERS: lane g holds the elements g E .. g E + E - 1 (the list is padded with +infinity to N = G E), and the whole
+// bitonic network runs on them -- all comparators ascending (the first step of a merge pairs an element with its mirror
+// image in the block), comparators inside a lane are a 64-bit compare and four selects on fixed registers, comparators
+// across lanes fetch the partner's element with two DPP moves (quad_perm: the lanes of a group are a quad).  No LDS
+// traffic, no index arithmetic: ~2.5 k instructions per wave at E = 32 against ~6-16 k for the same network walked
+// over the lists in LDS (profiles/r03_notes.md).
+template <int MASK>
+__device__ __forceinline__ unsigned long long quad_fetch(unsigned long long x) {
+    static_assert(MASK >= 1 && MASK <= 3, "partner inside the quad");
+    constexpr int ctrl = MASK == 1 ? 0xB1 : MASK == 2 ? 0x4E : 0x1B;      // quad_perm [1,0,3,2] / [2,3,0,1] / [3,2,1,0]
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)x, ctrl, 0xf, 0xf, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(x >> 32), ctrl, 0xf, 0xf, true);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+template <int G, int E>
+__device__ __forceinline__ void sort_key_lists(unsigned long long *keys, int pi, int gq, int cnt) {
+    static_assert(G == 4, "the lanes of a group are a DPP quad");
+    constexpr int kPts = kLanes / G, N = G * E;
+    unsigned long long r[E];
     wave_lds_fence();
-    for (int k = 2; k <= nmax; k <<= 1) {
-        const int half = k >> 1;
-        for (int pr = gq; pr < nmax / 2; pr += G) {              // merge step 1: i against its mirror image in the block of k
-            const int blk = pr / half * k, off = pr & (half - 1);
-            exchange(blk + off, blk + k - 1 - off);
-        }
-        wave_lds_fence();
-        for (int j = half >> 1; j > 0; j >>= 1) {
-            for (int pr = gq; pr < nmax / 2; pr += G) {
-                const int i = ((pr & ~(j - 1)) << 1) | (pr & (j - 1));
-                exchange(i, i + j);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int idx = gq * E + e;
+        r[e] = idx < cnt ? keys[idx * kPts + pi] : ~0ull;
+    }
+    // (the empty asm statements pin every comparator's results in place, in program order: left alone the scheduler
+    // overlaps dozens of comparators and needs 250-300 registers for a network that lives in 64)
+    auto inside = [](unsigned long long &a, unsigned long long &b) {          // a <- min, b <- max
+        const bool sw = b < a;
+        const unsigned long long lo = sw ? b : a, hi = sw ? a : b;
+        a = lo;
+        b = hi;
+        asm volatile("" : "+v"(a), "+v"(b));
+    };
+    auto across = [](unsigned long long mine, unsigned long long other, bool upper) {   // the lower lane keeps the minimum
+        const bool lt = other < mine;
+        unsigned long long res = (lt != upper) ? other : mine;
+        asm volatile("" : "+v"(res));
+        return res;
+    };
+#pragma unroll
+    for (int k = 2; k <= N; k <<= 1) {
+        if (k <= E) {                                   // merge step 1 inside the lane: i against its mirror image
+#pragma unroll
+            for (int blk = 0; blk < E; blk += k)
+#pragma unroll
+                for (int off = 0; off < k / 2; ++off) inside(r[blk + off], r[blk + k - 1 - off]);
+        } else {                                        // ... across lanes: partner lane g ^ (k / E - 1), its element E - 1 - e
+            const bool upper = (gq & (k / E / 2)) != 0;
+#pragma unroll
+            for (int e = 0; e < E / 2; ++e) {
+                unsigned long long o1, o2;
+                if (k / E - 1 == 1) {
+                    o1 = quad_fetch<1>(r[E - 1 - e]);
+                    o2 = quad_fetch<1>(r[e]);
+                } else {
+                    o1 = quad_fetch<3>(r[E - 1 - e]);
+                    o2 = quad_fetch<3>(r[e]);
+                }
+                r[e] = across(r[e], o1, upper);
+                r[E - 1 - e] = across(r[E - 1 - e], o2, upper);
             }
-            wave_lds_fence();
+        }
+#pragma unroll
+        for (int j = k / 4; j > 0; j >>= 1) {
+            if (j < E) {
+#pragma unroll
+                for (int a = 0; a < E; ++a)
+                    if ((a & j) == 0) inside(r[a], r[a + j]);
+            } else {                                    // partner lane g ^ (j / E), the same element
+                const bool upper = (gq & (j / E)) != 0;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const unsigned long long o = j / E == 1 ? quad_fetch<1>(r[e]) : quad_fetch<2>(r[e]);
+                    r[e] = across(r[e], o, upper);
+                }
+            }
         }
     }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int idx = gq * E + e;
+        if (idx < cnt) keys[idx * kPts + pi] = r[e];
+    }
+    wave_lds_fence();
+}
+
+constexpr int kSortedListKeys = 32 * kSortGroup;      // keys per point and pass: what the register sort holds
+
+// keeps the keys below `hi` of every point's list, in place and in order; returns the new length.  lcap = list capacity
+template <int G>
+__device__ __forceinline__ int keep_keys_below(unsigned long long *keys, int pi, int gq, unsigned group_shift, int cnt, int lcap,
+                                               unsigned long long hi) {
+    constexpr int kPts = kLanes / G;
+    int out = 0;
+    wave_lds_fence();
+    for (int base = 0; base < lcap; base += G) {
+        const int idx = base + gq;
+        const unsigned long long key = keys[min(idx, lcap - 1) * kPts + pi];
+        const bool keep = (idx < cnt) & (key < hi);
+        const unsigned gb = (unsigned)(__ballot(keep) >> group_shift) & ((1u << G) - 1u);
+        wave_lds_fence();                                   // every lane has read its key: the writes land at or before them
+        if (keep) keys[(out + __popc(gb & ((1u << gq) - 1u))) * kPts + pi] = key;
+        out += __popc(gb);
+        wave_lds_fence();
+    }
+    return out;
 }
 
 template <int G>
@@ -1282,11 +1360,15 @@ __device__ __forceinline__ int point_features_sorted(const float4 *__restrict__ 
     const int ent_last = (ecap - 1) * kPts + pi;
     const int col_address = lds_address(H + pi);
     const unsigned group_shift = (unsigned)(tid & ~(G - 1));
-    unsigned long long lo = 0ull, hi = ~0ull;      // this pass collects the keys of [lo, hi)
+    const unsigned long long key_end = (unsigned long long)__float_as_uint(f.r2) << 32;     // every key is below it (d2 < r2)
+    // A pass collects the keys of the window [lo, hi) of the point, sorts and adds them.  hi starts open (key_end); when
+    // a list is about to run full, hi is lowered to a pivot inside the window and the list is filtered -- the pass then
+    // still ends with ALL keys of [lo, hi), and the next pass takes [hi, key_end).
+    unsigned long long lo = 0ull, hi = key_end;
+    bool dropped = false;                          // hpp:336: element 0 of the whole order has been dropped
     int kf = 0;
     for (int pass = 0;; ++pass) {
         int cnt = 0;                               // keys in the point's list (the same in the lanes of the group)
-        bool trunc = false;                        // the list was cut: keys >= hi are left for the next pass
         rs.restart();
         for (;;) {
             // ---- search: accept words of the point
@@ -1321,35 +1403,32 @@ __device__ __forceinline__ int point_features_sorted(const float4 *__restrict__ 
                     e += refill ? 1 : 0;
                     nw = ent[min(e * kPts + pi, ent_last)];
                     const unsigned c1 = drop_lowest_bit(w), c2 = drop_lowest_bit(c1), c3 = drop_lowest_bit(c2);
-                    unsigned m;
-                    if (G == 2) {
-                        m = gq == 0 ? w : c1;
-                        w = c2;
-                    } else {
-                        m = gq == 0 ? w : gq == 1 ? c1 : gq == 2 ? c2 : c3;
-                        w = drop_lowest_bit(c3);
-                    }
+                    const unsigned m = gq == 0 ? w : gq == 1 ? c1 : gq == 2 ? c2 : c3;
+                    w = drop_lowest_bit(c3);
                     slot.valid = m != 0u;
                     const int tt = slot.valid ? wbase + lowest_bit_index(m) : 0;
                     slot.q = pts[tt];
                 };
                 auto collect = [&](Taken &now) {
+                    // room for the G keys of this round in every list, else: a pivot inside the window, the list filtered
+                    while (__any(cnt > lcap - G)) {
+                        if (cnt > lcap - G) {
+                            const unsigned lb = (unsigned)(lo >> 32), hb = (unsigned)(hi >> 32);
+                            if (hb - lb >= 2u) {           // halve the window in d2 (its values, not its bits: even counts on a surface)
+                                const float ld = __uint_as_float(lb), hd = __uint_as_float(hb);
+                                unsigned mb = __float_as_uint(ld + (hd - ld) * 0.5f);
+                                if (mb <= lb || mb >= hb) mb = lb + (hb - lb) / 2u;
+                                hi = (unsigned long long)mb << 32;
+                            } else {                       // one or two distances left: halve by the whole key (distance, index)
+                                hi = lo + (hi - lo) / 2ull;
+                            }
+                        }
+                        cnt = keep_keys_below<G>(keys, pi, gq, group_shift, cnt, lcap, hi);
+                    }
                     const unsigned long long key = ((unsigned long long)__float_as_uint(dist2(p.x, p.y, p.z, now.q)) << 32) |
                                                    (unsigned long long)(unsigned)__float_as_int(now.q.w);
-                    bool app = now.valid & (key >= lo) & (key < hi);
-                    unsigned gb = (unsigned)(__ballot(app) >> group_shift) & ((1u << G) - 1u);
-                    while (__any(cnt + __popc(gb) > lcap)) {
-                        // a list is full: sort, keep the smaller half, lower hi to the first key that is dropped
-                        sort_key_lists<G>(keys, pi, gq, cnt, lcap);
-                        if (cnt + __popc(gb) > lcap) {
-                            cnt = lcap / 2;
-                            hi = keys[cnt * kPts + pi];
-                            trunc = true;
-                        }
-                        app = app & (key < hi);
-                        gb = (unsigned)(__ballot(app) >> group_shift) & ((1u << G) - 1u);
-                        wave_lds_fence();
-                    }
+                    const bool app = now.valid & (key >= lo) & (key < hi);
+                    const unsigned gb = (unsigned)(__ballot(app) >> group_shift) & ((1u << G) - 1u);
                     if (app) keys[(cnt + __popc(gb & ((1u << gq) - 1u))) * kPts + pi] = key;
                     cnt += __popc(gb);
                     now.valid = false;
@@ -1366,10 +1445,8 @@ __device__ __forceinline__ int point_features_sorted(const float4 *__restrict__ 
             }
             if (rs.exhausted()) break;
         }
-        // ---- sort the lists; nmax = power of two >= the longest list of the wave
-        int nmax = 2;
-        while (__any(nmax < cnt)) nmax <<= 1;
-        sort_key_lists<G>(keys, pi, gq, cnt, nmax);
+        // ---- sort the lists (the one place where the network is instantiated)
+        sort_key_lists<G, kSortedListKeys / G>(keys, pi, gq, cnt);
         // ---- add the neighbors in order, G per round; hpp:336: element 0 of the whole order is dropped
         {
             struct Next {
@@ -1377,7 +1454,8 @@ __device__ __forceinline__ int point_features_sorted(const float4 *__restrict__ 
                 float d2;
                 f32x3 n;
             };
-            int k = pass == 0 ? 1 : 0;
+            int k = (!dropped & (cnt > 0)) ? 1 : 0;
+            dropped |= cnt > 0;
             const int key_last = (lcap - 1) * kPts + pi;
             auto take = [&](Next &slot) {
                 const int idx = k + gq;
@@ -1410,10 +1488,10 @@ __device__ __forceinline__ int point_features_sorted(const float4 *__restrict__ 
             } while (__any((k - G < cnt) | pa.valid | pb.valid));
 #undef KPL_SORTED_ROUND
         }
-        if (!__any(trunc)) break;
-        // the next pass: the keys above the last one added; a point that is done collects nothing any more
-        lo = trunc ? keys[(cnt - 1) * kPts + pi] + 1ull : ~0ull;
-        hi = ~0ull;
+        if (!__any(hi != key_end)) break;
+        // the next pass: the keys from the pivot on; a point whose window was never cut is done (an empty window)
+        lo = hi != key_end ? hi : key_end;
+        hi = key_end;
         wave_lds_fence();
     }
     wave_lds_fence();
@@ -2565,6 +2643,12 @@ static void run_scan(const ScanJobs &jobs, int nviews, hipStream_t st) {
 size_t btable_ints(int n) { return (size_t)kBins * (size_t)sort_chunks(n > 0 ? n : 1) + 2 * kBins; }
 
 void launch_index(const Batch &b, hipStream_t st) {
+    launch_index_points(b, st);
+    launch_index_records(b, st);
+}
+
+// first half: the kernels that read the POINTS only (bounding box, grid, bucket counts and offsets)
+void launch_index_points(const Batch &b, hipStream_t st) {
     const int nv = b.nviews, n = max_n(b);
     if (nv <= 0) return;
     if (n > 0) {
@@ -2576,6 +2660,12 @@ void launch_index(const Batch &b, hipStream_t st) {
     if (n > 0) bucket_hist_kernel<<<dim3(sort_chunks(n), nv), kWave, 0, st>>>(b);
     bucket_total_kernel<<<dim3(div_up(kBins, 256 / kWave), nv), 256, 0, st>>>(b);
     bucket_offsets_kernel<<<dim3(div_up(kBins, 256 / kWave), nv), 256, 0, st>>>(b);
+}
+
+// second half: from the scatter on the NORMALS are read too (the 32-byte record travels with the key)
+void launch_index_records(const Batch &b, hipStream_t st) {
+    const int nv = b.nviews, n = max_n(b);
+    if (nv <= 0) return;
     if (n > 0) bucket_scatter_kernel<<<dim3(sort_chunks(n), nv), kWave, 0, st>>>(b);
     // cells of a bucket held in LDS at a time: what the largest cell table of the batch can need, at most
     // 1024 (two cells per thread in the workgroup's scan; kSortWaves counters per cell)
@@ -2630,13 +2720,9 @@ static int accept_words(int F) {
     return e;
 }
 
-// Keys per point of the sorted-search mode (a power of two; longer neighborhoods take several passes): 128 keys
-// = 16 KB per wave of 16 points, 7-8 waves per CU next to the histograms; 64 for the largest histograms
-static int sorted_list_keys(int F) {
-    int l = 128;
-    while (l > 32 && sorted_lds_bytes<kSortGroup>(F, kSortWords, l) * 6 > (size_t)kLdsPerCu) l >>= 1;
-    return l;
-}
+// Keys per point and pass of the sorted-search mode = what the register sort holds (128: 16 KB per wave of 16
+// points; longer neighborhoods take several passes)
+static int sorted_list_keys(int) { return kSortedListKeys; }
 
 // Geometry of the forest kernel: one workgroup per CU; LDS = the top of the forest (at most
 // kForestNodeBytes) + one F x 64 float slice per wave, as many waves as then fit (2..16).

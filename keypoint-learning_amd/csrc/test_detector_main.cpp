@@ -60,11 +60,13 @@ const char *kUsage =
     "  --printResolution             print the cloud resolution (mean 2nd-NN distance) and exit.\n"
     "  --detectorNormals             do not pass normals: the detector estimates them itself (radius search\n"
     "                                with radiusFeatures, as the reference's initCompute does).\n"
+    "  --hostStaging                 setHostStaging(true): the setters copy cloud and normals into pinned buffers of the\n"
+    "                                engine, compute() uploads them by DMA.\n"
     "  --sortedSearch                hand the detector a sorted search tree (setSearchMethod(pcl::search::KdTree(true))):\n"
     "                                neighbors in ascending (distance, index) order instead of the engine's canonical order.\n";
 
 bool parse(int argc, char **argv, Options &o) {
-    static const char *flags[] = {"help", "flipNormals", "subSampling", "radiusInMr", "json", "printResolution", "detectorNormals", "checkProtected", "sortedSearch"};
+    static const char *flags[] = {"help", "flipNormals", "subSampling", "radiusInMr", "json", "printResolution", "detectorNormals", "checkProtected", "sortedSearch", "hostStaging"};
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         if (a == "-h") a = "--help";
@@ -269,8 +271,11 @@ int main(int argc, char **argv) {
     detector->setRadiusSearch(radius_features);
     if (vm.has("sortedSearch"))          // the inherited pcl::Keypoint::setSearchMethod; KdTree's constructor default is sorted = true
         detector->setSearchMethod(pcl::search::KdTree<PointInT>::Ptr(new pcl::search::KdTree<PointInT>(true)));
+    if (vm.has("hostStaging")) detector->setHostStaging(true);
+    auto t_set = std::chrono::steady_clock::now();
     detector->setInputCloud(cloud);
     if (!own_normals) detector->setNormals(normals);          // else: impl/KeypointLearning.hpp:125-148
+    const double set_s = seconds_since(t_set);
 
     // detect keypoints (:186-187)
     pcl::PointCloud<KeypointT>::Ptr keypoint(new pcl::PointCloud<KeypointT>());
@@ -279,15 +284,20 @@ int main(int argc, char **argv) {
     const double first_s = seconds_since(t0);
     t0 = std::chrono::steady_clock::now();
     detector->compute(*keypoint);                  // second call: scratch buffers already sized
-    const double warm_s = seconds_since(t0);
+    double warm_s = seconds_since(t0);
+    for (int rep = 0; rep < 5; ++rep) {            // steady state: the best of a few more
+        t0 = std::chrono::steady_clock::now();
+        detector->compute(*keypoint);
+        warm_s = std::min(warm_s, seconds_since(t0));
+    }
     if (!json) printf("Keypoint computed\n");
 
     if (vm.has("pathKP")) save_pcd_ascii(vm.str("pathKP", ""), *keypoint);
     if (json)
         printf("{\"points\": %zu, \"keypoints\": %zu, \"mr\": %.9g, \"radiusFeatures\": %.9g, \"radiusNMS\": %.9g, "
-               "\"threshold\": %.9g, \"annuli\": %d, \"bins\": %d, \"prepare_s\": %.6f, \"compute_first_s\": %.6f, "
+               "\"threshold\": %.9g, \"annuli\": %d, \"bins\": %d, \"prepare_s\": %.6f, \"set_s\": %.6f, \"compute_first_s\": %.6f, "
                "\"compute_s\": %.6f}\n",
-               cloud->size(), keypoint->size(), mr, radius_features, radius_nms, threshold, annuli, bins, prep_s, first_s, warm_s);
+               cloud->size(), keypoint->size(), mr, radius_features, radius_nms, threshold, annuli, bins, prep_s, set_s, first_s, warm_s);
     else
         printf("%zu keypoints out of %zu points (compute: %.3f ms)\nDONE\n", keypoint->size(), cloud->size(), warm_s * 1e3);
     return 0;

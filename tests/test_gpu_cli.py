@@ -389,3 +389,20 @@ def test_detect_views_all_devices_equals_test_detector(tmp_path):
             info = json.loads(one.stdout.strip().splitlines()[-1])
             assert rows[k]["keypoints"] == info["keypoints"] > 0 and rows[k]["points"] == info["points"]
             assert open(out).read() == open(str(tmp_path / "multi") + "%d.pcd" % k).read(), (k, extra)
+
+
+def test_cli_host_staging_gives_the_same_file(tmp_path):
+    """--hostStaging: setHostStaging(true) before the setters; compute() goes through the pinned staging path."""
+    z = np.load(os.path.join(GOLD, "cheff000.npz"))
+    pcd = tmp_path / "view.pcd"
+    write_pcd(pcd, z["xyz"], z["nrm"], True)
+    outs = []
+    for extra in ([], ["--hostStaging"]):
+        out = tmp_path / ("kp%d.pcd" % len(outs))
+        cmd = [EXE, "--pathCloud", str(pcd), "--pathRF", os.path.join(ROOT, "data", "forests", "synth200k_a5b6_t10.yaml.gz"),
+               "--pathKP=%s" % out, "--radiusFeatures", "%.9g" % float(z["r_feat"]), "--radiusNMS", "%.9g" % float(z["r_nms"]),
+               "-t", "0.85", "--annuli", "5", "--bins", "6", "--json"] + extra
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, res.stderr
+        outs.append(open(out).read())
+    assert outs[0] == outs[1] and outs[0].count("\n") > 100

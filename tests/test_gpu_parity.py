@@ -413,3 +413,35 @@ def test_every_forest_walker(kpl, oracle, cases, A, B, ntrees, nodes_per_tree, m
     assert cases.same_bits(scores, o_scores), walker
     assert np.array_equal(det.getKeypointsIndices(), o_kp), walker
     assert len(np.unique(o_scores[np.isfinite(o_scores)])) >= 3       # the walks do reach different leaves
+
+
+def test_pinned_host_staging_path(kpl, oracle, cases):
+    """kpl_host_staging + kpl_detect_keypoints_staged: the view in pinned buffers of the handle (packed 12-byte
+    records and PCL's 16 / 32-byte records), uploaded by DMA with the normals overlapped -- same keypoints and
+    responses as the oracle; repeated calls, a larger and a smaller view on the same handle, the empty view."""
+    A, B = 5, 6
+    fa = cases.trained_forest(A, B)
+    of = cases.oracle_forest(fa)
+    det = None
+    for (nx, ny, seed, xs, ns) in ((80, 60, 1, 12, 12), (120, 90, 3, 16, 32), (40, 30, 5, 12, 32), (80, 60, 1, 16, 12)):
+        xyz, nrm = cases.cloud(nx, ny, seed=seed, nan_points=7, nan_normals=5)
+        mr = oracle.cloud_resolution(xyz)
+        r, rn, thr = float(np.float32(6 * mr)), float(np.float32(4 * mr)), float(np.float32(0.5))
+        if det is None:
+            det = make_det(kpl, A, B, r, rn, thr, fa)
+        det.setRadiusSearch(r)
+        det.setNonMaxRadius(rn)
+        sx, sn = det.hostStaging(len(xyz), xs, ns)
+        assert sx.shape == (len(xyz), xs // 4) and sn.shape == (len(xyz), ns // 4)
+        sx[:] = 777.0
+        sn[:] = -3.0                                     # padding floats must not matter
+        sx[:, :3] = xyz
+        sn[:, :3] = nrm
+        o_sc, o_kp = oracle.detect(xyz, nrm, A, B, r, rn, thr, of)
+        for rep in range(2):
+            kp, kps = det.computeStaged()
+            assert np.array_equal(kp, o_kp) and len(o_kp) > 0
+            assert cases.same_bits(kps, o_sc[o_kp])
+    det.hostStaging(0)
+    kp, kps = det.computeStaged()
+    assert len(kp) == 0
