@@ -1737,8 +1737,11 @@ __device__ __forceinline__ int forest_sum_any_order(const ForestDev &forest, con
     const uint32_t line0 = ((uint32_t)forest.ntop + 15u) & ~15u;   // DEEP: slot of the first pair of blocks
     const uint32_t last_var = (uint32_t)nvars - 1u;
     const int ntrees = active ? forest.ntrees : 0;
-    int sum = 0;
-    int next_tree = first + tstride * kQueueWays;      // per lane: its first kQueueWays trees are taken
+    // the leaf values are small integers (order_free): their float sum is exact in any order (|sum| < 2^24) and needs no
+    // conversion per leaf; the resting leaf is slot `ntrees`, so "the lane's next tree, or rest" is min(next_tree, ntrees)
+    float sum = 0.0f;
+    // per lane: its first kQueueWays trees are taken; a lane without a point never takes one (its queue is "past the end")
+    int next_tree = active ? first + tstride * kQueueWays : 0x3fffffff;
     uint32_t nd[kQueueWays];
 #pragma unroll
     for (int k = 0; k < kQueueWays; ++k)               // level-major layout: the root of tree t is node t
@@ -1760,15 +1763,15 @@ __device__ __forceinline__ int forest_sum_any_order(const ForestDev &forest, con
             const uint32_t stride = (DEEP && ((child - line0) & 0x8000000fu) == 0u) ? 8u : 1u;
             const uint32_t next = child + (val[k] <= __uint_as_float(node[k].x) ? 0u : stride);
             if (STATS) depth += nd[k] != rest ? 1 : 0;
-            sum += leaf ? (int)__uint_as_float(node[k].x) : 0;
+            sum += leaf ? __uint_as_float(node[k].x) : 0.0f;
             // a walk that has reached its leaf takes the lane's next tree (its root is node next_tree) or rests
-            nd[k] = leaf ? (next_tree < ntrees ? (uint32_t)next_tree : rest) : next;
+            nd[k] = leaf ? min((uint32_t)next_tree, rest) : next;
             next_tree += leaf ? tstride : 0;           // (runs on past ntrees while the lane rests: a few steps)
             walking |= nd[k] != rest;
         }
         if (!__any(walking)) break;
     }
-    return sum;
+    return (int)sum;
 }
 
 // The scoring stage ("runForest", hpp:267-296) in two kernels over chunks of 64 consecutive storage
