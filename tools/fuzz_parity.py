@@ -1,5 +1,6 @@
 """Randomised parity soak: random small clouds, radii, histogram shapes, forests, thresholds and NMS modes through
-libkpl and through the oracle; every score must match bit for bit and every keypoint list exactly.  Every 25th case also
+libkpl and through the oracle, in the canonical and (40 % of the cases) the sorted neighbor order; every score must match
+bit for bit and every keypoint list exactly.  Every 25th case also
 runs a random organized depth image (steps, holes, non-finite x) through the integral-image normal estimation.
     python tools/fuzz_parity.py [seconds] [seed]
 """
@@ -43,13 +44,14 @@ def batch_case(kpl, rng):
         r, rn = float(np.float32(mr * rng.uniform(2, 7))), float(np.float32(mr * rng.uniform(0.5, 5)))
         thr = float(np.float32(rng.choice([0.0, 0.5, 0.85])))
         nms, draws = bool(rng.random() < 0.8), bool(rng.random() < 0.4)
+        srt = bool(rng.random() < 0.4)
         dthr = float(np.float32(mr * rng.uniform(0, 3)))
         fa = synth.random_forest(A * B, ntrees=int(rng.integers(1, 12)), max_depth=int(rng.integers(1, 10)),
                                  seed=int(rng.integers(1, 1 << 30)), target_nodes_per_tree=int(rng.integers(3, 200)))
         det = kpl.KeypointLearningDetector()
         det.setNAnnulus(A); det.setNBins(B); det.setNonMaxima(nms); det.setNonMaxRadius(rn)
         det.setNonMaximaDrawsRemove(draws); det.setNonMaximaDrawsThreshold(dthr)
-        det.setPredictionThreshold(thr); det.setRadiusSearch(r)
+        det.setPredictionThreshold(thr); det.setRadiusSearch(r); det.setSortedSearch(srt)
         helpers.load_arrays(det, fa)
         dx = torch.from_numpy(xyz).to(dev) if n else torch.zeros(1, 3, device=dev)
         dn = torch.from_numpy(nrm).to(dev) if n else torch.zeros(1, 3, device=dev)
@@ -58,7 +60,7 @@ def batch_case(kpl, rng):
         det.bindCloudDevice(dx.data_ptr(), 12, dn.data_ptr(), 12, n)
         dets.append(det); bufs.append((dx, dn, ds, dk, n))
         expect.append(kplo.detect(xyz, nrm, A, B, r, rn, thr, helpers.oracle_forest(fa), non_maxima=nms,
-                                  draws_remove=draws, draws_threshold=dthr))
+                                  draws_remove=draws, draws_threshold=dthr, order=kplo.ORDER_SORTED if srt else kplo.ORDER_CANONICAL))
     args = (dets, [b[2].data_ptr() for b in bufs], [b[3][1:].data_ptr() if b[4] else None for b in bufs],
             [b[4] for b in bufs], [b[3][0:1].data_ptr() for b in bufs])
     for attempt in range(2):
@@ -145,6 +147,7 @@ def main():
         rn = float(np.float32(mr * rng.uniform(0.0, 6.0)))
         thr = float(np.float32(rng.choice([0.0, 0.3, 0.5, 0.85, 1.0])))
         nms, draws = bool(rng.random() < 0.85), bool(rng.random() < 0.4)
+        srt = bool(rng.random() < 0.4)                 # neighbors in sorted (distance, index) order
         dthr = float(np.float32(mr * rng.uniform(0, 4)))
         fa = synth.random_forest(A * B, ntrees=int(rng.integers(1, 14)), max_depth=int(rng.integers(1, 12)),
                                  seed=int(rng.integers(1, 1 << 30)), target_nodes_per_tree=int(rng.integers(3, 400)))
@@ -152,7 +155,7 @@ def main():
             fa.value[:] = np.round(fa.value * 2) / 2
         det.setNAnnulus(A); det.setNBins(B); det.setNonMaxima(nms); det.setNonMaxRadius(rn)
         det.setNonMaximaDrawsRemove(draws); det.setNonMaximaDrawsThreshold(dthr)
-        det.setPredictionThreshold(thr); det.setRadiusSearch(r)
+        det.setPredictionThreshold(thr); det.setRadiusSearch(r); det.setSortedSearch(srt)
         helpers.load_arrays(det, fa)
         det.setInputCloud(np.ascontiguousarray(xyz).reshape(-1, 3)); det.setNormals(np.ascontiguousarray(nrm).reshape(-1, 3))
         try:
@@ -162,13 +165,13 @@ def main():
                 continue
             raise
         o_sc, o_kp = kplo.detect(xyz, nrm, A, B, r, rn, thr, helpers.oracle_forest(fa), non_maxima=nms,
-                                 draws_remove=draws, draws_threshold=dthr)
+                                 draws_remove=draws, draws_threshold=dthr, order=kplo.ORDER_SORTED if srt else kplo.ORDER_CANONICAL)
         ok = helpers.same_bits(sc, o_sc) and np.array_equal(det.getKeypointsIndices(), o_kp)
         if not ok:
-            np.savez("fuzz_failure.npz", xyz=xyz, nrm=nrm, A=A, B=B, r=r, rn=rn, thr=thr, nms=nms, draws=draws, dthr=dthr,
+            np.savez("fuzz_failure.npz", xyz=xyz, nrm=nrm, A=A, B=B, r=r, rn=rn, thr=thr, nms=nms, draws=draws, dthr=dthr, srt=srt,
                      root=fa.root, var=fa.var, thrs=fa.thr, left=fa.left, right=fa.right, value=fa.value)
-            print("MISMATCH case %d kind %d n %d A %d B %d r %g rn %g thr %g nms %d draws %d -> fuzz_failure.npz"
-                  % (cases, kind, n, A, B, r, rn, thr, nms, draws))
+            print("MISMATCH case %d kind %d n %d A %d B %d r %g rn %g thr %g nms %d draws %d sorted %d -> fuzz_failure.npz"
+                  % (cases, kind, n, A, B, r, rn, thr, nms, draws, srt))
             return 1
         if rng.random() < 0.25 and n > 0:               # the preparation steps as well
             k = int(rng.integers(3, 33))
