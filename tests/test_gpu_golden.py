@@ -60,6 +60,29 @@ def test_config1_cheff_view(kpl, cases):
     assert np.array_equal(kp[:, :3], z["xyz"][z["kp"]])
 
 
+def test_sorted_mode_fixture(kpl, cases):
+    """tests/golden/sorted_case.npz: sorted-search mode on the committed clouds, no oracle in the loop"""
+    z, c, s = (np.load(os.path.join(GOLD, f)) for f in ("small_case.npz", "cheff000.npz", "sorted_case.npz"))
+    det = detector(kpl, 5, 6, float(z["r_feat"]), float(z["r_nms"]), float(np.float32(0.5)), os.path.join(GOLD, "small_forest.yaml.gz"))
+    det.setSortedSearch(True)
+    det.setInputCloud(z["xyz"])
+    det.setNormals(z["nrm"])
+    for A, B in ((5, 6), (8, 10)):
+        det.setNAnnulus(A)
+        det.setNBins(B)
+        assert cases.same_bits(det.computePointsForTrainingFeatures(z["query"]), s["small_feat_%dx%d" % (A, B)])
+    det.setNAnnulus(5)
+    det.setNBins(6)
+    _, scores = det.compute()
+    assert cases.same_bits(scores, s["small_scores"]) and np.array_equal(det.getKeypointsIndices(), s["small_kp_thr050"])
+    det = detector(kpl, 5, 6, float(c["r_feat"]), float(c["r_nms"]), float(c["thr"]), CFG_FOREST)
+    det.setSortedSearch(True)
+    det.setInputCloud(c["xyz"])
+    det.setNormals(c["nrm"])
+    _, scores = det.compute()
+    assert cases.same_bits(scores, s["cheff_scores"]) and np.array_equal(det.getKeypointsIndices(), s["cheff_kp"])
+
+
 def test_config2_full_size_vs_oracle_and_properties(kpl, oracle, cases):
     """BASELINE.json configs[1] at full size (200k points)."""
     from tools import forest_yaml, synth

@@ -120,3 +120,20 @@ def test_sorted_detect_is_consistent(oracle, cases):
     assert cases.same_bits(sc, g.scores(nrm, A, B, r, of, order=oracle.ORDER_SORTED))
     assert np.array_equal(kp, g.nms(sc, rn, 0.5))
     assert cases.same_bits(sc, oracle.detect(xyz, nrm, A, B, r, rn, 0.5, of, order=oracle.ORDER_SORTED, threads=4)[0])
+
+
+def test_sorted_fixture(oracle, cases):
+    """tests/golden/sorted_case.npz: the oracle's sorted mode on the two committed clouds (regression anchor; the arrays a
+    PCL + OpenCV run with a sorted search tree could regenerate bit for bit)."""
+    import os
+    from tools import forest_yaml
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    z, s = np.load(os.path.join(gold, "small_case.npz")), np.load(os.path.join(gold, "sorted_case.npz"))
+    r, rn = float(z["r_feat"]), float(z["r_nms"])
+    g = oracle.Grid(z["xyz"], r)
+    for A, B in ((5, 6), (8, 10)):
+        assert cases.same_bits(g.features(z["nrm"], A, B, r, z["query"], order=oracle.ORDER_SORTED), s["small_feat_%dx%d" % (A, B)])
+    of = cases.oracle_forest(forest_yaml.load_forest(os.path.join(gold, "small_forest.yaml.gz")))
+    sc, kp = oracle.detect(z["xyz"], z["nrm"], 5, 6, r, rn, float(f32(0.5)), of, order=oracle.ORDER_SORTED)
+    assert cases.same_bits(sc, s["small_scores"]) and np.array_equal(kp, s["small_kp_thr050"])
+    assert not cases.same_bits(s["small_scores"], z["scores"])

@@ -129,7 +129,35 @@ def make_cheff():
           os.path.getsize(os.path.join(GOLD, "cheff000.npz")) // 1024, "KiB")
 
 
+def make_sorted_case():
+    """the same two clouds in SORTED-search mode (neighbors in ascending (distance, index) order: what a
+    pcl::search::KdTree(true) handed to setSearchMethod gives the feature loop).  This is the file a PCL + OpenCV run
+    could regenerate and compare BIT FOR BIT (tests/golden/README.md); until then a regression anchor."""
+    z = np.load(os.path.join(GOLD, "small_case.npz"))
+    xyz, nrm, q = z["xyz"], z["nrm"], z["query"]
+    r, rn = float(z["r_feat"]), float(z["r_nms"])
+    g = kplo.Grid(xyz, r)
+    out = {}
+    for A, B in ((5, 6), (8, 10)):
+        out["small_feat_%dx%d" % (A, B)] = g.features(nrm, A, B, r, q, order=kplo.ORDER_SORTED)
+    fa = forest_yaml.load_forest(os.path.join(GOLD, "small_forest.yaml.gz"))
+    of = kplo.Forest(fa.root, fa.var, fa.thr, fa.left, fa.right, fa.value, fa.var_count)
+    sc, kp = kplo.detect(xyz, nrm, 5, 6, r, rn, f32(0.5), of, order=kplo.ORDER_SORTED)
+    out["small_scores"], out["small_kp_thr050"] = sc, kp
+    c = np.load(os.path.join(GOLD, "cheff000.npz"))
+    fa = forest_yaml.load_forest(os.path.join(ROOT, "data", "forests", "synth200k_a5b6_t10.yaml.gz"))
+    of = kplo.Forest(fa.root, fa.var, fa.thr, fa.left, fa.right, fa.value, fa.var_count)
+    sc, kp = kplo.detect(c["xyz"], c["nrm"], 5, 6, float(c["r_feat"]), float(c["r_nms"]), float(c["thr"]), of,
+                         order=kplo.ORDER_SORTED, threads=8)
+    out["cheff_scores"], out["cheff_kp"] = sc, kp
+    np.savez_compressed(os.path.join(GOLD, "sorted_case.npz"), **out)
+    print("sorted_case.npz:", {k: v.shape for k, v in out.items()}, os.path.getsize(os.path.join(GOLD, "sorted_case.npz")) // 1024, "KiB")
+
+
 if __name__ == "__main__":
+    if "--sorted-only" in sys.argv:          # needs only the committed fixtures, not the reference checkout
+        make_sorted_case()
+        sys.exit(0)
     if not os.path.isdir(REF):
         print("reference checkout absent: nothing to do")
         sys.exit(0)
@@ -138,3 +166,4 @@ if __name__ == "__main__":
     make_small_case()
     make_normals_case()
     make_cheff()
+    make_sorted_case()
