@@ -192,7 +192,9 @@ def main():
         d_cnt.append(d_packed[k, 0:1])
         d_kp.append(d_packed[k, 1:])
         views[k] = (xyz, nrm, mr)
-    tstreams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(ng - 1)]
+    # every group on a stream of its own, none on the null stream: event waits that involve the legacy default stream
+    # serialise the groups (measured: 1 532 instead of 1 785 Mpoints/s with the per-step gather, profiles/r03_notes.md)
+    tstreams = [torch.cuda.Stream() for _ in range(ng)]
     stream = tstreams[0].cuda_stream
     p_scores = [t.data_ptr() for t in d_scores]
     p_kp = [t.data_ptr() for t in d_kp]
@@ -207,9 +209,13 @@ def main():
         else:
             kpl.compute_batch_device(dets[sl], p_scores[sl], p_kp[sl], caps, p_cnt[sl], tstreams[g].cuda_stream)
 
+    gather_done = [None] * ng            # N > 1: the gather of a group's previous batch (it reads the buffers the next one writes)
+
     def step():
         g = step_no[0] % ng
         step_no[0] += 1
+        if gather_done[g] is not None:
+            tstreams[g].wait_event(gather_done[g])
         run_group(g)
         return g
 
@@ -255,12 +261,21 @@ def main():
     if use_dist:
         kd = importlib.import_module("keypoint-learning_amd.dist")
 
+        comm_stream = torch.cuda.Stream()
+
         def full_step():
             g = step()
-            with torch.cuda.stream(tstreams[g]):    # the collective is ordered after that batch's stream
+            # the collective runs on a stream of its own, ordered after that batch and before the group's NEXT batch
+            # (two steps later): it never holds up the scoring of the other group
+            batch_done = torch.cuda.Event()
+            batch_done.record(tstreams[g])
+            with torch.cuda.stream(comm_stream):
+                comm_stream.wait_event(batch_done)
                 send = d_packed[g * nb:(g + 1) * nb, :gather_cap + 1].contiguous().view(-1)
                 # the one exchange step of the path: all-gather of the packed keypoint lists (RCCL)
                 gathered[0] = kd.gather_keypoints(send if args.backend == "nccl" else send.cpu())
+                gather_done[g] = torch.cuda.Event()
+                gather_done[g].record(comm_stream)
     else:
         full_step = step
 
