@@ -1596,6 +1596,50 @@ __device__ __forceinline__ float forest_sum(const ForestDev &forest, const uint2
     return (float)sum;
 }
 
+// The same in-step walk for a lane that takes every tstride-th tree starting at `first` (a point shared by tstride
+// lanes): at most WAYS trees per lane, the whole forest in LDS, features x[var * xstride].  Returns the lane's part of
+// the sum as a float -- exact, and independent of the split, when the leaf values are small integers (order_free).
+template <bool STATS, int WAYS>
+__device__ __forceinline__ float forest_sum_strided(const ForestDev &forest, const uint2 *lnodes, const float *x, int xstride,
+                                                    int nvars, int first, int tstride, int &depth) {
+    const uint32_t last_var = (uint32_t)nvars - 1u;
+    uint32_t nd[WAYS];
+    uint2 node[WAYS];
+    bool mine[WAYS], done[WAYS];
+#pragma unroll
+    for (int k = 0; k < WAYS; ++k) {
+        mine[k] = first + tstride * k < forest.ntrees;
+        nd[k] = mine[k] ? (uint32_t)(first + tstride * k) : (uint32_t)forest.ntrees;     // no tree: the resting leaf (value 0)
+        done[k] = !mine[k];
+    }
+    for (;;) {
+#pragma unroll
+        for (int k = 0; k < WAYS; ++k) node[k] = lnodes[nd[k]];
+        float val[WAYS];
+        bool leaf[WAYS];
+#pragma unroll
+        for (int k = 0; k < WAYS; ++k) {
+            const uint32_t var = node[k].y >> 24;
+            leaf[k] = var == 255u;
+            val[k] = x[__umul24(min(var, last_var), (uint32_t)xstride)];      // a leaf reads the last feature and ignores it
+        }
+        bool all_done = true;
+#pragma unroll
+        for (int k = 0; k < WAYS; ++k) {
+            const uint32_t next = (node[k].y & 0x00ffffffu) + (val[k] <= __uint_as_float(node[k].x) ? 0u : 1u);
+            if (STATS) depth += done[k] ? 0 : 1;
+            if (STATS) done[k] = leaf[k];
+            nd[k] = leaf[k] ? nd[k] : next;
+            all_done &= leaf[k];
+        }
+        if (__all(all_done)) break;
+    }
+    float sum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < WAYS; ++k) sum += __uint_as_float(node[k].x);           // (the resting leaf adds 0)
+    return sum;
+}
+
 // WAYS trees of a forest with blocks, walked to their leaves: tree[k] < 0 = no tree (leaf value 0).
 //   phase 1  the top part, one level per step, until every walk is at a leaf or at the root of a block
 //   phase 2  one block = up to three levels per step.  A finished walk fetches block 0 (one line shared
@@ -1913,6 +1957,84 @@ __global__ __launch_bounds__(1024) void forest_kernel(Batch b, int maxF, int nld
             if (!a.nd.non_maxima) a.flags[__float_as_int(w.p.w)] = 1;               // hpp:189-196
             // hpp:205-207: a non-finite response is never a candidate (!pcl_isfinite(intensity))
             else if (isfinite(score) && !((double)score < a.nd.thr)) a.cand.list[atomicAdd(a.cand.count, 1)] = w.s;
+        }
+    }
+}
+
+// The forest kernel for small forests whose sum is exact in any order (class labels: every forest the reference
+// trains; the 10-tree bench forest): G = 2 lanes per point.  A wave takes half a chunk (32 points, F x 32 floats = 3.8 KB
+// at F = 30 instead of 7.7 KB), lane 32 g + p walks the trees g, g + 2, ... of point p in step (5 or 8 of them), the
+// partial sums meet through one cross-lane read.  Same work per point; but a wave's in-step walk lasts as long as the
+// deepest of its walks (320 instead of 640 of them), and 16 waves need 118 KB of LDS instead of 13 waves 156 KB: the other
+// batch's feature kernel keeps 40 KB of every CU while this one runs.  8 views of 200 k points: 0.152 -> 0.133 ms alone,
+// two batches in flight 1 802 -> 1 884 Mpoints/s.
+constexpr int kPairWays = 8;           // trees per lane at most: forests of up to 16 trees (5 for up to 10)
+template <bool STATS, int G, int WAYS>
+__global__ __launch_bounds__(1024) void forest_pair_kernel(Batch b, int maxF, int nlds_cap) {
+    extern __shared__ uint2 lnodes[];
+    constexpr int kPts = kLanes / G;                         // points per wave
+    const ViewDev &a = b.view[blockIdx.y];
+    const int lane = threadIdx.x & (kLanes - 1), wid = threadIdx.x / kLanes, nwaves = blockDim.x / kLanes;
+    const int p = lane & (kPts - 1), g = lane / kPts;
+    const int nlds = min(nlds_cap, a.forest.nnodes);        // the whole forest (launch_forest_stage checks that it fits)
+    for (int i = threadIdx.x; i < nlds; i += blockDim.x) lnodes[i] = a.forest.nodes[i];
+    __syncthreads();
+    float *H = reinterpret_cast<float *>(lnodes + nlds_cap) + (size_t)wid * maxF * kPts;
+    const int nunits = (a.n + kPts - 1) / kPts;              // units of kPts consecutive storage positions
+    const int F = a.f.F, stride = gridDim.x * nwaves;
+    const int nfinite = a.cell_start[a.ds->grid.ncells];
+    // the feature rows of the NEXT unit are requested before the trees of the current one are walked: rows G c + g of
+    // the unit per load (G rows per load instruction)
+    constexpr int kAhead = 32 / G;
+    float ahead[kAhead];
+    auto request = [&](int unit) {
+        const float *o = a.feat + (size_t)(unit / G) * F * kLanes + (unit % G) * kPts + p;
+#pragma unroll
+        for (int c = 0; c < kAhead; ++c) ahead[c] = (unit < nunits && G * c + g < F) ? o[(G * c + g) * kLanes] : 0.0f;
+    };
+    int unit = blockIdx.x * nwaves + wid;
+    request(unit);
+    for (; unit < nunits; unit += stride) {
+        {   // per ORIGINAL point: NaN for points that are not in the grid
+            const int i = unit * kPts + p;
+            if (g == 0 && i < a.n && a.scores && a.cid[i] < 0) a.scores[i] = NAN;
+        }
+        const int s = unit * kPts + p;                       // storage position of the lane's point
+        const bool in_range = s < nfinite;
+        const float4 np = in_range ? a.nrm[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool scoreable = in_range && np.w != 0.0f;     // hpp:277
+        wave_lds_fence();
+#pragma unroll
+        for (int c = 0; c < kAhead; ++c)
+            if (G * c + g < F) H[(G * c + g) * kPts + p] = ahead[c];
+        if (F > G * kAhead) {
+            const float *o = a.feat + (size_t)(unit / G) * F * kLanes + (unit % G) * kPts + p;
+            for (int c = G * kAhead + g; c < F; c += G) H[c * kPts + p] = o[c * kLanes];
+        }
+        wave_lds_fence();
+        request(unit + stride);
+        int depth = 0;
+        float part = forest_sum_strided<STATS, WAYS>(a.forest, lnodes, H + p, kPts, F, g, G, depth);
+#pragma unroll
+        for (int off = kPts; off < kLanes; off <<= 1) {      // exact in any order: integer leaf values
+            part += __shfl_xor(part, off);
+            if (STATS) depth += __shfl_xor(depth, off);
+        }
+        if (g != 0 || !in_range) continue;
+        float score = NAN;
+        if (scoreable) {
+            score = 1 - (part / (a.forest.ntrees * 1.0f));                          // hpp:287
+            if (STATS) {
+                atomicAdd(&a.stats->sum_depth, (unsigned long long)depth);
+                atomicAdd(&a.stats->n_scored, 1ull);
+            }
+        }
+        const int orig = __float_as_int(a.pts[s].w);
+        a.score_sorted[s] = score;
+        if (a.scores) a.scores[orig] = score;
+        if (scoreable) {
+            if (!a.nd.non_maxima) a.flags[orig] = 1;                                // hpp:189-196
+            else if (isfinite(score) && !((double)score < a.nd.thr)) a.cand.list[atomicAdd(a.cand.count, 1)] = s;
         }
     }
 }
@@ -2813,6 +2935,32 @@ void launch_forest_stage(const Batch &b, hipStream_t st) {
         if (stats) forest_split_kernel<true, kSplitWays><<<sgrid, (int)w * kLanes, lds, st>>>(b, maxF, nlds_cap, G);
         else forest_split_kernel<false, kSplitWays><<<sgrid, (int)w * kLanes, lds, st>>>(b, maxF, nlds_cap, G);
         return;
+    }
+    // small order-free forests that fit the LDS whole: two lanes per point (forest_pair_kernel)
+    {
+        int max_all = 1, max_trees = 0;
+        for (int v = 0; v < b.nviews; ++v) {
+            max_all = b.view[v].forest.nnodes > max_all ? b.view[v].forest.nnodes : max_all;
+            max_trees = b.view[v].forest.ntrees > max_trees ? b.view[v].forest.ntrees : max_trees;
+        }
+        constexpr int G = 2;       // (4 lanes per point, 3 trees each: 0.172 instead of 0.133 ms, profiles/r03_notes.md)
+        const size_t node_bytes = sizeof(uint2) * (size_t)max_all, slice = sizeof(float) * (size_t)maxF * (kLanes / G);
+        if (any_order && max_trees <= 2 * kPairWays && node_bytes <= kForestNodeBytes && node_bytes + 16 * slice <= kForestLds) {
+            const int waves = 16;
+            int wgs = div_up(cu_count(), b.nviews);
+            const int wgs_max = div_up(div_up(n, kLanes / G), waves);
+            if (wgs > wgs_max) wgs = wgs_max;
+            const size_t lds = node_bytes + slice * (size_t)waves;
+            const dim3 grid(wgs, b.nviews);
+            if (max_trees <= 10) {
+                if (stats) forest_pair_kernel<true, 2, 5><<<grid, waves * kLanes, lds, st>>>(b, maxF, max_all);
+                else forest_pair_kernel<false, 2, 5><<<grid, waves * kLanes, lds, st>>>(b, maxF, max_all);
+            } else {
+                if (stats) forest_pair_kernel<true, 2, kPairWays><<<grid, waves * kLanes, lds, st>>>(b, maxF, max_all);
+                else forest_pair_kernel<false, 2, kPairWays><<<grid, waves * kLanes, lds, st>>>(b, maxF, max_all);
+            }
+            return;
+        }
     }
     const ForestLaunch fl = forest_launch(maxF, max_nodes);
     int wgs = div_up(cu_count(), b.nviews);                   // persistent: about one workgroup per CU
