@@ -72,7 +72,8 @@ struct kpl_detector {
     DevBuf stage_xyz, stage_nrm, stage_idx, stage_feat;
     DevBuf dstate, cid, btable, cell_start, tmp_idx, scan_tmp, pts, nrm, pos_of;
     DevBuf score_sorted, flags, prefix, stats, out_scores, out_kp, out_count, cand_list, cand_count;
-    DevBuf draw_list, draw_count, skip, feat;
+    DevBuf draw_list, draw_count, skip, feat, scan_state;
+    unsigned epoch = 0;           // detect calls so far (tags the words of scan_state)
     DevBuf org_scratch;           // kpl_estimate_normals_organized: change map, distance map, integral image
     int cells_cap = 0;            // capacity (cells) of cell_start
     DevState *h_state = nullptr;  // pinned copy of the device state (status read-back)
@@ -356,6 +357,12 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
     }
     KPL_HIP(h, h->cand_list.ensure(sizeof(int) * nn));
     KPL_HIP(h, h->prefix.ensure(sizeof(int) * (nn + 2)));
+    if (h->scan_state.cap < scan_state_bytes(n)) {
+        KPL_HIP(h, hipDeviceSynchronize());
+        KPL_HIP(h, h->scan_state.ensure(scan_state_bytes(n)));
+        KPL_HIP(h, hipMemset(h->scan_state.p, 0, h->scan_state.cap));     // epoch 0 = "never written"
+    }
+    if (++h->epoch == 0u) h->epoch = 1u;
     const NmsDesc nd = make_nms(h->prm);
     if (nd.draws_remove) {
         if (h->skip.cap < sizeof(int) * nn) {
@@ -375,6 +382,8 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
     v.scores = d_scores;
     v.flags = h->flags.as<int>();
     v.prefix = h->prefix.as<int>();
+    v.scan_state = h->scan_state.as<unsigned long long>();
+    v.epoch = h->epoch;
     v.cand = NmsList{h->cand_list.as<int>(), h->cand_count.as<int>()};
     v.draw_list = h->draw_list.as<int>();
     v.draw_count = h->draw_count.as<int>();
@@ -654,7 +663,7 @@ void kpl_destroy(kpl_detector *h) {
                       &h->dstate, &h->cid, &h->btable, &h->cell_start, &h->tmp_idx, &h->scan_tmp,
                       &h->pts, &h->nrm, &h->pos_of, &h->score_sorted, &h->flags, &h->prefix, &h->stats,
                       &h->out_scores, &h->out_kp, &h->out_count, &h->cand_list, &h->cand_count,
-                      &h->draw_list, &h->draw_count, &h->skip, &h->feat};
+                      &h->draw_list, &h->draw_count, &h->skip, &h->feat, &h->scan_state};
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->h_state) (void)hipHostFree(h->h_state);

@@ -99,6 +99,8 @@ struct ViewDev {
     float *score_sorted;         // [n] out, storage order
     float *scores;               // [n] out, original order (may be null)
     int *flags, *prefix;         // [n+1] keypoint flags in original order and their scan
+    unsigned long long *scan_state;   // one word per 4096 flags: the single-pass scan of the compaction (kernels.hip)
+    unsigned epoch;              // tag of this call in those words (never 0)
     NmsList cand;                // points that passed the threshold
     // draws pass + compaction ("detectKeypoints")
     int *draw_list, *draw_count, *skip;
@@ -148,6 +150,8 @@ void launch_forest_stage(const Batch &b, hipStream_t st);
 // all zero on entry to a detect call; the compaction leaves them zeroed again
 void launch_post(const Batch &b, hipStream_t st);
 
+// bytes of ViewDev::scan_state for a view of n points (zeroed once when allocated, never cleared afterwards)
+size_t scan_state_bytes(int n);
 // ints of the (chunk, bin) table + bin totals + bin starts of the index sort of a view of n points (the two
 // arrays of kBuckets + 1 ints each sit at the end)
 size_t btable_ints(int n);

@@ -2694,30 +2694,113 @@ __global__ __launch_bounds__(128) void radius_normals_kernel(const float4 *__res
                  out.curvature_stride, i);
 }
 
-// ordered compaction; also leaves flags[] and the candidate counter clean for the next call
-__global__ __launch_bounds__(256) void compact_kernel(Batch b) {
+// Ordered compaction of the keypoint flags; also leaves flags[] and the candidate counter clean for the next call.
+// ONE launch: scan of the keypoint flags and ordered scatter together, the running total handed from
+// block to block through a word per block (single-pass scan with decoupled look-back).  Block x of a view owns the flags
+// [4096 x, 4096 x + 4096): it counts them, publishes the count (status AGGREGATE), one wave adds up the words of the blocks
+// before it -- 64 at a time, back to the nearest block that already knows its inclusive prefix -- publishes its own inclusive
+// prefix (status PREFIX) and scatters.  A word is (call epoch << 32 | status << 30 | value): words of earlier calls are simply
+// "not there yet", nothing is cleared between calls.  Workgroups are dispatched in index order, so the blocks a block waits
+// for are running or done.  Replaces scan_sums + scan_top + scan_apply + compact_kernel: the chain NMS -> keypoint list is 2
+// launches instead of 5, which matters most where every launch queues behind another batch's feature kernel.
+constexpr unsigned kScanAggregate = 1u, kScanPrefix = 2u;
+
+__device__ __forceinline__ void scan_publish(unsigned long long *word, unsigned epoch, unsigned status, unsigned value) {
+    __hip_atomic_store(word, ((unsigned long long)epoch << 32) | ((unsigned long long)status << 30) | (unsigned long long)value,
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(kScanBlock) void compact_scan_kernel(Batch b) {
     const ViewDev &v = b.view[blockIdx.y];
-    const DevState *ds = v.ds;
-    int *flags = v.flags;
-    const int *prefix = v.prefix;
     const int n = v.n, kp_cap = v.kp_cap;
-    int *kp_idx = v.kp_idx, *kp_count = v.kp_count, *cand_count = v.cand.count;
-    float *kp_score = v.kp_score;
+    const int nb = n > 0 ? (n + kScanChunk - 1) / kScanChunk : 1;      // blocks of this view (block 0 exists for an empty view too)
+    if ((int)blockIdx.x >= nb) return;
+    int *flags = v.flags;
     int *skip = v.nd.draws_remove ? v.skip : nullptr;
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) {
-        *kp_count = ds->status != 0 ? -1 : prefix[n];   // -1: see kpl_sync_status
-        *cand_count = 0;
-    }
-    if (i >= n) return;
-    if (skip) skip[i] = 0;
-    if (flags[i]) {
-        int pos = prefix[i];
-        if (pos < kp_cap) {
-            kp_idx[pos] = i;
-            if (kp_score) kp_score[pos] = v.scores[i];       // (scores is set whenever kp_score is)
+    unsigned long long *state = v.scan_state;
+    const unsigned epoch = v.epoch;
+    const int base = blockIdx.x * kScanChunk + threadIdx.x * kScanPerThread;
+    int f[kScanPerThread];
+    int s = 0;
+    const bool whole = base + kScanPerThread <= n;
+    if (whole) {
+        int4 *q = reinterpret_cast<int4 *>(flags + base);
+#pragma unroll
+        for (int k = 0; k < kScanPerThread / 4; ++k) {
+            const int4 x = q[k];
+            f[4 * k] = x.x;
+            f[4 * k + 1] = x.y;
+            f[4 * k + 2] = x.z;
+            f[4 * k + 3] = x.w;
+            q[k] = make_int4(0, 0, 0, 0);                    // flags[] is left clean for the next call
         }
-        flags[i] = 0;
+    } else {
+#pragma unroll
+        for (int k = 0; k < kScanPerThread; ++k) {
+            f[k] = base + k < n ? flags[base + k] : 0;
+            if (base + k < n) flags[base + k] = 0;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kScanPerThread; ++k) s += f[k] != 0 ? 1 : 0;
+    int total;
+    const int excl = block_exclusive_scan(s, &total);
+    __shared__ int carry;
+    if (threadIdx.x < kWave) {                               // the first wave: publish, look back, publish
+        const int lane = threadIdx.x;
+        if (lane == 0) scan_publish(&state[blockIdx.x], epoch, blockIdx.x == 0 ? kScanPrefix : kScanAggregate, (unsigned)total);
+        int before = 0;
+        for (int top = (int)blockIdx.x - 1; top >= 0;) {     // blocks top, top - 1, ... top - 63
+            const int j = top - lane;
+            unsigned long long w = 0ull;
+            bool ready;
+            int polls = 0;
+            do {                                             // every lane of the window up to the nearest PREFIX must be there
+                if (j >= 0) w = __hip_atomic_load(&state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ready = j < 0 || ((unsigned)(w >> 32) == epoch && ((unsigned)w >> 30) != 0u);
+                const unsigned long long have = __ballot(ready);
+                const unsigned long long pref = __ballot(ready && j >= 0 && ((unsigned)w >> 30) == kScanPrefix);
+                // usable when the lanes below the first PREFIX lane (or all 64) are ready
+                const int first = pref ? __builtin_ctzll(pref) : 63;
+                const unsigned long long need = first == 63 ? ~0ull : ((2ull << first) - 1ull);
+                if ((have & need) == need) {
+                    const bool take = j >= 0 && lane <= first;
+                    int val = take ? (int)((unsigned)w & 0x3fffffffu) : 0;
+                    for (int off = kWave / 2; off > 0; off >>= 1) val += __shfl_xor(val, off);
+                    before += val;
+                    top = pref ? -1 : top - kWave;
+                    break;
+                }
+                if (++polls > (1 << 22)) {                   // (never seen; a wrong count is better than a hung device)
+                    before = -(1 << 29);
+                    top = -1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            } while (true);
+        }
+        if (lane == 0) {
+            if (blockIdx.x != 0) scan_publish(&state[blockIdx.x], epoch, kScanPrefix, (unsigned)(before + total));
+            carry = before;
+            if ((int)blockIdx.x == nb - 1) {                 // the last block knows the keypoint count
+                *v.kp_count = v.ds->status != 0 ? -1 : before + total;     // -1: see kpl_sync_status
+                *v.cand.count = 0;
+            }
+        }
+    }
+    __syncthreads();
+    int run = carry + excl;
+#pragma unroll
+    for (int k = 0; k < kScanPerThread; ++k) {
+        const int i = base + k;
+        if (skip && i < n) skip[i] = 0;
+        if (f[k] != 0) {
+            if (run < kp_cap) {
+                v.kp_idx[run] = i;
+                if (v.kp_score) v.kp_score[run] = v.scores[i];     // (scores is set whenever kp_score is)
+            }
+            ++run;
+        }
     }
 }
 
@@ -3014,14 +3097,10 @@ void launch_post(const Batch &b, hipStream_t st) {
             draws_kernel<<<dim3(1, nv), 64, 0, st>>>(b);
         }
     }
-    jobs.match = -1;
-    for (int v = 0; v < nv; ++v) {
-        const ViewDev &w = b.view[v];
-        jobs.job[v] = ScanJob{w.flags, w.prefix, nullptr, nullptr, w.n, w.scan_tmp};
-    }
-    run_scan(jobs, nv, st);
-    compact_kernel<<<dim3(div_up(n > 0 ? n : 1, 256), nv), 256, 0, st>>>(b);
+    compact_scan_kernel<<<dim3(n > 0 ? div_up(n, kScanChunk) : 1, nv), kScanBlock, 0, st>>>(b);
 }
+
+size_t scan_state_bytes(int n) { return sizeof(unsigned long long) * ((size_t)(n > 0 ? n : 1) / kScanChunk + 2); }
 
 void launch_resolution(const float4 *pts, const int *cell_start, const int *pos_of, const DevState *ds,
                        int n, float *val, double *out, void *scratch, hipStream_t st) {
