@@ -42,8 +42,8 @@ def main():
         shutil.copy(stats[-1], os.path.join(prof, tag + "_kernel_stats.csv"))
         for r in csv.DictReader(open(stats[-1])):
             name = r["Name"]
-            for k in ("feature_kernel<false>", "forest_kernel<false>", "nms_kernel<false>", "cell_sort_store_kernel",
-                      "bucket_scatter_kernel", "bucket_hist_kernel"):
+            for k in ("feature_kernel<false>", "forest_kernel<false>", "forest_pair_kernel<false, 2, 5>", "nms_kernel<false>",
+                      "cell_sort_store_kernel", "bucket_scatter_kernel", "bucket_hist_kernel", "compact_scan_kernel"):
                 if k in name:
                     avg_ns[k] = float(r["AverageNs"])
                     calls[k] = int(r["Calls"])
@@ -69,7 +69,7 @@ def main():
         shutil.copy(cpath, os.path.join(prof, tag + "_valu_ceiling.json"))
         ceiling = json.load(open(cpath))
     kernels = {}
-    for k in ("feature_kernel<false>", "forest_kernel<false>"):
+    for k in ("feature_kernel<false>", "forest_kernel<false>", "forest_pair_kernel<false, 2, 5>"):
         c = pmc.get(k)
         if not c:
             continue
@@ -92,14 +92,15 @@ def main():
                     e[name] = round(c[name], 1)
             # VALU issue model: instructions by class x the issue ceilings measured on this box
             if ceiling and c.get("SQ_INSTS_VALU_ADD_F32") is not None:
-                mangled = {"feature_kernel<false>": "feature_kernelILb0", "forest_kernel<false>": "forest_kernelILb0"}[k]
+                mangled = {"feature_kernel<false>": "feature_kernelILb0", "forest_kernel<false>": "forest_kernelILb0",
+                           "forest_pair_kernel<false, 2, 5>": "forest_pair_kernelILb0ELi2ELi5"}[k]
                 e["valu_model"] = valu_model.model(c, c.get("GRBM_GUI_ACTIVE_valu", c["GRBM_GUI_ACTIVE"]) / XCDS, ceiling, mangled)
                 e["valu_issue_frac"] = e["valu_model"]["valu_issue_frac"]
             if c.get("SQ_LDS_BANK_CONFLICT") is not None and c.get("SQ_ACTIVE_INST_LDS"):
                 # SQ_ACTIVE_INST_LDS / SQ_LDS_BANK_CONFLICT count quad-cycles summed over the SIMDs (MI355X_MICROARCH.md)
                 e["lds_busy"] = round(c["SQ_ACTIVE_INST_LDS"] * 4.0 / (SIMDS * c.get("GRBM_GUI_ACTIVE_lds", c["GRBM_GUI_ACTIVE"]) / XCDS), 4)
                 e["lds_bank_conflict_share"] = round(c["SQ_LDS_BANK_CONFLICT"] / max(c["SQ_ACTIVE_INST_LDS"], 1.0), 4)
-        kernels[k.split("<")[0]] = e
+        kernels["forest_kernel" if k.startswith("forest_pair") else k.split("<")[0]] = dict(e, kernel=k)
     json.dump({"tag": tag, "source_sha256": sha, "views_per_launch": views, "kernels": kernels,
                "formulas": {"hbm_bytes": "(2*FETCH_SIZE + WRITE_SIZE) KiB * 1024, separate rocprofv3 --pmc passes",
                             "valu_busy": "SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * GRBM_GUI_ACTIVE / 8): an UPPER bound (4 cycles per instruction)",
