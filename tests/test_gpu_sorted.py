@@ -154,3 +154,35 @@ def test_batch_mixes_both_orders(kpl, oracle, cases):
                                        order=oracle.ORDER_SORTED if srt else oracle.ORDER_CANONICAL)
             assert cases.same_bits(ds.cpu().numpy(), o_sc)
             assert np.array_equal(dk[1:1 + int(dk[0].item())].cpu().numpy(), o_kp)
+
+
+def test_sorted_mode_counters_and_device_features(kpl, oracle, cases):
+    """the instrumented pass (kpl_collect_stats) and the device-resident feature entry point in sorted mode: the neighbor
+    counts do not depend on the order, the feature rows equal the oracle's sorted rows"""
+    import torch
+    from tools import forest_yaml
+    import os
+    forest = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data", "forests", "synth200k_a5b6_t10.yaml.gz")
+    xyz, nrm = cases.cloud(90, 70, seed=12)
+    mr = oracle.cloud_resolution(xyz)
+    r, rn, thr = float(np.float32(6 * mr)), float(np.float32(4 * mr)), float(np.float32(0.85))
+    dev = torch.device("cuda", 0)
+    n = len(xyz)
+    dx, dn = torch.from_numpy(xyz.copy()).to(dev), torch.from_numpy(nrm.copy()).to(dev)
+    stats = {}
+    for srt in (False, True):
+        det = make_det(kpl, 5, 6, r, rn, thr, sorted_search=srt)
+        assert det.loadForest(forest)
+        det.bindCloudDevice(dx.data_ptr(), 12, dn.data_ptr(), 12, n)
+        stats[srt] = det.collectStats(None)
+        q = torch.arange(0, n, 5, dtype=torch.int32, device=dev)
+        out = torch.empty(len(q), 30, dtype=torch.float32, device=dev)
+        det._push()
+        det._check(det._lib.kpl_compute_features_device(det._h, q.data_ptr(), len(q), out.data_ptr(), None))
+        torch.cuda.synchronize()
+        want = oracle.Grid(xyz, r).features(nrm, 5, 6, r, q.cpu().numpy(), order=oracle.ORDER_SORTED if srt else oracle.ORDER_CANONICAL)
+        assert cases.same_bits(out.cpu().numpy(), want)
+    assert stats[False]["sum_kf"] == stats[True]["sum_kf"] > 0 and stats[False]["n_scored"] == stats[True]["n_scored"] == n
+    fa = forest_yaml.load_forest(forest)
+    c = oracle.Grid(xyz, r).alg_counters(nrm, 5, 6, r, rn, thr, cases.oracle_forest(fa))
+    assert stats[False]["sum_kf"] == c["sum_kf"] and stats[False]["sum_depth"] == c["sum_depth"]
