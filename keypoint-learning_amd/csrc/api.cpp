@@ -73,7 +73,6 @@ struct kpl_detector {
     DevBuf dstate, cid, btable, cell_start, tmp_idx, scan_tmp, pts, nrm, pos_of;
     DevBuf score_sorted, flags, prefix, stats, out_scores, out_kp, out_count, cand_list, cand_count;
     DevBuf draw_list, draw_count, skip, feat, scan_state;
-    unsigned epoch = 0;           // detect calls so far (tags the words of scan_state)
     DevBuf org_scratch;           // kpl_estimate_normals_organized: change map, distance map, integral image
     int cells_cap = 0;            // capacity (cells) of cell_start
     DevState *h_state = nullptr;  // pinned copy of the device state (status read-back)
@@ -360,9 +359,8 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
     if (h->scan_state.cap < scan_state_bytes(n)) {
         KPL_HIP(h, hipDeviceSynchronize());
         KPL_HIP(h, h->scan_state.ensure(scan_state_bytes(n)));
-        KPL_HIP(h, hipMemset(h->scan_state.p, 0, h->scan_state.cap));     // epoch 0 = "never written"
+        KPL_HIP(h, hipMemset(h->scan_state.p, 0, h->scan_state.cap));     // tag 0 = "never written"
     }
-    if (++h->epoch == 0u) h->epoch = 1u;
     const NmsDesc nd = make_nms(h->prm);
     if (nd.draws_remove) {
         if (h->skip.cap < sizeof(int) * nn) {
@@ -383,7 +381,6 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
     v.flags = h->flags.as<int>();
     v.prefix = h->prefix.as<int>();
     v.scan_state = h->scan_state.as<unsigned long long>();
-    v.epoch = h->epoch;
     v.cand = NmsList{h->cand_list.as<int>(), h->cand_count.as<int>()};
     v.draw_list = h->draw_list.as<int>();
     v.draw_count = h->draw_count.as<int>();

@@ -100,7 +100,6 @@ struct ViewDev {
     float *scores;               // [n] out, original order (may be null)
     int *flags, *prefix;         // [n+1] keypoint flags in original order and their scan
     unsigned long long *scan_state;   // one word per 4096 flags: the single-pass scan of the compaction (kernels.hip)
-    unsigned epoch;              // tag of this call in those words (never 0)
     NmsList cand;                // points that passed the threshold
     // draws pass + compaction ("detectKeypoints")
     int *draw_list, *draw_count, *skip;
@@ -129,6 +128,7 @@ struct DevState {
     int ncells_needed;    // what this view needs (to grow the cell tables before a retry)
     int bshift, nbuckets; // index sort: nbuckets buckets of 2^bshift consecutive cells
     uint32_t bbox[6];     // order-preserving encoded min / max accumulators (self re-arming)
+    uint32_t scan_epoch;  // tag of the next detect call in the words of scan_state (advanced on the device, never 0)
 };
 void init_dev_state(DevState *host_copy);
 

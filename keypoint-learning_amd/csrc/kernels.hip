@@ -2699,8 +2699,8 @@ __global__ __launch_bounds__(128) void radius_normals_kernel(const float4 *__res
 // block to block through a word per block (single-pass scan with decoupled look-back).  Block x of a view owns the flags
 // [4096 x, 4096 x + 4096): it counts them, publishes the count (status AGGREGATE), one wave adds up the words of the blocks
 // before it -- 64 at a time, back to the nearest block that already knows its inclusive prefix -- publishes its own inclusive
-// prefix (status PREFIX) and scatters.  A word is (call epoch << 32 | status << 30 | value): words of earlier calls are simply
-// "not there yet", nothing is cleared between calls.  Workgroups are dispatched in index order, so the blocks a block waits
+// prefix (status PREFIX) and scatters.  A word is (call tag << 32 | status << 30 | value): words of earlier calls are simply
+// "not there yet", nothing is cleared between calls; the tag is a counter in the view's DevState.  Workgroups are dispatched in index order, so the blocks a block waits
 // for are running or done.  Replaces scan_sums + scan_top + scan_apply + compact_kernel: the chain NMS -> keypoint list is 2
 // launches instead of 5, which matters most where every launch queues behind another batch's feature kernel.
 constexpr unsigned kScanAggregate = 1u, kScanPrefix = 2u;
@@ -2718,7 +2718,9 @@ __global__ __launch_bounds__(kScanBlock) void compact_scan_kernel(Batch b) {
     int *flags = v.flags;
     int *skip = v.nd.draws_remove ? v.skip : nullptr;
     unsigned long long *state = v.scan_state;
-    const unsigned epoch = v.epoch;
+    // the tag of this call lives ON THE DEVICE (DevState, advanced by the last block below): a call that is replayed from a
+    // captured hipGraph gets a fresh tag every time, which a tag passed as a kernel argument would not
+    const unsigned epoch = v.ds->scan_epoch;
     const int base = blockIdx.x * kScanChunk + threadIdx.x * kScanPerThread;
     int f[kScanPerThread];
     int s = 0;
@@ -2785,6 +2787,8 @@ __global__ __launch_bounds__(kScanBlock) void compact_scan_kernel(Batch b) {
             if ((int)blockIdx.x == nb - 1) {                 // the last block knows the keypoint count
                 *v.kp_count = v.ds->status != 0 ? -1 : before + total;     // -1: see kpl_sync_status
                 *v.cand.count = 0;
+                // every block of this launch has published, hence started, hence read the tag: the next call's may be set
+                v.ds->scan_epoch = epoch + 1u == 0u ? 1u : epoch + 1u;
             }
         }
     }
@@ -2825,6 +2829,7 @@ inline int div_up(int a, int b) { return (a + b - 1) / b; }
 // =============================================================================================
 void init_dev_state(DevState *host_copy) {
     memset(host_copy, 0, sizeof(*host_copy));
+    host_copy->scan_epoch = 1u;         // 0 = "never written" in the words of the compaction's scan
     for (int k = 0; k < 3; ++k) {
         host_copy->bbox[k] = 0xffffffffu;
         host_copy->bbox[3 + k] = 0u;
