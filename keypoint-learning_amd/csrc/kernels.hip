@@ -705,7 +705,9 @@ __device__ __forceinline__ void soft_pair(int n, float nm1, float v, float dim, 
     // k = (int)floor(v / dim) and "if (k == n) k--" (cpp:45-48, :76-79).  v >= 0 here (a square root; a cosine
     // clamped to [0, 2]), so k >= 0, and the floor -- an integer-valued float far below 2^24 -- clamped to
     // nm1 = (float)(n - 1) IS the (float)k of cpp:52 / :83: no round trip through the integer
-    const float kf = fminf(floorf(div_rn(v, dim, rdim)), nm1);
+    // (the minimum as an INTEGER minimum of the bit patterns -- both floats are >= +0 --: fminf would first canonicalise the
+    // launch constant nm1 with a v_max_f32 of its own, every time)
+    const float kf = __int_as_float(min(__float_as_int(floorf(div_rn(v, dim, rdim))), __float_as_int(nm1)));
     k = (int)kf;
     float center = (kf * dim) + half_dim;
     float wt = v - center;
