@@ -373,7 +373,7 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
     }
     v.f = make_feat(h->prm);
     v.forest = ForestDev{h->d_nodes.as<uint2>(), h->flat.ntrees, (int)h->flat.nodes.size(), (int)h->flat.ntop,
-                         h->flat.order_free ? 1 : 0};
+                         h->flat.order_free ? 1 : 0, h->flat.chain};
     v.nd = nd;
     v.feat = h->feat.as<float>();
     v.score_sorted = h->score_sorted.as<float>();

@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <algorithm>
 #include <memory>
 
 namespace kpl {
@@ -385,12 +386,16 @@ bool flatten_forest(const ForestModel &m, FlatForest &out, std::string &err) {
     out.var_count = m.var_count;
     out.nodes.reserve((size_t)nn);
     out.order_free = m.ntrees() <= (1 << 15);
+    for (int64_t i = 0; i < nn && out.order_free; ++i)
+        if (m.var[i] < 0 && (!(std::fabs(m.value[i]) <= 32768.0) || m.value[i] != std::floor(m.value[i]))) out.order_free = false;
+    // the forests the chained kernel takes (kernels.hip): level-major throughout, leaf records linked
+    out.chain = out.order_free && m.ntrees() >= kChainMinTrees && m.var_count >= kChainMinVars ? (int)kChainStride : 0;
     std::vector<char> seen((size_t)nn, 0);
     // Top part: ONE breadth-first pass over the whole forest, level by level: the roots of all trees
     // first (root of tree t = node t), then the second level of all trees, and so on, while the whole
     // next level still fits kTopNodes slots.  A node's record is written when it is visited; its two
     // children get adjacent slots reserved at that moment.
-    struct Item { int src; uint32_t dst; int depth; };
+    struct Item { int src; uint32_t dst; int depth; int tree; };
     auto emit = [&](const Item &it, uint32_t lpos, std::string &e) -> int {   // 1 = internal, 0 = leaf, -1 = error
         if (seen[it.src]) { e = "node reachable twice (not a tree)"; return -1; }
         seen[it.src] = 1;
@@ -400,9 +405,9 @@ bool flatten_forest(const ForestModel &m, FlatForest &out, std::string &err) {
             const float v = (float)m.value[it.src];
             // (double)v != value also rejects NaN; +-Inf leaves would make the tree sum Inf - Inf = NaN
             if (!std::isfinite(m.value[it.src]) || (double)v != m.value[it.src]) { e = "leaf value is not a finite float"; return -1; }
-            if (!(std::fabs(v) <= 32768.0f) || v != std::floor(v)) out.order_free = false;
             memcpy(&fn.x, &v, 4);
-            fn.y = kLeafVar << 24;
+            // chained: a leaf points at the root of the tree that follows its own in the chain (forest.h), or at the resting leaf
+            fn.y = (kLeafVar << 24) | (out.chain ? (uint32_t)std::min(it.tree + out.chain, m.ntrees()) : 0u);
             out.nodes[it.dst] = fn;
             return 0;
         }
@@ -420,7 +425,7 @@ bool flatten_forest(const ForestModel &m, FlatForest &out, std::string &err) {
     for (int t = 0; t < m.ntrees(); ++t) {
         const int r = m.root[t];
         if (r < 0 || r >= nn) { err = "root index out of range"; return false; }
-        level.push_back(Item{r, (uint32_t)out.nodes.size(), 1});      // the root of tree t is slot t
+        level.push_back(Item{r, (uint32_t)out.nodes.size(), 1, t});      // the root of tree t is slot t
         out.nodes.push_back(FlatNode{0, 0});
     }
     // the resting leaf (value 0) right behind the roots: where a walk without a tree sits (kernels.hip)
@@ -428,14 +433,14 @@ bool flatten_forest(const ForestModel &m, FlatForest &out, std::string &err) {
         FlatNode rest;
         const float zero = 0.0f;
         memcpy(&rest.x, &zero, 4);
-        rest.y = kLeafVar << 24;
+        rest.y = (kLeafVar << 24) | (uint32_t)m.ntrees();      // it follows itself
         out.nodes.push_back(rest);
     }
     std::vector<Item> pairs;          // internal nodes of the last top level: their children start the blocked part
     while (!level.empty()) {
         size_t internal = 0;
         for (const Item &it : level) internal += m.var[it.src] >= 0 ? 1 : 0;
-        const bool top = out.nodes.size() + 2 * internal <= (size_t)kTopNodes;
+        const bool top = out.chain != 0 || out.nodes.size() + 2 * internal <= (size_t)kTopNodes;
         next.clear();
         for (const Item &it : level) {
             if (m.var[it.src] >= 0 && !top) {       // its children start a block: slot known only then
@@ -448,8 +453,8 @@ bool flatten_forest(const ForestModel &m, FlatForest &out, std::string &err) {
             if (kind == 1) {
                 out.nodes.push_back(FlatNode{0, 0});
                 out.nodes.push_back(FlatNode{0, 0});
-                next.push_back(Item{m.left[it.src], lpos, it.depth + 1});
-                next.push_back(Item{m.right[it.src], lpos + 1, it.depth + 1});
+                next.push_back(Item{m.left[it.src], lpos, it.depth + 1, it.tree});
+                next.push_back(Item{m.right[it.src], lpos + 1, it.depth + 1, it.tree});
             }
         }
         if (!top) break;
@@ -478,7 +483,7 @@ bool flatten_forest(const ForestModel &m, FlatForest &out, std::string &err) {
             depth[0] = parent.depth + 1;
             for (uint32_t sl = 0; sl < 7; ++sl) {
                 if (src[sl] < 0) continue;
-                const Item it{src[sl], b + sl, depth[sl]};
+                const Item it{src[sl], b + sl, depth[sl], parent.tree};
                 if (sl < 3) {
                     const uint32_t c = 1 + 2 * sl;                                // children of slot sl: slots 1 + 2 sl, 2 + 2 sl
                     const int kind = emit(it, b + c, err);

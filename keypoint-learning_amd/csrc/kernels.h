@@ -62,6 +62,7 @@ struct ForestDev {
     int nnodes;              // slots
     int ntop;                // slots of the level-major top part; slots >= ntop are 8-slot blocks (forest.h)
     int order_free;          // FlatForest::order_free: the trees of a point may be summed in any order
+    int chain;               // FlatForest::chain: the leaf records chain tree t to tree t + chain
 };
 
 struct StatsDev {

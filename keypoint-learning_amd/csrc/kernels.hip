@@ -1531,6 +1531,7 @@ __device__ __forceinline__ int point_features_sorted(const float4 *__restrict__ 
 //                            in the L1 until the walk comes back for the next level: the deep walk of
 //                            config 5 moved 28 GB from the L2 for 1.8 GB of nodes (profiles/r02_notes.md).
 constexpr int kTreeWays = 10;    // forest entirely in LDS
+constexpr int kChainWays = 4;    // chained forest (forest_sum_chained): walks per lane
 constexpr int kDeepWays = 4;     // forest with blocks: 16 VGPRs of block per way
 
 template <int WAYS>
@@ -1759,6 +1760,42 @@ __device__ __forceinline__ float forest_sum_deep(const ForestDev &forest, const 
     return (float)sum;
 }
 
+// Node reads of a forest that is only partly in LDS, without merging two paths in registers: per walk ONE register
+// pair, written by an LDS read under the exec mask of the lanes whose node is staged and by a global load under the mask
+// of the others (byte offset slot x 8 in both address spaces: `lnodes` is at LDS address 0).  The two never write the
+// same lane, so neither has to wait for the other, and a walk none of whose lanes is beyond the staged part issues no
+// load instruction at all.  All reads of the four walks are in flight before the one wait.  (The compiler cannot express
+// this: it would wait for the LDS data before it lets the load overwrite the register, or select between two results --
+// 8 instructions per walk and step where this takes 5.)
+#define KPL_FETCH_ONE(K)                                                                                           \
+    "s_andn2_b64 exec, %[sv], %[f" #K "]\n\t"                                                                      \
+    "ds_read_b64 %[n" #K "], %[a" #K "]\n\t"                                                                       \
+    "s_and_b64 exec, %[sv], %[f" #K "]\n\t"                                                                        \
+    "s_cbranch_scc0 " #K "f\n\t"                                                                                   \
+    "global_load_dwordx2 %[n" #K "], %[a" #K "], %[base]\n\t"                                                      \
+    #K ":\n\t"
+__device__ __forceinline__ void fetch_nodes_masked(const uint2 *gnodes, uint32_t last_lds_byte, const uint32_t (&at)[4],
+                                                   uint2 (&node)[4]) {
+    unsigned long long r0, r1, r2, r3, f0, f1, f2, f3, saved;
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 "v_cmp_lt_u32 %[f0], %[last], %[a0]\n\t"          // lanes whose node is beyond the staged part
+                 "v_cmp_lt_u32 %[f1], %[last], %[a1]\n\t"          // (all four compared while every lane is enabled)
+                 "v_cmp_lt_u32 %[f2], %[last], %[a2]\n\t"
+                 "v_cmp_lt_u32 %[f3], %[last], %[a3]\n\t"
+                 KPL_FETCH_ONE(0) KPL_FETCH_ONE(1) KPL_FETCH_ONE(2) KPL_FETCH_ONE(3)
+                 "s_mov_b64 exec, %[sv]\n\t"
+                 "s_waitcnt vmcnt(0) lgkmcnt(0)"
+                 : [n0] "=&v"(r0), [n1] "=&v"(r1), [n2] "=&v"(r2), [n3] "=&v"(r3), [sv] "=&s"(saved),
+                   [f0] "=&s"(f0), [f1] "=&s"(f1), [f2] "=&s"(f2), [f3] "=&s"(f3)
+                 : [last] "s"(last_lds_byte), [a0] "v"(at[0]), [a1] "v"(at[1]), [a2] "v"(at[2]), [a3] "v"(at[3]), [base] "s"(gnodes)
+                 : "scc");
+    node[0] = make_uint2((uint32_t)r0, (uint32_t)(r0 >> 32));
+    node[1] = make_uint2((uint32_t)r1, (uint32_t)(r1 >> 32));
+    node[2] = make_uint2((uint32_t)r2, (uint32_t)(r2 >> 32));
+    node[3] = make_uint2((uint32_t)r3, (uint32_t)(r3 >> 32));
+}
+#undef KPL_FETCH_ONE
+
 // A forest whose leaf values are small integers (class labels: every forest the reference trains,
 // src/main_train_detector.cpp:405-407): the double sum of hpp:281 is then exact in any order and equals an
 // int32 sum, so the trees of a point may be shared out over several lanes and need not be kept in step.
@@ -1769,18 +1806,13 @@ __device__ __forceinline__ float forest_sum_deep(const ForestDev &forest, const 
 // A walk without a tree sits on the forest's resting leaf (slot `ntrees`, value 0, forest.h): it "reaches a
 // leaf" at every step, adds 0 and stays -- no per-walk flags, the loop is bound by VALU issue.
 //
-// DEEP: the forest has blocks (slots >= ntop); nodes beyond the LDS are read one by one from global memory,
-// lanes whose node is in LDS send that load to node 0 (one line shared by all of them).  A walk goes 2
-// levels below the top part on average on config 5: too few to pay for the four loads of a whole block
-// (walk_deep in step for every lane: 2.46 ms against 1.56; top-part steps and deep steps taken apart: 7.1 ms,
-// 3.2 G instructions; deep loads issued by the lanes that need one only: 1.73 ms -- profiles/r02_notes.md).
-template <bool STATS, int kQueueWays, bool DEEP>
+// (The whole forest is in LDS here; forests that are not take forest_sum_chained or forest_sum_deep.)
+template <bool STATS, int kQueueWays>
 __device__ __forceinline__ int forest_sum_any_order(const ForestDev &forest, const uint2 *lnodes, int nlds,
                                                     const float *x, int xstride, int nvars, int first, int tstride,
                                                     bool active, int &depth) {
     const uint32_t last_lds = (uint32_t)(nlds - 1);
     const uint32_t rest = (uint32_t)forest.ntrees;                  // the resting leaf
-    const uint32_t line0 = ((uint32_t)forest.ntop + 15u) & ~15u;   // DEEP: slot of the first pair of blocks
     const uint32_t last_var = (uint32_t)nvars - 1u;
     const int ntrees = active ? forest.ntrees : 0;
     // the leaf values are small integers (order_free): their float sum is exact in any order (|sum| < 2^24) and needs no
@@ -1794,7 +1826,7 @@ __device__ __forceinline__ int forest_sum_any_order(const ForestDev &forest, con
         nd[k] = first + tstride * k < ntrees ? (uint32_t)(first + tstride * k) : rest;
     for (;;) {
         uint2 node[kQueueWays];
-        fetch_nodes<kQueueWays>(forest, lnodes, last_lds, !DEEP, nd, node);
+        fetch_nodes<kQueueWays>(forest, lnodes, last_lds, true, nd, node);
         float val[kQueueWays];
 #pragma unroll
         for (int k = 0; k < kQueueWays; ++k)           // a leaf (var = 255) reads the last feature and ignores it
@@ -1804,10 +1836,7 @@ __device__ __forceinline__ int forest_sum_any_order(const ForestDev &forest, con
         for (int k = 0; k < kQueueWays; ++k) {
             const bool leaf = (node[k].y >> 24) == 255u;
             const uint32_t child = node[k].y & 0x00ffffffu;
-            // right sibling: the next slot, except where the children start blocks of their own (the left one's
-            // at the head of a 16-slot line, forest.h) -- then 8 slots on
-            const uint32_t stride = (DEEP && ((child - line0) & 0x8000000fu) == 0u) ? 8u : 1u;
-            const uint32_t next = child + (val[k] <= __uint_as_float(node[k].x) ? 0u : stride);
+            const uint32_t next = child + (val[k] <= __uint_as_float(node[k].x) ? 0u : 1u);
             if (STATS) depth += nd[k] != rest ? 1 : 0;
             sum += leaf ? __uint_as_float(node[k].x) : 0.0f;
             // a walk that has reached its leaf takes the lane's next tree (its root is node next_tree) or rests
@@ -1815,6 +1844,78 @@ __device__ __forceinline__ int forest_sum_any_order(const ForestDev &forest, con
             next_tree += leaf ? tstride : 0;           // (runs on past ntrees while the lane rests: a few steps)
             walking |= nd[k] != rest;
         }
+        if (!__any(walking)) break;
+    }
+    return (int)sum;
+}
+
+// The any-order sum (see forest_sum_any_order) with the tree queue taken out of the loop: the leaf records of a chained
+// forest (forest.h: level-major throughout, siblings adjacent) link the trees t, t + chain, t + 2 chain, ..., the last one
+// to the resting leaf, which points at itself.  Walk k of the lane starts at the root of tree first + tstride * k and
+// just follows the records (chain = tstride x kChainWays); the loop ends when every walk of the wave rests.
+//   * a walk is kept as the BYTE offset of its node (slot x 8): the address of both node reads
+//   * a walk that rests is at a leaf: the "is every walk resting" test is run only when every walk of every lane is at
+//     one, and the wave looks every second step
+// A wave issues its instructions one after the other and four waves per SIMD hide little of it: what counts here is
+// the NUMBER of instructions per walk and step, of any kind -- 19 where the tree queue of forest_sum_any_order with the
+// two node paths merged in registers took 45 (config 5: forest kernel 1.23 -> 0.88 ms; 75 instructions per step of
+// the wave, one per 5 cycles of the SIMD).  The price is that a walk cannot take over trees from a slower one of the
+// same lane (config 5: 91 steps per 16 points against 82; 49 if no walk ever idled -- profiles/r03_notes.md).
+template <bool STATS, bool DEEP>
+__device__ __forceinline__ int forest_sum_chained(const ForestDev &forest, const uint2 *lnodes, int nlds,
+                                                  const float *x, int xstride, int nvars, int first, int tstride,
+                                                  bool active, int &depth) {
+    constexpr int WAYS = kChainWays;
+    static_assert(WAYS == 4, "fetch_nodes_masked is written for four walks");
+    const uint32_t last_lds_byte = (uint32_t)(nlds - 1) << 3;
+    const uint32_t rest = (uint32_t)forest.ntrees << 3;             // the resting leaf
+    const uint32_t last_var = (uint32_t)nvars - 1u;
+    const int ntrees = active ? forest.ntrees : 0;
+    const uint32_t xbase = (uint32_t)lds_address(x), xbytes = (uint32_t)xstride * 4u;
+    float sum = 0.0f;
+    uint32_t at[WAYS];
+#pragma unroll
+    for (int k = 0; k < WAYS; ++k)                     // level-major layout: the root of tree t is node t
+        at[k] = first + tstride * k < ntrees ? (uint32_t)(first + tstride * k) << 3 : rest;
+    const unsigned long long every_lane = __ballot(true);
+    auto step = [&]() -> unsigned long long {              // one step of the four walks; returns the lanes whose walks are ALL at a leaf
+        uint2 node[WAYS];
+        if (DEEP) {
+            fetch_nodes_masked(forest.nodes, last_lds_byte, at, node);
+        } else {
+#pragma unroll
+            for (int k = 0; k < WAYS; ++k) node[k] = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(lnodes) + at[k]);
+        }
+        float val[WAYS];
+#pragma unroll
+        for (int k = 0; k < WAYS; ++k)                 // a leaf (var = 255) reads the last feature and ignores it
+            val[k] = hist_at((int)(__umul24(min(node[k].y >> 24, last_var), xbytes) + xbase));
+        unsigned long long all_at_leaf = every_lane;
+#pragma unroll
+        for (int k = 0; k < WAYS; ++k) {
+            const bool leaf = (node[k].y >> 24) == 255u;
+            all_at_leaf &= __ballot(leaf);
+            if (STATS) depth += at[k] != rest ? 1 : 0;
+            sum += leaf ? __uint_as_float(node[k].x) : 0.0f;             // (a small integer: exact in any order)
+            uint32_t next;                                                // (child + right) x 8, the variable shifted out
+            // of a leaf: on to the root of the next tree of the chain (its "left child")
+            const bool left = leaf | (val[k] <= __uint_as_float(node[k].x));
+            asm("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(next) : "v"(node[k].y), "v"(left ? 0u : 8u));
+            at[k] = next & 0x07ffffffu;
+        }
+        return all_at_leaf;
+    };
+    for (;;) {
+        // two steps per test (a resting walk stays at its leaf, so the second step's answer is enough): the test and the
+        // compiler's loop bookkeeping around it are 10 instructions
+        unsigned long long all_at_leaf;
+        do {
+            step();
+            all_at_leaf = step();
+        } while (all_at_leaf != every_lane);
+        bool walking = false;
+#pragma unroll
+        for (int k = 0; k < WAYS; ++k) walking |= at[k] != rest;
         if (!__any(walking)) break;
     }
     return (int)sum;
@@ -1942,7 +2043,7 @@ __global__ __launch_bounds__(1024) void forest_kernel(Batch b, int maxF, int nld
                 fsum = forest_sum_deep<STATS>(a.forest, lnodes, nlds, H + lane, depth);
             // trees out of step only where it pays (more trees than ways) and is exact (integer leaves)
             else if (a.forest.order_free && a.forest.ntrees > kTreeWays)
-                fsum = (float)forest_sum_any_order<STATS, kTreeWays, false>(a.forest, lnodes, nlds, H + lane, kLanes, F, 0, 1, true, depth);
+                fsum = (float)forest_sum_any_order<STATS, kTreeWays>(a.forest, lnodes, nlds, H + lane, kLanes, F, 0, 1, true, depth);
             else
                 fsum = forest_sum<STATS>(a.forest, lnodes, nlds, H + lane, F, depth);
             score = 1 - (fsum / (a.forest.ntrees * 1.0f));                         // hpp:287
@@ -2042,21 +2143,20 @@ __global__ __launch_bounds__(1024) void forest_pair_kernel(Batch b, int maxF, in
 }
 
 // The forest kernel for a large histogram and many trees whose sum is exact in any order (config 5:
-// F = 80, 100 trees, 16 MB of nodes): 64 / G points per wave, G lanes per point, lane g of a point
-// walks the trees g, g + G, ... and the G partial sums are added at the end.  The F x 64 floats of a
-// whole wave of points (20 KB at F = 80) leave room for 4 waves per CU next to the node cache -- one
-// per SIMD, and every step of the walk waits for a node from beyond the L2; with G = 4 the slice of a
+// F = 80, 100 trees, 16 MB of nodes; the forest in the chained layout of forest.h): 64 / G points per wave, G lanes
+// per point, lane g of a point walks the chains g, g + G, ... (forest_sum_chained) and the G partial sums are added at
+// the end.  The F x 64 floats of a whole wave of points (20 KB at F = 80) leave room for 4 waves per CU next to the node
+// cache -- one per SIMD, and every step of the walk waits for a node from beyond the L2; with G = 4 the slice of a
 // wave is 5 KB and 16 waves fit.
-// Few walks per lane there: the kernel is bound by VALU issue (0.85 busy at 10 walks per lane, of which
-// under half were on live trees: a lane has only trees / G trees to keep its walks busy).
 
-template <bool STATS, int kSplitWays>
+template <bool STATS>
 __global__ __launch_bounds__(1024) void forest_split_kernel(Batch b, int maxF, int nlds_cap, int G) {
     extern __shared__ uint2 lnodes[];
     const ViewDev &a = b.view[blockIdx.y];
     const int lane = threadIdx.x & (kLanes - 1), wid = threadIdx.x / kLanes, nwaves = blockDim.x / kLanes;
     const int ppw = kLanes / G, p = lane % ppw, g = lane / ppw;
     const int nlds = min(nlds_cap, a.forest.ntop);        // the top part, or as much of it as fits
+    if (lds_address(reinterpret_cast<const float *>(lnodes)) != 0) __builtin_trap();      // fetch_nodes_masked relies on it
     for (int i = threadIdx.x; i < nlds; i += blockDim.x) lnodes[i] = a.forest.nodes[i];
     __syncthreads();
     float *H = reinterpret_cast<float *>(lnodes + nlds_cap) + (size_t)wid * maxF * ppw;
@@ -2078,8 +2178,8 @@ __global__ __launch_bounds__(1024) void forest_split_kernel(Batch b, int maxF, i
         wave_lds_fence();
         int depth = 0;
         int sum = nlds < a.forest.nnodes
-                      ? forest_sum_any_order<STATS, kSplitWays, true>(a.forest, lnodes, nlds, H + p, ppw, F, g, G, scoreable, depth)
-                      : forest_sum_any_order<STATS, kSplitWays, false>(a.forest, lnodes, nlds, H + p, ppw, F, g, G, scoreable, depth);
+                      ? forest_sum_chained<STATS, true>(a.forest, lnodes, nlds, H + p, ppw, F, g, G, scoreable, depth)
+                      : forest_sum_chained<STATS, false>(a.forest, lnodes, nlds, H + p, ppw, F, g, G, scoreable, depth);
         for (int off = ppw; off < kLanes; off <<= 1) {
             sum += __shfl_xor(sum, off);
             if (STATS) depth += __shfl_xor(depth, off);
@@ -3005,12 +3105,16 @@ void launch_forest_stage(const Batch &b, hipStream_t st) {
         any_order &= b.view[v].forest.order_free != 0;
         stats |= b.view[v].stats != nullptr;
     }
-    // several lanes per point (forest_split_kernel) when every forest of the batch may be summed in any
-    // order, has trees to share out, and a whole wave of histograms would crowd the waves out of LDS
-    // (lanes per point x walks per lane -> forest kernel ms on config 5, 1 M points, 100 trees: 4 x 3 1.57, 4 x 2
-    // 1.63, 4 x 5 1.78, 8 x 3 1.74, 8 x 5 2.07, 2 x 3 2.08, 2 x 5 2.13; one lane per point with 10 walks 2.15)
-    constexpr int G = 4, kSplitWays = 3;
-    if (any_order && min_trees >= 40 && sizeof(float) * (size_t)maxF * kLanes >= 8192) {
+    // several lanes per point (forest_split_kernel) when every forest of the batch is chained (forest.h: its sum is exact in
+    // any order, it has trees to share out -- >= 40 --, and a whole wave of its histograms -- F >= 32 -- would crowd the
+    // waves out of LDS).  Lanes per point x walks per lane -> forest kernel ms on config 5 (1 M points, 100 trees), with the
+    // tree queue of round 2: 4 x 3 1.57, 4 x 2 1.63, 4 x 5 1.78, 8 x 3 1.74, 8 x 5 2.07, 2 x 3 2.08, 2 x 5 2.13, one lane
+    // per point with 10 walks 2.15; chained: 4 x 3 1.02, 4 x 4 0.94, 4 x 5 0.97, 4 x 6 0.99 (profiles/r03_notes.md)
+    constexpr int G = 4;
+    int chain = b.view[0].forest.chain;
+    for (int v = 0; v < b.nviews; ++v) chain = b.view[v].forest.chain == chain ? chain : 0;
+    const int ways = chain / G;
+    if (any_order && ways == kChainWays && chain == ways * G) {
         const size_t slice = sizeof(float) * (size_t)maxF * (kLanes / G);
         size_t node_bytes = sizeof(uint2) * (size_t)max_nodes;
         if (node_bytes > kForestNodeBytes) node_bytes = kForestNodeBytes;
@@ -3022,8 +3126,8 @@ void launch_forest_stage(const Batch &b, hipStream_t st) {
         const int wgs_max = div_up(div_up(n, kLanes / G), (int)w);
         if (wgs > wgs_max) wgs = wgs_max;
         const dim3 sgrid(wgs, b.nviews);
-        if (stats) forest_split_kernel<true, kSplitWays><<<sgrid, (int)w * kLanes, lds, st>>>(b, maxF, nlds_cap, G);
-        else forest_split_kernel<false, kSplitWays><<<sgrid, (int)w * kLanes, lds, st>>>(b, maxF, nlds_cap, G);
+        if (stats) forest_split_kernel<true><<<sgrid, (int)w * kLanes, lds, st>>>(b, maxF, nlds_cap, G);
+        else forest_split_kernel<false><<<sgrid, (int)w * kLanes, lds, st>>>(b, maxF, nlds_cap, G);
         return;
     }
     // small order-free forests that fit the LDS whole: two lanes per point (forest_pair_kernel)

@@ -390,14 +390,16 @@ def test_fractional_leaf_values_are_summed_in_tree_order(kpl, oracle, cases, ntr
     (5, 6, 10, 5000, 25, "forest_sum_deep: top part in LDS, then whole blocks, trees in step"),
     (5, 6, 60, 1500, 20, "forest_sum_deep, more trees than ways"),
     (5, 6, 3, 40000, 28, "forest_sum_deep, chains of blocks"),
-    (8, 10, 50, 100, 12, "forest_split_kernel, forest entirely in LDS: every lane's walks out of step"),
-    (8, 10, 64, 1200, 22, "forest_split_kernel with blocks: out of step, deep nodes one by one"),
+    (8, 10, 50, 100, 12, "forest_split_kernel, chained forest entirely in LDS"),
+    (8, 10, 64, 1200, 22, "forest_split_kernel, chained forest beyond the LDS: deep nodes by exec-masked loads"),
+    (8, 10, 41, 700, 20, "forest_split_kernel, chains of unequal length (41 trees over 16 chains)"),
+    (8, 4, 47, 900, 24, "forest_split_kernel, F = 32 (the smallest chained forest), 47 trees"),
     (5, 6, 40, 150, 12, "forest_kernel, entirely in LDS, more trees than ways: out of step"),
 ])
 def test_every_forest_walker(kpl, oracle, cases, A, B, ntrees, nodes_per_tree, max_depth, walker):
     """Class-label forests (integer leaf values, what the reference trains) of the shapes that take the
-    different walks of kernels.hip: entirely in LDS or with 8-slot blocks below the top part (forest.h), one
-    lane or four lanes per point."""
+    different walks of kernels.hip: entirely in LDS, with 8-slot blocks below the top part or chained (forest.h),
+    one lane or four lanes per point."""
     from tools import synth
     xyz, nrm = cases.cloud()
     mr = cases.resolution()
@@ -445,3 +447,55 @@ def test_pinned_host_staging_path(kpl, oracle, cases):
     det.hostStaging(0)
     kp, kps = det.computeStaged()
     assert len(kp) == 0
+
+
+def test_chained_forest_in_a_batch_with_a_tree_order_forest(kpl, oracle, cases):
+    """Two views in ONE batch: one with a chained forest (64 trees, F = 80: level-major throughout, leaf records
+    linked -- forest.h), one whose forest has fractional leaf values (trees in order).  The batch cannot take the
+    chained kernel, so the chained layout goes through forest_kernel's walk_deep (no blocks: every level node by node);
+    alone, the chained view takes forest_split_kernel.  Same scores and keypoints either way."""
+    import copy
+    import torch
+    from tools import synth
+    A, B = 8, 10
+    xyz, nrm = cases.cloud()
+    mr = cases.resolution()
+    r, rn, thr = float(np.float32(6 * mr)), float(np.float32(4 * mr)), float(np.float32(0.4))
+    feat = oracle.Grid(xyz, r).features(nrm, A, B, r, np.arange(0, len(xyz), 5, dtype=np.int32))
+    chained = synth.random_forest(A * B, ntrees=64, max_depth=22, seed=17, target_nodes_per_tree=1200, feat=feat)
+    ordered = copy.deepcopy(synth.random_forest(A * B, ntrees=12, max_depth=16, seed=19, target_nodes_per_tree=1500, feat=feat))
+    value = np.asarray(ordered.value, dtype=np.float64).copy()
+    leaves = np.asarray(ordered.var) < 0
+    value[leaves] = np.random.default_rng(7).uniform(-2.0, 2.0, size=int(leaves.sum())).astype(np.float32).astype(np.float64)
+    ordered.value = value
+    dev = torch.device("cuda", 0)
+    dets, bufs, want = [], [], []
+    for fa in (chained, ordered):
+        det = make_det(kpl, A, B, r, rn, thr, fa)
+        n = len(xyz)
+        dx, dn = torch.from_numpy(xyz.copy()).to(dev), torch.from_numpy(nrm.copy()).to(dev)
+        ds = torch.empty(n, dtype=torch.float32, device=dev)
+        dk = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+        det.bindCloudDevice(dx.data_ptr(), 12, dn.data_ptr(), 12, n)
+        dets.append(det)
+        bufs.append((dx, dn, ds, dk))
+        want.append(oracle.detect(xyz, nrm, A, B, r, rn, thr, cases.oracle_forest(fa)))
+    st = torch.cuda.Stream()
+
+    def check(which):
+        st.synchronize()
+        for k in which:
+            ds, dk = bufs[k][2], bufs[k][3]
+            assert dets[k].syncStatus(st.cuda_stream) == kpl.OK
+            assert cases.same_bits(ds.cpu().numpy(), want[k][0])
+            assert np.array_equal(dk[1:1 + int(dk[0].item())].cpu().numpy(), want[k][1])
+            ds.fill_(-1.0)
+            dk.zero_()
+
+    kpl.compute_batch_device(dets, [b[2].data_ptr() for b in bufs], [b[3][1:].data_ptr() for b in bufs],
+                             [len(b[2]) for b in bufs], [b[3][0:1].data_ptr() for b in bufs], st.cuda_stream)
+    check((0, 1))
+    kpl.compute_batch_device(dets[:1], [bufs[0][2].data_ptr()], [bufs[0][3][1:].data_ptr()], [len(bufs[0][2])],
+                             [bufs[0][3][0:1].data_ptr()], st.cuda_stream)
+    check((0,))
+    assert len(np.unique(want[0][0][np.isfinite(want[0][0])])) > 10 and len(np.unique(want[1][0][np.isfinite(want[1][0])])) > 10
