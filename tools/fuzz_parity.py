@@ -149,8 +149,10 @@ def main():
         nms, draws = bool(rng.random() < 0.85), bool(rng.random() < 0.4)
         srt = bool(rng.random() < 0.4)                 # neighbors in sorted (distance, index) order
         dthr = float(np.float32(mr * rng.uniform(0, 4)))
-        fa = synth.random_forest(A * B, ntrees=int(rng.integers(1, 14)), max_depth=int(rng.integers(1, 12)),
-                                 seed=int(rng.integers(1, 1 << 30)), target_nodes_per_tree=int(rng.integers(3, 400)))
+        many = rng.random() < 0.15                     # many trees: out-of-step walks; chained layout when A * B >= 32 (forest.h)
+        fa = synth.random_forest(A * B, ntrees=int(rng.integers(40, 90)) if many else int(rng.integers(1, 14)),
+                                 max_depth=int(rng.integers(1, 20 if many else 12)),
+                                 seed=int(rng.integers(1, 1 << 30)), target_nodes_per_tree=int(rng.integers(3, 1500 if many else 400)))
         if rng.random() < 0.5:                         # coarse leaf values: many exact score ties
             fa.value[:] = np.round(fa.value * 2) / 2
         det.setNAnnulus(A); det.setNBins(B); det.setNonMaxima(nms); det.setNonMaxRadius(rn)
