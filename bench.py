@@ -533,7 +533,7 @@ def main():
         xyz, nrm, mr = views[0]
         r_feat, r_nms = float(np.float32(6.0 * mr)), float(np.float32(4.0 * mr))
         reps_c, t_cpu = 0, 0.0
-        while t_cpu < 8.0 and reps_c < 8:
+        while t_cpu < 12.0 and reps_c < 32:        # ~12 s of single-thread work (the contract asks for 10-30 s)
             c0 = time.perf_counter()
             kplo.detect(xyz, nrm, A, B, r_feat, r_nms, thr, of, threads=1)
             t_cpu += time.perf_counter() - c0
