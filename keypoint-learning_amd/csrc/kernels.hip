@@ -2262,18 +2262,21 @@ __global__ __launch_bounds__(kLanes) void features_sorted_kernel(const float4 *_
 // detectKeypoints, hpp:197-256 with draws_remove == false (order-independent predicate):
 // keypoint <=> score >= thr (float promoted to double, hpp:207 -- tested by the forest kernel,
 // which appends the candidates to `cand`) and no neighbor within r_nms has a strictly greater
-// score (hpp:219).  16 lanes share one candidate.  The kernel is a chain of dependent loads, so
-// the chain is kept short: the 16 lanes fetch the ranges of the (<= 16) rows of cells of the search
-// box at once, the rows are then treated as ONE list of positions (prefix sums over the 16 lanes,
-// binary search per position), and the scores of four steps of 16 positions are requested together.
-// A position only matters if its score is greater (or, for the draws pass, equal): only then is its
-// point loaded and its distance tested -- rare, most candidates sit on score plateaus and survive.
-constexpr int kNmsGroup = 16;
-constexpr int kNmsAhead = 4;     // steps of 16 positions whose score loads are in flight together (8 measured the same)
+// score (hpp:219).  L lanes share one candidate and walk the rows of cells of its search box one after
+// the other, kNmsAhead positions per lane and step, scores first: a position only matters if its score is
+// greater (or, for the draws pass, equal) -- only then is its point loaded and its distance tested --, and the
+// group stops at the first greater neighbor inside the radius (most candidates are not maxima).
+// L is a choice between latency and work (launch_post): for one view alone on the GPU the kernel is a chain of
+// dependent loads -- 16 lanes, 8 when the view has so many candidates that the groups of 16 would need several rounds
+// (62 k points 0.020 ms; 500 k points at r_nms = 4 mr 0.030 ms); for a batch, where the other batch's kernels fill the GPU
+// anyway, what counts is the number of instructions -- 4 lanes (8 views of 200 k points, two batches in flight: 1 888 ->
+// 1 940 Mpoints/s; one lane per candidate: 1 946, but 64 views of 63 k points 1 380 instead of 1 445).  Until r03f
+// one kernel took 16 lanes per candidate and treated the rows as one list (prefix sums + a binary search per position
+// through ds_bpermute): 75 wave-instructions per candidate (profiles/r03_notes.md).
+constexpr int kNmsAhead = 4;     // positions per lane whose score loads are in flight together
 
-template <bool STATS>
-__global__ __launch_bounds__(256) void nms_kernel(Batch b) {
-    const ViewDev &v = b.view[blockIdx.y];
+template <bool STATS, int L>
+__device__ __forceinline__ void nms_scan(const ViewDev &v) {
     const float4 *__restrict__ pts = v.pts;
     const int *__restrict__ cell_start = v.cell_start;
     const NmsDesc nd = v.nd;
@@ -2285,90 +2288,65 @@ __global__ __launch_bounds__(256) void nms_kernel(Batch b) {
     const bool DRAWS = nd.draws_remove != 0;
     const GridDesc g = v.ds->grid;
     const int ncand = *cand.count;
-    const int lane = threadIdx.x & (kNmsGroup - 1);
-    const int wlane = threadIdx.x & (kWave - 1), gbase = wlane & ~(kNmsGroup - 1);
-    const int groups = gridDim.x * (blockDim.x / kNmsGroup);
     const int t_last = max(cell_start[g.ncells] - 1, 0);
-    for (int k0 = (blockIdx.x * blockDim.x + threadIdx.x) / kNmsGroup;; k0 += groups) {
-        const bool have = k0 < ncand;
-        if (!__any(have)) break;                      // (groups of a wave finish together: whole waves leave)
-        const int s = have ? cand.list[k0] : 0;
+    const int lane = threadIdx.x & (L - 1), gbase = (threadIdx.x & (kWave - 1)) & ~(L - 1);
+    const unsigned long long gmask = (1ull << L) - 1ull;
+    // (the lanes of a group take the same branches: a ballot inside these loops sees the whole group)
+    for (int k = (blockIdx.x * blockDim.x + threadIdx.x) / L; k < ncand; k += gridDim.x * (blockDim.x / L)) {
+        const int s = cand.list[k];
         const float si = score_sorted[s];
         const float4 p = pts[s];
         const CellBox bx = make_box(g, p.x, p.y, p.z, nd.rr);
-        // rows of the box in blocks of 4 x 4 (one block when r_nms <= the cell edge, the usual case);
-        // lane r of the group owns row r = (kz, ky) of the block
-        const int nyb = have ? bx.hi[1] - bx.lo[1] + 1 : 0, nzb = have ? bx.hi[2] - bx.lo[2] + 1 : 0;
-        int wny = max(nyb, __shfl_xor(nyb, 16)), wnz = max(nzb, __shfl_xor(nzb, 16));
-        wny = max(wny, __shfl_xor(wny, 32));
-        wnz = max(wnz, __shfl_xor(wnz, 32));
         bool greater = false, draw = false;
         int kn = 0;
-        for (int kz0 = 0; kz0 < wnz; kz0 += 4)
-        for (int ky0 = 0; ky0 < wny; ky0 += 4) {
-            const int ky = ky0 + (lane & 3), kz = kz0 + (lane >> 2);
-            const bool rvalid = ky < nyb && kz < nzb;
-            const int row = rvalid ? ((bx.lo[2] + kz) * g.dims[1] + bx.lo[1] + ky) * g.dims[0] : 0;
-            const int r0 = rvalid ? cell_start[row + bx.lo[0]] : 0;
-            const int r1 = rvalid ? cell_start[row + bx.hi[0] + 1] : 0;
-            const int len = r1 - r0;
-            int incl = len;                              // inclusive prefix over the 16 lanes of the group
-            for (int off = 1; off < kNmsGroup; off <<= 1) {
-                const int o = __shfl_up(incl, off, kNmsGroup);
-                if (lane >= off) incl += o;
-            }
-            const int total = __shfl(incl, gbase + kNmsGroup - 1);
-            int wtotal = total;                          // the longest list of the wave's 4 groups bounds the loop
-            wtotal = max(wtotal, __shfl_xor(wtotal, 16));
-            wtotal = max(wtotal, __shfl_xor(wtotal, 32));
-            for (int f0 = 0; f0 < wtotal; f0 += kNmsAhead * kNmsGroup) {
-                int t[kNmsAhead];
-                float sj[kNmsAhead];
-                bool in[kNmsAhead];
+        for (int cz = bx.lo[2]; cz <= bx.hi[2] && (STATS || !greater); ++cz)
+            for (int cy = bx.lo[1]; cy <= bx.hi[1] && (STATS || !greater); ++cy) {
+                const int row = (cz * g.dims[1] + cy) * g.dims[0];
+                const int r0 = cell_start[row + bx.lo[0]], r1 = cell_start[row + bx.hi[0] + 1];
+                for (int base = r0; base < r1 && (STATS || !greater); base += L * kNmsAhead) {
+                    const int t0 = base + lane * kNmsAhead;
+                    float sj[kNmsAhead];
 #pragma unroll
-                for (int a = 0; a < kNmsAhead; ++a) {
-                    const int f = f0 + a * kNmsGroup + lane;
-                    in[a] = f < total;
-                    // row of position f: the first row whose inclusive prefix exceeds f (binary search over 16 lanes)
-                    int lo = 0;
+                    for (int a = 0; a < kNmsAhead; ++a) sj[a] = score_sorted[min(t0 + a, t_last)];
+                    bool hit = false, tie = false;
 #pragma unroll
-                    for (int step = 8; step > 0; step >>= 1) {
-                        const int pre = __shfl(incl, gbase + lo + step - 1);
-                        lo += pre <= f ? step : 0;
+                    for (int a = 0; a < kNmsAhead; ++a) {
+                        const int t = t0 + a;
+                        const bool in = t < r1;
+                        const bool gt = in && si < sj[a];                                  // hpp:219
+                        const bool eq = DRAWS && in && si == sj[a] && t != s;              // hpp:224-229
+                        if (STATS ? in : (gt || eq)) {
+                            const float4 q = pts[t];
+                            const bool inside = dist2(p.x, p.y, p.z, q) < nd.r2;
+                            if (STATS) kn += inside;
+                            hit |= inside && gt;
+                            tie |= inside && eq;
+                        }
                     }
-                    lo = min(lo, kNmsGroup - 1);
-                    const int rincl = __shfl(incl, gbase + lo), rlen = __shfl(len, gbase + lo), rstart = __shfl(r0, gbase + lo);
-                    t[a] = in[a] ? rstart + (f - (rincl - rlen)) : t_last;
-                    sj[a] = score_sorted[min(max(t[a], 0), t_last)];
-                }
-#pragma unroll
-                for (int a = 0; a < kNmsAhead; ++a) {
-                    const bool gt = in[a] && si < sj[a];                                  // hpp:219
-                    const bool eq = DRAWS && in[a] && si == sj[a] && t[a] != s;           // hpp:224-229
-                    const bool need = STATS ? in[a] : (gt || eq);
-                    if (__any(need)) {
-                        const float4 q = pts[need ? t[a] : 0];
-                        const bool inside = need && dist2(p.x, p.y, p.z, q) < nd.r2;
-                        if (STATS) kn += inside;
-                        const unsigned long long hit = __ballot(inside && gt), tie = __ballot(inside && eq);
-                        if ((hit >> gbase) & 0xffffull) greater = true;
-                        if ((tie >> gbase) & 0xffffull) draw = true;
+                    if (L == 1) {
+                        greater |= hit;
+                        draw |= tie;
+                    } else {
+                        greater |= ((__ballot(hit) >> gbase) & gmask) != 0ull;
+                        if (DRAWS) draw |= ((__ballot(tie) >> gbase) & gmask) != 0ull;
                     }
                 }
-                if (!STATS && !__any(have && !greater)) break;
             }
-            if (!STATS && !__any(have && !greater)) break;
-        }
         if (STATS) {
-            for (int off = kNmsGroup / 2; off > 0; off >>= 1) kn += __shfl_xor(kn, off);
-            if (lane == 0 && have) {
-                atomicAdd(&stats->sum_kn, (unsigned long long)kn);
-                atomicAdd(&stats->n_thresholded, 1ull);
-            }
+            atomicAdd(&stats->sum_kn, (unsigned long long)kn);
+            if (lane == 0) atomicAdd(&stats->n_thresholded, 1ull);
         }
         // 1 = keypoint (hpp:252-253); 2 = maximum with draws, decided by draws_kernel (hpp:233-250)
-        if (lane == 0 && have && !greater) flags[__float_as_int(p.w)] = (DRAWS && draw) ? 2 : 1;
+        if (lane == 0 && !greater) flags[__float_as_int(p.w)] = (DRAWS && draw) ? 2 : 1;
     }
+}
+
+// L lanes per candidate, or LMANY when the view has more than `many` candidates (0 = never)
+template <bool STATS, int L, int LMANY>
+__global__ __launch_bounds__(256) void nms_kernel(Batch b, int many) {
+    const ViewDev &v = b.view[blockIdx.y];
+    if (LMANY != 0 && v.nd.non_maxima && *v.cand.count > many) nms_scan<STATS, LMANY == 0 ? L : LMANY>(v);
+    else nms_scan<STATS, L>(v);
 }
 
 // non_maxima_draws_remove == true, hpp:231-250: the order-dependent greedy pass over the maxima
@@ -3196,10 +3174,20 @@ void launch_post(const Batch &b, hipStream_t st) {
     ScanJobs jobs;
     jobs.zero_in = 0;
     if (n > 0 && nms) {
-        int blocks = div_up(n, 256 / kNmsGroup);        // at most one group per point ...
-        if (blocks > 1024) blocks = 1024;               // ... but a few waves per SIMD are plenty
-        if (stats) nms_kernel<true><<<dim3(blocks, nv), 256, 0, st>>>(b);
-        else nms_kernel<false><<<dim3(blocks, nv), 256, 0, st>>>(b);
+        // lanes per candidate: a batch is scored for throughput (4), a single view for latency (16, 8 when it has many candidates)
+        const int L = nv >= 2 ? 4 : 16;
+        int blocks = div_up(n, 256 / L);                // at most one group per point ...
+        const int most = nv >= 2 ? 128 : 2048;          // ... but a few waves per SIMD are plenty
+        if (blocks > most) blocks = most;
+        const dim3 grid(blocks, nv);
+        const int many = 5 * blocks * (256 / 16) / 4;   // more candidates than the groups of 16 take in about one round
+        if (nv >= 2) {
+            if (stats) nms_kernel<true, 4, 0><<<grid, 256, 0, st>>>(b, 0);
+            else nms_kernel<false, 4, 0><<<grid, 256, 0, st>>>(b, 0);
+        } else {
+            if (stats) nms_kernel<true, 16, 8><<<grid, 256, 0, st>>>(b, many);
+            else nms_kernel<false, 16, 8><<<grid, 256, 0, st>>>(b, many);
+        }
         if (draws) {
             jobs.match = 2;
             for (int v = 0; v < nv; ++v) {
