@@ -123,6 +123,7 @@ static_assert(sizeof(Batch) <= 4096, "a Batch travels as kernel arguments: 4 KB 
 constexpr int kStatusOk = 0, kStatusGridTooLarge = 1, kStatusCellCapacity = 2, kStatusBadOrigin = 3;
 constexpr long long kMaxGridCells = 1ll << 28;
 constexpr int kBuckets = 1024;   // buckets of the index sort (kernels.hip "Index build")
+constexpr int kDrawRounds = 24;      // parallel rounds of the draws pass before the sequential rest (kernels.hip)
 struct DevState {
     GridDesc grid;        // written by grid_setup_kernel, read by every later kernel
     int status;           // kStatus*: on failure the grid is empty and kp_count becomes -1
@@ -130,6 +131,7 @@ struct DevState {
     int bshift, nbuckets; // index sort: nbuckets buckets of 2^bshift consecutive cells
     uint32_t bbox[6];     // order-preserving encoded min / max accumulators (self re-arming)
     uint32_t scan_epoch;  // tag of the next detect call in the words of scan_state (advanced on the device, never 0)
+    int draws_left[kDrawRounds + 1];   // draws pass: [0] = listed maxima, [r + 1] = still undecided after round r (re-armed per call)
 };
 void init_dev_state(DevState *host_copy);
 
