@@ -174,6 +174,11 @@ def main():
                      root=fa.root, var=fa.var, thrs=fa.thr, left=fa.left, right=fa.right, value=fa.value)
             print("MISMATCH case %d kind %d n %d A %d B %d r %g rn %g thr %g nms %d draws %d sorted %d -> fuzz_failure.npz"
                   % (cases, kind, n, A, B, r, rn, thr, nms, draws, srt))
+            kp = det.getKeypointsIndices()
+            print("  scores bit-exact %s; keypoints device %d oracle %d; only device %s only oracle %s; draws threshold %g; trees %d"
+                  % (helpers.same_bits(sc, o_sc), len(kp), len(o_kp), np.setdiff1d(kp, o_kp)[:8], np.setdiff1d(o_kp, kp)[:8], dthr, fa.ntrees))
+            _, sc2 = det.compute()
+            print("  the same call again: scores %s keypoints %s" % (helpers.same_bits(sc2, o_sc), np.array_equal(det.getKeypointsIndices(), o_kp)))
             return 1
         if rng.random() < 0.25 and n > 0:               # the preparation steps as well
             k = int(rng.integers(3, 33))
