@@ -242,6 +242,33 @@ def test_draws_remove_plateau_line(kpl, oracle, cases):
         assert det.getKeypointsIndices().tolist() == o_kp.tolist()
 
 
+@pytest.mark.parametrize("order", ["scan", "shuffled"])
+def test_draws_remove_on_a_constant_score_plane(kpl, oracle, cases, order):
+    """Every point a maximum with draws (a constant forest: one plateau over the whole view): the greedy pass is then a
+    chain through the list -- in scan order every entry waits for its left neighbor and for the row above, so the parallel
+    rounds of the draws pass decide a front at a time and the sequential rest takes the bulk; in shuffled order the
+    rounds take nearly all of it.  Same survivors as the reference's loop in both orders."""
+    from tools import synth
+    from tools.forest_yaml import ForestArrays
+    xyz, nrm = synth.make_cloud(120, 90, seed=31)
+    if order == "shuffled":
+        xyz, nrm = synth.shuffle_cloud(xyz, nrm, 77)
+    mr = oracle.cloud_resolution(xyz)
+    A, B = 5, 6
+    r, rn = float(np.float32(6 * mr)), float(np.float32(4 * mr))
+    fa = ForestArrays([0], [-1], [0.0], [-1], [-1], [0.0], A * B)         # one leaf: every score = 1
+    det = make_det(kpl, A, B, r, rn, 0.5, fa, draws_remove=True)
+    det.setInputCloud(xyz)
+    det.setNormals(nrm)
+    for dthr_mul in (1.5, 2.5, 4.0):
+        dthr = float(np.float32(dthr_mul * mr))
+        det.setNonMaximaDrawsThreshold(dthr)
+        det.compute()
+        _, o_kp = oracle.detect(xyz, nrm, A, B, r, rn, 0.5, cases.oracle_forest(fa), draws_remove=True, draws_threshold=dthr)
+        assert np.array_equal(det.getKeypointsIndices(), o_kp)
+        assert 0 < len(o_kp) < len(xyz) // 2
+
+
 def test_cloud_resolution_bit_exact(kpl, oracle, cases):
     """kpl_cloud_resolution = computeCloudResolution (point_cloud_utilities.hpp:120-151)."""
     det = kpl.KeypointLearningDetector()
