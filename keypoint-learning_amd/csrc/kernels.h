@@ -103,7 +103,7 @@ struct ViewDev {
     unsigned long long *scan_state;   // one word per 4096 flags: the single-pass scan of the compaction (kernels.hip)
     NmsList cand;                // points that passed the threshold
     // draws pass + compaction ("detectKeypoints")
-    int *draw_list, *draw_count, *skip;
+    int *draw_list, *draw_count, *skip;    // draw_list: [n] listed maxima, then [n] adjacency counts, then [n x kDrawAdj] adjacency (draws pass)
     int *kp_idx;
     float *kp_score;             // [kp_cap] forest response of each keypoint (may be null; needs `scores`)
     int kp_cap;
@@ -123,7 +123,8 @@ static_assert(sizeof(Batch) <= 4096, "a Batch travels as kernel arguments: 4 KB 
 constexpr int kStatusOk = 0, kStatusGridTooLarge = 1, kStatusCellCapacity = 2, kStatusBadOrigin = 3;
 constexpr long long kMaxGridCells = 1ll << 28;
 constexpr int kBuckets = 1024;   // buckets of the index sort (kernels.hip "Index build")
-constexpr int kDrawRounds = 24;      // parallel rounds of the draws pass before the sequential rest (kernels.hip)
+constexpr int kDrawRounds = 8;       // parallel rounds of the draws pass, before the adjacency pass and the sequential rest (kernels.hip)
+constexpr int kDrawAdj = 16;         // lower-index neighbors an entry of the draws pass keeps for the sequential rest
 struct DevState {
     GridDesc grid;        // written by grid_setup_kernel, read by every later kernel
     int status;           // kStatus*: on failure the grid is empty and kp_count becomes -1
@@ -131,7 +132,7 @@ struct DevState {
     int bshift, nbuckets; // index sort: nbuckets buckets of 2^bshift consecutive cells
     uint32_t bbox[6];     // order-preserving encoded min / max accumulators (self re-arming)
     uint32_t scan_epoch;  // tag of the next detect call in the words of scan_state (advanced on the device, never 0)
-    int draws_left[kDrawRounds + 1];   // draws pass: [0] = listed maxima, [r + 1] = still undecided after round r (re-armed per call)
+    int draws_left[kDrawRounds + 2];   // draws pass: [0] = listed maxima, [r + 1] = still undecided after round r, last: after the adjacency pass
 };
 void init_dev_state(DevState *host_copy);
 

@@ -2430,29 +2430,152 @@ __global__ __launch_bounds__(256) void draws_round_kernel(Batch b, int round) {
     }
 }
 
-// what the rounds left undecided, in index order, one wave per view
-__global__ __launch_bounds__(64) void draws_rest_kernel(Batch b) {
+// After the rounds: maxima in scan order along a plateau wait for their left neighbor and for the row above, one link of
+// such a chain per round.  What is left is done in two passes.  draws_adj_kernel, parallel: every entry that is still
+// undecided sweeps its neighborhood once more -- dropped if a lower-index neighbor is kept by now, decided if none of
+// them is undecided any more; otherwise it writes the LIST POSITIONS of the lower-index neighbors it waits for (at most
+// kDrawAdj; the count runs on beyond that) and whether it has a draw within the threshold at all.
+__global__ __launch_bounds__(256) void draws_adj_kernel(Batch b) {
     const ViewDev &v = b.view[blockIdx.y];
     if (!v.nd.draws_remove) return;
     DevState *ds = v.ds;
     if (ds->draws_left[kDrawRounds] == 0) return;
+    const NmsDesc nd = v.nd;
+    const float4 *__restrict__ pts = v.pts;
+    const int *__restrict__ cell_start = v.cell_start;
+    const float *__restrict__ score_sorted = v.score_sorted;
     const int count = *v.draw_count;
+    int *adjn = v.draw_list + v.n, *adj = v.draw_list + 2 * (size_t)v.n;
     const GridDesc g = ds->grid;
-    const int lane = threadIdx.x;
-    for (int k = 0; k < count; ++k) {
+    const int lane = threadIdx.x & (kDrawLanes - 1), gbase = (threadIdx.x & (kWave - 1)) & ~(kDrawLanes - 1);
+    const unsigned long long gmask = (1ull << kDrawLanes) - 1ull;
+    auto group_any = [&](bool x) { return ((__ballot(x) >> gbase) & gmask) != 0ull; };
+    for (int k = (blockIdx.x * blockDim.x + threadIdx.x) / kDrawLanes; k < count; k += gridDim.x * (blockDim.x / kDrawLanes)) {
         const int idx = v.draw_list[k];
         if (__hip_atomic_load(&v.skip[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kDrawUndecided) continue;
-        bool any_draw, lower_kept, lower_undecided;               // (every lower-index entry is decided by now)
-        draws_sweep<64>(v, g, idx, lane, any_draw, lower_kept, lower_undecided);
-        any_draw = __any(any_draw);
-        lower_kept = __any(lower_kept);
-        const bool kept = !lower_kept && any_draw;
-        if (lane == 0) {
-            v.flags[idx] = kept ? 1 : 0;
-            __hip_atomic_store(&v.skip[idx], kept ? kDrawKept : kDrawDropped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int s = v.pos_of[idx];
+        const float4 p = pts[s];
+        const float si = score_sorted[s];
+        const CellBox bx = make_box(g, p.x, p.y, p.z, nd.rr);
+        bool any_draw = false, lower_kept = false, pending = false;
+        for (int cz = bx.lo[2]; cz <= bx.hi[2]; ++cz)
+            for (int cy = bx.lo[1]; cy <= bx.hi[1]; ++cy) {
+                const int row = (cz * g.dims[1] + cy) * g.dims[0];
+                const int t0 = cell_start[row + bx.lo[0]], t1 = cell_start[row + bx.hi[0] + 1];
+                for (int t = t0 + lane; t < t1; t += kDrawLanes) {
+                    const float4 q = pts[t];
+                    if (t != s && dist2(p.x, p.y, p.z, q) < nd.r2 && si == score_sorted[t]) {
+                        const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;          // hpp:239, as in draws_sweep
+                        const float distance = sqrtf(dx * dx + (dy * dy + dz * dz));
+                        if (distance < nd.draws_thr) {                                      // hpp:240
+                            any_draw = true;
+                            const int qi = __float_as_int(q.w);
+                            if (qi < idx) {
+                                const int sq = __hip_atomic_load(&v.skip[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                lower_kept |= sq == kDrawKept;
+                                if (sq == kDrawUndecided) {
+                                    pending = true;
+                                    const int slot = atomicAdd(&adjn[k], 1);
+                                    if (slot < kDrawAdj) adj[(size_t)k * kDrawAdj + slot] = v.prefix[qi];   // its position in the list
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        any_draw = group_any(any_draw);
+        lower_kept = group_any(lower_kept);
+        pending = group_any(pending);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the group's appends, before lane 0 tags the count
+        if (lane != 0) continue;
+        if (lower_kept) {
+            v.flags[idx] = 0;
+            __hip_atomic_store(&v.skip[idx], kDrawDropped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (!pending) {
+            v.flags[idx] = any_draw ? 1 : 0;
+            __hip_atomic_store(&v.skip[idx], any_draw ? kDrawKept : kDrawDropped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (any_draw) atomicOr(&adjn[k], 1 << 30);
+            atomicAdd(&ds->draws_left[kDrawRounds + 1], 1);
         }
-        // the state (an agent-scope store, straight to L2) must have landed before the next entry's agent-scope loads
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+
+// ... and draws_rest_kernel, one wave per view, in index order: the states of all listed maxima as 2-bit fields in LDS,
+// the adjacency rows of 64 entries at a time through LDS; an entry costs two LDS round trips (its row, the states of its
+// neighbors -- all of them decided by then, they come first in the list) instead of a sweep through memory.  An
+// entry with more than kDrawAdj waiting neighbors takes the sweep (draws_sweep reads the states from skip[], which is
+// kept up to date).  lds_words = state words that fit (16 entries each); a longer list reads its states from skip[].
+__global__ __launch_bounds__(64) void draws_rest_kernel(Batch b, int lds_words) {
+    extern __shared__ uint32_t dlds[];
+    const ViewDev &v = b.view[blockIdx.y];
+    if (!v.nd.draws_remove) return;
+    DevState *ds = v.ds;
+    if (ds->draws_left[kDrawRounds + 1] == 0) return;
+    const int count = *v.draw_count;
+    const int *list = v.draw_list, *adjn = v.draw_list + v.n, *adj = v.draw_list + 2 * (size_t)v.n;
+    const GridDesc g = ds->grid;
+    const int lane = threadIdx.x;
+    const int nwords = (count + 15) / 16;
+    const bool in_lds = nwords <= lds_words;
+    uint32_t *state = dlds;
+    int *rows = reinterpret_cast<int *>(dlds + lds_words);               // [64][kDrawAdj]
+    if (in_lds) {
+        for (int w = lane; w < nwords; w += 64) {
+            uint32_t word = 0u;
+            for (int e = 0; e < 16; ++e) {
+                const int k = w * 16 + e;
+                if (k < count) word |= (uint32_t)(v.skip[list[k]] & 3) << (2 * e);
+            }
+            state[w] = word;
+        }
+    }
+    wave_lds_fence();
+    auto state_of = [&](int pos) -> int {
+        if (in_lds) return (int)((state[pos >> 4] >> ((pos & 15) * 2)) & 3u);
+        return __hip_atomic_load(&v.skip[list[pos]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    const size_t adj_len = (size_t)v.n * kDrawAdj;
+    for (int k0 = 0; k0 < count; k0 += 64) {
+        const int kk = k0 + lane;
+        const int my_state = kk < count ? state_of(kk) : kDrawDropped;
+        unsigned long long todo = __ballot(my_state == kDrawUndecided);
+        if (todo == 0ull) continue;
+        const int my_idx = kk < count ? list[kk] : 0, my_n = kk < count ? adjn[kk] : 0;
+        wave_lds_fence();
+        for (int r = 0; r < kDrawAdj; ++r) {                             // the rows of the chunk, contiguous in memory
+            const size_t at = (size_t)k0 * kDrawAdj + (size_t)r * 64 + lane;
+            rows[r * 64 + lane] = at < adj_len ? adj[at] : 0;
+        }
+        wave_lds_fence();
+        while (todo != 0ull) {
+            const int j = __builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const int idx = __builtin_amdgcn_readlane(my_idx, j), nraw = __builtin_amdgcn_readlane(my_n, j);
+            const int n = nraw & 0xffffff;
+            bool any_draw = ((nraw >> 30) & 1) != 0, kept;
+            if (n > kDrawAdj) {                                          // more neighbors than the row holds: sweep
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (this wave's decisions must be in skip[])
+                bool a, lk, lu;
+                draws_sweep<64>(v, g, idx, lane, a, lk, lu);
+                any_draw = __any(a);
+                kept = __any(lk);
+            } else {
+                const int pos = lane < n ? rows[j * kDrawAdj + lane] : 0;
+                kept = __any(lane < n && state_of(pos) == kDrawKept);
+            }
+            const int decision = (!kept && any_draw) ? kDrawKept : kDrawDropped;
+            if (lane == 0) {
+                if (in_lds) {
+                    const int pos = k0 + j;
+                    state[pos >> 4] = (state[pos >> 4] & ~(3u << ((pos & 15) * 2))) | ((uint32_t)decision << ((pos & 15) * 2));
+                }
+                v.flags[idx] = decision == kDrawKept ? 1 : 0;                       // hpp:245-248
+                __hip_atomic_store(&v.skip[idx], decision, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (!in_lds) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wave_lds_fence();
+        }
     }
 }
 
@@ -2944,9 +3067,10 @@ __global__ __launch_bounds__(256) void list_match_kernel(Batch b, int match) {
     int *list = v.draw_list, *count = v.draw_count;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) *count = prefix[n];
-    if (i <= kDrawRounds) v.ds->draws_left[i] = i == 0 ? prefix[n] : 0;     // the draws pass of this call (draws_round_kernel)
+    if (i <= kDrawRounds + 1) v.ds->draws_left[i] = i == 0 ? prefix[n] : 0; // the draws pass of this call (draws_round_kernel)
     if (i < n && flags[i] == match) {
         list[prefix[i]] = i;
+        list[n + prefix[i]] = 0;                                              // adjacency count (draws_adj_kernel)
         v.skip[i] = 3;                                                        // kDrawUndecided
     }
 }
@@ -3250,7 +3374,10 @@ void launch_post(const Batch &b, hipStream_t st) {
             int dblocks = div_up(n, 256 / kDrawLanes);
             if (dblocks > 256) dblocks = 256;
             for (int r = 0; r < kDrawRounds; ++r) draws_round_kernel<<<dim3(dblocks, nv), 256, 0, st>>>(b, r);
-            draws_rest_kernel<<<dim3(1, nv), 64, 0, st>>>(b);
+            draws_adj_kernel<<<dim3(dblocks, nv), 256, 0, st>>>(b);
+            int lds_words = div_up(n, 16);                                    // 2 bits of state per listed maximum
+            if (lds_words > 36 * 1024) lds_words = 36 * 1024;                 // 144 KB
+            draws_rest_kernel<<<dim3(1, nv), 64, sizeof(uint32_t) * (size_t)lds_words + sizeof(int) * 64 * kDrawAdj, st>>>(b, lds_words);
         }
     }
     compact_scan_kernel<<<dim3(n > 0 ? div_up(n, kScanChunk) : 1, nv), kScanBlock, 0, st>>>(b);
