@@ -124,7 +124,7 @@ constexpr int kStatusOk = 0, kStatusGridTooLarge = 1, kStatusCellCapacity = 2, k
 constexpr long long kMaxGridCells = 1ll << 28;
 constexpr int kBuckets = 1024;   // buckets of the index sort (kernels.hip "Index build")
 constexpr int kDrawRounds = 8;       // parallel rounds of the draws pass, before the adjacency pass and the sequential rest (kernels.hip)
-constexpr int kDrawAdj = 16;         // lower-index neighbors an entry of the draws pass keeps for the sequential rest
+constexpr int kDrawAdj = 32;         // lower-index neighbors an entry of the draws pass keeps for the sequential rest
 struct DevState {
     GridDesc grid;        // written by grid_setup_kernel, read by every later kernel
     int status;           // kStatus*: on failure the grid is empty and kp_count becomes -1

@@ -2548,7 +2548,45 @@ __global__ __launch_bounds__(64) void draws_rest_kernel(Batch b, int lds_words) 
             rows[r * 64 + lane] = at < adj_len ? adj[at] : 0;
         }
         wave_lds_fence();
-        while (todo != 0ull) {
+        const bool mine = my_state == kDrawUndecided;
+        const int n_mine = my_n & 0xffffff;
+        if (in_lds && !__any(mine && n_mine > kDrawAdj)) {
+            // the usual chunk: every lane walks the row of ITS entry once -- neighbors before the chunk are decided, their
+            // states are read now; neighbors inside the chunk become a 64-bit mask -- and the sequential part runs on
+            // scalars: an entry is dropped iff a neighbor before the chunk is kept or one inside it has been kept so far
+            bool kept_before = false;
+            unsigned long long inside = 0ull;
+            if (mine)
+                for (int q = 0; q < n_mine; ++q) {
+                    const int pos = rows[lane * kDrawAdj + q];
+                    if (pos >= k0) inside |= 1ull << (pos - k0);
+                    else kept_before |= state_of(pos) == kDrawKept;
+                }
+            const int may_keep = (mine && !kept_before && ((my_n >> 30) & 1)) ? 1 : 0;
+            const int in_lo = (int)(unsigned)inside, in_hi = (int)(unsigned)(inside >> 32);
+            unsigned long long kept_mask = __ballot(my_state == kDrawKept);
+            for (unsigned long long t = todo; t != 0ull; t &= t - 1ull) {
+                const int j = __builtin_ctzll(t);
+                const unsigned long long in_j = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(in_hi, j) << 32) |
+                                                (unsigned)__builtin_amdgcn_readlane(in_lo, j);
+                if (__builtin_amdgcn_readlane(may_keep, j) != 0 && (in_j & kept_mask) == 0ull) kept_mask |= 1ull << j;
+            }
+            const int final_state = mine ? (((kept_mask >> lane) & 1ull) ? kDrawKept : kDrawDropped) : my_state;
+            if (mine) {
+                v.flags[my_idx] = final_state == kDrawKept ? 1 : 0;                 // hpp:245-248
+                __hip_atomic_store(&v.skip[my_idx], final_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const unsigned long long b0 = __ballot((final_state & 1) != 0), b1 = __ballot((final_state & 2) != 0);
+            if (lane < 4 && (k0 >> 4) + lane < nwords) {                            // the chunk's four state words
+                const unsigned lo = (unsigned)(b0 >> (16 * lane)) & 0xffffu, hi = (unsigned)(b1 >> (16 * lane)) & 0xffffu;
+                uint32_t word = 0u;
+                for (int e = 0; e < 16; ++e) word |= (((lo >> e) & 1u) | (((hi >> e) & 1u) << 1)) << (2 * e);
+                state[(k0 >> 4) + lane] = word;
+            }
+            wave_lds_fence();
+            continue;
+        }
+        while (todo != 0ull) {                                           // a chunk with an entry that has to sweep: one by one
             const int j = __builtin_ctzll(todo);
             todo &= todo - 1ull;
             const int idx = __builtin_amdgcn_readlane(my_idx, j), nraw = __builtin_amdgcn_readlane(my_n, j);
