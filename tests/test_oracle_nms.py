@@ -69,6 +69,51 @@ def test_draw_removal_greedy(oracle):
     assert g.nms(s2, 1.5, 0.5, draws_remove=True, draws_threshold=0.5).tolist() == [1]
 
 
+def test_draw_removal_is_the_first_maximal_independent_set(oracle):
+    """The reference's loop over the maxima with draws (hpp:231-250: skip list, ascending index) restated as the rule the
+    device evaluates out of order (kernels.hip, draws pass): a listed maximum is dropped iff a listed maximum of LOWER index
+    that is itself not dropped has it within the draws threshold, and one without any draw within the threshold does not
+    survive either.  Random clouds with few score levels (many plateaus), both computed from scratch in numpy."""
+    rng = np.random.default_rng(2026)
+    for trial in range(12):
+        n = int(rng.integers(40, 400))
+        xyz = (rng.random((n, 3)) * np.array([12.0, 9.0, 1.0])).astype(np.float32)
+        s = (rng.integers(0, 4, size=n) / 4.0).astype(np.float32)
+        r_nms = float(np.float32(rng.uniform(1.0, 2.5)))
+        dthr = float(np.float32(rng.uniform(0.3, 3.0)))
+        thr = 0.3
+        kp = oracle.Grid(xyz, r_nms).nms(s, r_nms, thr, draws_remove=True, draws_threshold=dthr)
+        # the same from the definition
+        d2 = np.zeros((n, n), np.float32)
+        for k in range(3):                                   # FLANN's L2_Simple order: ((dx*dx) + dy*dy) + dz*dz
+            dk = xyz[:, None, k] - xyz[None, :, k]
+            d2 = d2 + dk * dk
+        near = d2 < np.float32(r_nms) * np.float32(r_nms)
+        np.fill_diagonal(near, False)
+        cand = s.astype(np.float64) >= thr
+        is_max = cand & ~np.array([np.any(near[i] & (s > s[i])) for i in range(n)])
+        draw = near & (s[:, None] == s[None, :])
+        listed = is_max & draw.any(axis=1)
+        dx, dy, dz = (xyz[:, None, k] - xyz[None, :, k] for k in range(3))
+        dist = np.sqrt(dx * dx + (dy * dy + dz * dz))        # hpp:239 (a - b).norm()
+        within = draw & (dist < np.float32(dthr))
+        dropped = np.zeros(n, bool)
+        keep = []
+        for i in range(n):                                   # ascending index = the reference's order
+            if is_max[i] and not listed[i]:
+                keep.append(i)                               # a strict maximum without draws
+            if not listed[i]:
+                continue
+            lower = np.nonzero(within[i, :i] & listed[:i] & ~dropped[:i])[0]
+            lower = [j for j in lower if within[j].any()]    # j itself survived (it has a draw within the threshold: i)
+            dropped[i] = len(lower) > 0
+            if not dropped[i] and within[i].any():
+                keep.append(i)
+            elif not dropped[i]:
+                dropped[i] = True                            # no draw within the threshold: does not survive, marks nobody
+        assert kp.tolist() == sorted(keep), (trial, n, r_nms, dthr)
+
+
 def test_committed_fixture_end_to_end(oracle, cases):
     from tools import forest_yaml
     z = np.load(os.path.join(GOLD, "small_case.npz"))
