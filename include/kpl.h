@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define KPL_VERSION 130
+#define KPL_VERSION 140
 
 typedef enum kpl_status {
     KPL_OK = 0,
@@ -45,8 +45,11 @@ typedef enum kpl_status {
     KPL_ERR_UNSUPPORTED = 8,   /* k-search mode, surface != input, > 255 features ...          */
     KPL_ERR_IO = 9,            /* file cannot be read                                          */
     KPL_ERR_NO_CLOUD = 10,     /* compute before a cloud was bound                             */
-    KPL_ERR_RETRY = 11         /* kpl_sync_status: the view needed larger cell tables; they have
+    KPL_ERR_RETRY = 11,        /* kpl_sync_status: the view needed larger cell tables; they have
                                   been grown, enqueue the same call again                      */
+    KPL_ERR_INTERNAL = 12      /* a device-side consistency check failed (the look-back of the
+                                  compaction's scan timed out): the results of the call are
+                                  invalid, *d_kp_count is -1 or unspecified; call again         */
 } kpl_status;
 
 typedef struct kpl_detector kpl_detector;

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KPL_LIB_PATH") or os.path.join(_HERE, "libkpl.so")
 
 OK, ERR_INVALID_ARG, ERR_NO_FOREST, ERR_FOREST_PARSE, ERR_VAR_COUNT, ERR_GRID_TOO_LARGE, \
-    ERR_CAPACITY, ERR_DEVICE, ERR_UNSUPPORTED, ERR_IO, ERR_NO_CLOUD, ERR_RETRY = range(12)
+    ERR_CAPACITY, ERR_DEVICE, ERR_UNSUPPORTED, ERR_IO, ERR_NO_CLOUD, ERR_RETRY, ERR_INTERNAL = range(13)
 
 
 NEIGHBORS_CANONICAL, NEIGHBORS_SORTED = 0, 1      # kpl_params.neighbor_order

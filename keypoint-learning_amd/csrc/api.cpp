@@ -10,6 +10,8 @@
 
 #include <cmath>
 #include <cstdarg>
+#include <cstddef>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -323,6 +325,13 @@ int sync_status(kpl_detector *h, hipStream_t st) {
         return fail(h, KPL_ERR_GRID_TOO_LARGE, "bounding box / radius needs more than 2^28 grid cells");
     if (h->h_state->status == kStatusBadOrigin)
         return fail(h, KPL_ERR_INVALID_ARG, "the grid origin (kpl_set_grid_origin) exceeds the minimum of the view");
+    if (h->h_state->scan_fail != 0) {
+        // a workgroup of the compaction's single-pass scan never saw its predecessors publish (kernels.hip,
+        // compact_scan_kernel): the keypoint list of that call is invalid.  Cleared here so that the next call starts clean
+        KPL_HIP(h, hipMemsetAsync((char *)h->dstate.p + offsetof(DevState, scan_fail), 0, sizeof(int), st));
+        KPL_HIP(h, hipStreamSynchronize(st));
+        return fail(h, KPL_ERR_INTERNAL, "keypoint compaction: the look-back of the single-pass scan timed out (call again)");
+    }
     if (h->h_state->status == kStatusCellCapacity) {
         const int64_t need = h->h_state->ncells_needed;
         h->index_valid = false;
@@ -609,6 +618,7 @@ const char *kpl_status_string(int s) {
         case KPL_ERR_IO: return "i/o error";
         case KPL_ERR_NO_CLOUD: return "no cloud bound";
         case KPL_ERR_RETRY: return "cell tables grown, call again";
+        case KPL_ERR_INTERNAL: return "internal error on the device (result invalid)";
         default: return "unknown status";
     }
 }
@@ -645,6 +655,7 @@ int kpl_create(kpl_detector **out, int device) {
         return KPL_ERR_DEVICE;
     }
     init_dev_state(h->h_state);
+    if (const char *e = getenv("KPL_DEBUG_SCAN_POLL_LIMIT")) set_scan_poll_limit(atoi(e));      // tests: force the scan's failure path
     if (hipMemcpy(h->dstate.p, h->h_state, sizeof(DevState), hipMemcpyHostToDevice) != hipSuccess) {
         kpl_destroy(h);
         return KPL_ERR_DEVICE;

@@ -132,9 +132,13 @@ struct DevState {
     int bshift, nbuckets; // index sort: nbuckets buckets of 2^bshift consecutive cells
     uint32_t bbox[6];     // order-preserving encoded min / max accumulators (self re-arming)
     uint32_t scan_epoch;  // tag of the next detect call in the words of scan_state (advanced on the device, never 0)
+    int scan_fail;        // set by a block of compact_scan_kernel whose look-back gave up: the call failed (kpl_sync_status -> KPL_ERR_INTERNAL, which clears it)
     int draws_left[kDrawRounds + 2];   // draws pass: [0] = listed maxima, [r + 1] = still undecided after round r, last: after the adjacency pass
 };
 void init_dev_state(DevState *host_copy);
+// look-back polls of the compaction's single-pass scan before the call is failed (default 2^22; < 0: every block but the
+// first gives up at once -- the failure path, forced by tests through KPL_DEBUG_SCAN_POLL_LIMIT)
+void set_scan_poll_limit(int polls);
 
 // ---- the three stages of compute(), each over every view of the batch ------------------------
 // index build ("initCompute"): needs the input + index fields of ViewDev

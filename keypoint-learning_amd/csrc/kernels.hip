@@ -2998,7 +2998,7 @@ __device__ __forceinline__ void scan_publish(unsigned long long *word, unsigned 
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ __launch_bounds__(kScanBlock) void compact_scan_kernel(Batch b) {
+__global__ __launch_bounds__(kScanBlock) void compact_scan_kernel(Batch b, int poll_limit) {
     const ViewDev &v = b.view[blockIdx.y];
     const int n = v.n, kp_cap = v.kp_cap;
     const int nb = n > 0 ? (n + kScanChunk - 1) / kScanChunk : 1;      // blocks of this view (block 0 exists for an empty view too)
@@ -3007,8 +3007,9 @@ __global__ __launch_bounds__(kScanBlock) void compact_scan_kernel(Batch b) {
     int *skip = v.nd.draws_remove ? v.skip : nullptr;
     unsigned long long *state = v.scan_state;
     // the tag of this call lives ON THE DEVICE (DevState, advanced by the last block below): a call that is replayed from a
-    // captured hipGraph gets a fresh tag every time, which a tag passed as a kernel argument would not
-    const unsigned epoch = v.ds->scan_epoch;
+    // captured hipGraph gets a fresh tag every time, which a tag passed as a kernel argument would not.  Read ONCE, as an
+    // atomic load: the last block rewrites the field while earlier blocks may still be in their look-back
+    const unsigned epoch = __hip_atomic_load(&v.ds->scan_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int base = blockIdx.x * kScanChunk + threadIdx.x * kScanPerThread;
     int f[kScanPerThread];
     int s = 0;
@@ -3040,7 +3041,8 @@ __global__ __launch_bounds__(kScanBlock) void compact_scan_kernel(Batch b) {
         const int lane = threadIdx.x;
         if (lane == 0) scan_publish(&state[blockIdx.x], epoch, blockIdx.x == 0 ? kScanPrefix : kScanAggregate, (unsigned)total);
         int before = 0;
-        for (int top = (int)blockIdx.x - 1; top >= 0;) {     // blocks top, top - 1, ... top - 63
+        bool timed_out = poll_limit < 0 && blockIdx.x != 0;  // (poll_limit < 0: the failure path forced by a test)
+        for (int top = (int)blockIdx.x - 1; top >= 0 && !timed_out;) {     // blocks top, top - 1, ... top - 63
             const int j = top - lane;
             unsigned long long w = 0ull;
             bool ready;
@@ -3061,33 +3063,42 @@ __global__ __launch_bounds__(kScanBlock) void compact_scan_kernel(Batch b) {
                     top = pref ? -1 : top - kWave;
                     break;
                 }
-                if (++polls > (1 << 22)) {                   // (never seen; a wrong count is better than a hung device)
-                    before = -(1 << 29);
-                    top = -1;
+                if (++polls > poll_limit) {                  // (never seen.  Liveness rests on the dispatch order of the
+                    timed_out = true;                        // workgroups; if that ever fails the call FAILS, it does not guess)
                     break;
                 }
                 __builtin_amdgcn_s_sleep(1);
             } while (true);
         }
+        if (timed_out) {
+            // the keypoint list of this view is not written from here on; the host sees the failure through
+            // DevState::scan_fail (kpl_sync_status -> KPL_ERR_INTERNAL) and, when the last block gets to see it, kp_count = -1.
+            // The word published for the blocks behind is well formed (a PREFIX of what is known: they must not wait forever)
+            before = 0;
+            if (lane == 0) __hip_atomic_store(&v.ds->scan_fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (lane == 0) {
-            if (blockIdx.x != 0) scan_publish(&state[blockIdx.x], epoch, kScanPrefix, (unsigned)(before + total));
-            carry = before;
+            if (blockIdx.x != 0) scan_publish(&state[blockIdx.x], epoch, kScanPrefix, (unsigned)(before + total) & 0x3fffffffu);
+            carry = timed_out ? -1 : before;
             if ((int)blockIdx.x == nb - 1) {                 // the last block knows the keypoint count
-                *v.kp_count = v.ds->status != 0 ? -1 : before + total;     // -1: see kpl_sync_status
+                const bool failed = v.ds->status != 0 || timed_out ||
+                                    __hip_atomic_load(&v.ds->scan_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                *v.kp_count = failed ? -1 : before + total;     // -1: see kpl_sync_status
                 *v.cand.count = 0;
                 // every block of this launch has published, hence started, hence read the tag: the next call's may be set
-                v.ds->scan_epoch = epoch + 1u == 0u ? 1u : epoch + 1u;
+                __hip_atomic_store(&v.ds->scan_epoch, epoch + 1u == 0u ? 1u : epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
     __syncthreads();
+    const bool scatter = carry >= 0;                         // (a block whose look-back failed writes nothing)
     int run = carry + excl;
 #pragma unroll
     for (int k = 0; k < kScanPerThread; ++k) {
         const int i = base + k;
         if (skip && i < n) skip[i] = 0;
         if (f[k] != 0) {
-            if (run < kp_cap) {
+            if (scatter && run >= 0 && run < kp_cap) {
                 v.kp_idx[run] = i;
                 if (v.kp_score) v.kp_score[run] = v.scores[i];     // (scores is set whenever kp_score is)
             }
@@ -3115,7 +3126,11 @@ __global__ __launch_bounds__(256) void list_match_kernel(Batch b, int match) {
 
 inline int div_up(int a, int b) { return (a + b - 1) / b; }
 
+int g_scan_poll_limit = 1 << 22;       // look-back polls of compact_scan_kernel before the call is failed (set_scan_poll_limit)
+
 }  // namespace
+
+void set_scan_poll_limit(int polls) { g_scan_poll_limit = polls; }
 
 // =============================================================================================
 // launch wrappers
@@ -3418,7 +3433,7 @@ void launch_post(const Batch &b, hipStream_t st) {
             draws_rest_kernel<<<dim3(1, nv), 64, sizeof(uint32_t) * (size_t)lds_words + sizeof(int) * 64 * kDrawAdj, st>>>(b, lds_words);
         }
     }
-    compact_scan_kernel<<<dim3(n > 0 ? div_up(n, kScanChunk) : 1, nv), kScanBlock, 0, st>>>(b);
+    compact_scan_kernel<<<dim3(n > 0 ? div_up(n, kScanChunk) : 1, nv), kScanBlock, 0, st>>>(b, g_scan_poll_limit);
 }
 
 size_t scan_state_bytes(int n) { return sizeof(unsigned long long) * ((size_t)(n > 0 ? n : 1) / kScanChunk + 2); }

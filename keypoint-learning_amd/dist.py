@@ -14,14 +14,15 @@ def shard(n_items, world, rank):
 
 
 def pack_keypoints(kp_idx, kp_count, cap):
-    """[cap + 1] int32: element 0 = count (clamped to cap), then the indices, zero padded.
-    `kp_idx` is the buffer kpl_detect_device wrote (length >= count), `kp_count` a 1-element
+    """[cap + 1] int32: element 0 = the TRUE count (not clamped: a count above cap tells the receiver that
+    the list was cut, a negative one that the call failed), then the first min(count, cap) indices, zero
+    padded.  `kp_idx` is the buffer kpl_detect_device wrote (length >= count), `kp_count` a 1-element
     tensor or an int.  Stays on the device of `kp_idx`; no host sync."""
     out = torch.zeros(cap + 1, dtype=torch.int32, device=kp_idx.device)
     if torch.is_tensor(kp_count):
-        out[0:1] = torch.clamp(kp_count.to(torch.int32).reshape(1), max=cap)
+        out[0:1] = kp_count.to(torch.int32).reshape(1)
     else:
-        out[0] = min(int(kp_count), cap)
+        out[0] = int(kp_count)
     n = min(cap, kp_idx.numel())
     out[1:1 + n] = kp_idx[:n]
     return out
@@ -39,12 +40,23 @@ def gather_keypoints(packed, group=None):
     return torch.stack(parts)
 
 
-def unpack_keypoints(gathered):
-    """[world, cap + 1] -> list of 1-D index tensors, one per rank (a count above cap means the
-    list was truncated to cap entries; a negative count means that rank's call failed)."""
+class KeypointListError(ValueError):
+    """A gathered keypoint list is unusable: cut at the packing capacity, or its call failed (count < 0)."""
+
+
+def unpack_keypoints(gathered, strict=True):
+    """[world, cap + 1] -> list of 1-D index tensors, one per row.  A count above cap means the list was cut to cap
+    entries, a negative count that the row's call failed: both raise KeypointListError unless strict=False (then the
+    cut list / an empty list is returned, as before)."""
     g = gathered.cpu()
     cap = g.shape[1] - 1
-    return [g[r, 1:1 + max(0, min(int(g[r, 0]), cap))].clone() for r in range(g.shape[0])]
+    counts = g[:, 0].tolist()
+    if strict:
+        bad = [(r, c) for r, c in enumerate(counts) if c < 0 or c > cap]
+        if bad:
+            raise KeypointListError("keypoint lists (row, count) %s do not fit the packing capacity %d or come from a failed call"
+                                    % (bad[:8], cap))
+    return [g[r, 1:1 + max(0, min(int(counts[r]), cap))].clone() for r in range(g.shape[0])]
 
 
 # ---- one large cloud over several GPUs (SURVEY.md 8(e), "single huge cloud"): slabs with a halo ----

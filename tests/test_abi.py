@@ -26,7 +26,7 @@ def test_header_symbols_are_exported_and_bound(kpl):
 
 def test_version_and_status_strings(kpl):
     lib = kpl.load_library()
-    assert lib.kpl_version() == 130
+    assert lib.kpl_version() == 140
     assert lib.kpl_status_string(0) == b"ok"
     assert b"forest" in lib.kpl_status_string(kpl.ERR_NO_FOREST)
 
