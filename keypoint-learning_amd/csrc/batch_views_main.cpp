@@ -22,9 +22,11 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -93,6 +95,36 @@ struct Worker {
 
 size_t slot_ints(int cap) { return (size_t)1 + 2 * (size_t)cap; }
 
+// The device threads agree on success BEFORE every collective: a thread that failed on the way (a KPL error on one view,
+// a second RETRY, a HIP error) must not leave the others waiting in ncclAllGather for a rank that never comes.
+// agree(ok) returns true iff every thread of the round said ok; all of them then skip or enter the collective together.
+class Rendezvous {
+  public:
+    explicit Rendezvous(int parties) : parties_(parties) {}
+    bool agree(bool ok) {
+        std::unique_lock<std::mutex> lock(m_);
+        all_ok_ = (arrived_ == 0 ? true : all_ok_) && ok;
+        const unsigned long gen = generation_;
+        if (++arrived_ == parties_) {
+            result_ = all_ok_;
+            arrived_ = 0;
+            ++generation_;
+            cv_.notify_all();
+            return result_;
+        }
+        cv_.wait(lock, [&] { return generation_ != gen; });
+        return result_;
+    }
+
+  private:
+    std::mutex m_;
+    std::condition_variable cv_;
+    const int parties_;
+    int arrived_ = 0;
+    unsigned long generation_ = 0;
+    bool all_ok_ = true, result_ = true;
+};
+
 int prepare(Worker &w, const Options &o) {
     CHECK_HIP(hipSetDevice(w.device));
     CHECK_HIP(hipStreamCreateWithFlags(&w.st[0], hipStreamNonBlocking));
@@ -145,8 +177,8 @@ int prepare(Worker &w, const Options &o) {
 }
 
 // one round: every view of this device scored (batches of up to 8, alternating streams), results written by the
-// engine straight into the packed send buffer, then the node-wide gather
-int score_and_gather(Worker &w, bool first) {
+// engine straight into the packed send buffer ...
+int score(Worker &w, bool first) {
     CHECK_HIP(hipSetDevice(w.device));
     const int nv = (int)w.views.size();
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -175,6 +207,13 @@ int score_and_gather(Worker &w, bool first) {
         if (!retry) break;
     }
     CHECK_HIP(hipStreamSynchronize(w.st[1]));                          // the gather is enqueued behind stream 0: wait for the other one
+    return 0;
+}
+
+// ... then the node-wide gather -- entered by every device thread or by none (Rendezvous)
+int score_and_gather(Worker &w, bool first, Rendezvous &rv) {
+    const int rc = score(w, first);
+    if (!rv.agree(rc == 0)) return rc ? rc : 1;                        // some device failed: nobody enters the collective
     CHECK_NCCL(ncclAllGather(w.d_send, w.d_recv, slot_ints(w.cap) * (size_t)w.slots, ncclInt32, w.comm, w.st[0]));
     CHECK_HIP(hipStreamSynchronize(w.st[0]));
     return 0;
@@ -237,9 +276,14 @@ int main(int argc, char **argv) {
     for (int d = 0; d < ndev; ++d) workers[(size_t)d].comm = comms[(size_t)d];
 
     // one host thread per device: prepare, one checked round, then the timed rounds
+    Rendezvous rv(ndev);
     auto body = [&](Worker &w) {
         w.rc = prepare(w, o);
-        if (!w.rc) w.rc = score_and_gather(w, true);
+        if (!rv.agree(w.rc == 0)) {                                    // a device could not be prepared: nobody scores
+            if (!w.rc) w.rc = 1;
+            return;
+        }
+        w.rc = score_and_gather(w, true, rv);
     };
     {
         std::vector<std::thread> th;
@@ -251,7 +295,8 @@ int main(int argc, char **argv) {
     if (o.rounds > 1) {
         auto timed = [&](Worker &w) {
             const auto t0 = std::chrono::steady_clock::now();
-            for (int r = 0; r < o.rounds && !w.rc; ++r) w.rc = score_and_gather(w, false);
+            // (a failed round fails on every device -- score_and_gather agrees first --, so all threads leave the loop together)
+            for (int r = 0; r < o.rounds && !w.rc; ++r) w.rc = score_and_gather(w, false, rv);
             w.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         };
         std::vector<std::thread> th;
@@ -290,11 +335,18 @@ int main(int argc, char **argv) {
         total_points += v.n;
         total_kp += nk;
     }
+    std::string per_device = "[";
+    for (const Worker &w : workers) {
+        char buf[64];
+        snprintf(buf, sizeof(buf), "%s%.4f", w.rank ? ", " : "", o.rounds > 1 ? w.seconds / o.rounds * 1e3 : 0.0);
+        per_device += buf;
+    }
+    per_device += "]";
     printf("{\"devices\": %d, \"views\": %zu, \"views_per_device\": %d, \"points\": %lld, \"keypoints\": %lld, "
            "\"exchange\": \"one ncclAllGather of %d x %zu int32 per round\", \"rounds\": %d, \"makespan_ms_per_round\": %.4f, "
-           "\"Mpoints_per_s\": %.2f}\n",
+           "\"device_ms_per_round\": %s, \"Mpoints_per_s\": %.2f}\n",
            ndev, views.size(), slots, total_points, total_kp, ndev * slots, slot_ints(cap), o.rounds, makespan * 1e3,
-           makespan > 0 ? total_points / makespan / 1e6 : 0.0);
+           per_device.c_str(), makespan > 0 ? total_points / makespan / 1e6 : 0.0);
     for (Worker &w : workers) {
         (void)hipSetDevice(w.device);
         for (View *v : w.views) { (void)hipFree(v->d_xyz); (void)hipFree(v->d_nrm); kpl_destroy(v->h); }

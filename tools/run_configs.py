@@ -3,7 +3,7 @@
 inputs, median of timed batches); the CPU columns are the oracle timed in the same process; parity
 (scores bit-exact + keypoint lists identical) is checked before any number is reported.
 
-    python tools/run_configs.py [cfg1 cfg2 cfg3 cfg4 cfg5]
+    python tools/run_configs.py [cfg0 cfg1 cfg2 cfg3 cfg4 cfg5]
 """
 import importlib
 import json
@@ -28,10 +28,11 @@ CFG_FOREST = os.path.join(ROOT, "data", "forests", "synth200k_a5b6_t10.yaml.gz")
 DEV = torch.device("cuda", 0)
 
 
-def make_detector(A, B, r, rn, thr, forest):
+def make_detector(A, B, r, rn, thr, forest, sorted_search=False):
     det = kpl.KeypointLearningDetector()
     det.setNAnnulus(A); det.setNBins(B); det.setNonMaxima(True); det.setNonMaxRadius(rn)
     det.setNonMaximaDrawsRemove(False); det.setPredictionThreshold(thr); det.setRadiusSearch(r)
+    det.setSortedSearch(sorted_search)
     if isinstance(forest, str):
         assert det.loadForest(forest), det.lastError()
     else:
@@ -133,6 +134,36 @@ def report(name, xyz, nrm, A, B, rmul_f, rmul_n, thr, forest, fa, extra=None):
     return row
 
 
+def cfg0():
+    """The reference's own default operating point (TestDetector with no options, main_test_detector.cpp:62-67, :105-106):
+    cheff001, 5 x 10, radiusFeatures 20 / radiusNMS 4 in the cloud's units (~30 / 6 mesh resolutions, K_f ~ 2 900), both
+    neighbor orders, checked against the committed oracle outputs (tests/golden/cheff001.npz)."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "cheff001.npz"))
+    forest = os.path.join(ROOT, "data", "forests", "cheff_a5b10_t10.yaml.gz")
+    fa = forest_yaml.load_forest(forest)
+    xyz, nrm = z["xyz"], z["nrm"]
+    r, rn, thr = float(z["r_feat"]), float(z["r_nms"]), float(z["thr"])
+    rows = {}
+    for order in ("canonical", "sorted"):
+        det = make_detector(5, 10, r, rn, thr, forest, sorted_search=order == "sorted")
+        mr = det.cloudResolution(xyz)
+        t, sc, kp, phases, st = time_gpu(det, xyz, nrm, reps=10, batch=3)
+        ok = bool(helpers.same_bits(sc, z["scores_" + order]) and np.array_equal(kp, z["kp_" + order]))
+        n = len(xyz)
+        b_feat = 24 * (st["n_scored"] + st["sum_kf"])
+        rows[order] = {"config": "cfg0 TestDetector defaults: cheff001, 5x10, r_feat 20 (%.1f mr), r_nms 4, %s order" % (r / mr, order),
+                       "N": n, "T": fa.ntrees, "nodes": int(fa.nnodes), "mr": round(mr, 5), "gpu_Mpts": round(n / t / 1e6, 2),
+                       "gpu_ms": round(t * 1e3, 4), "phases_ms": {k: round(v, 4) for k, v in phases.items()},
+                       "K_f": round(st["sum_kf"] / max(st["n_scored"], 1), 1), "keypoints": int(len(kp)),
+                       "feature_kernel_alg_GBps": round(b_feat / (phases["feature_ms"] * 1e-3) / 1e9, 1),
+                       "feature_kernel_frac_of_8TBps": round(b_feat / (phases["feature_ms"] * 1e-3) / 8e12, 4), "parity": ok}
+        print(json.dumps(rows[order]), flush=True)
+        assert ok, "PARITY FAILURE in cfg0 " + order
+    print(json.dumps({"config": "cfg0 sorted / canonical", "compute_ratio": round(rows["sorted"]["gpu_ms"] / rows["canonical"]["gpu_ms"], 3),
+                      "feature_kernel_ratio": round(rows["sorted"]["phases_ms"]["feature_ms"] / rows["canonical"]["phases_ms"]["feature_ms"], 3)}),
+          flush=True)
+
+
 def cfg1():
     z = np.load(os.path.join(ROOT, "tests", "golden", "cheff000.npz"))
     fa = forest_yaml.load_forest(CFG_FOREST)
@@ -227,6 +258,6 @@ def cfg5():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"]
+    which = sys.argv[1:] or ["cfg0", "cfg1", "cfg2", "cfg3", "cfg4", "cfg5"]
     for name in which:
         globals()[name]()
