@@ -75,6 +75,7 @@ struct kpl_detector {
     DevBuf dstate, cid, btable, cell_start, tmp_idx, scan_tmp, pts, nrm, pos_of;
     DevBuf score_sorted, flags, prefix, stats, out_scores, out_kp, out_count, cand_list, cand_count;
     DevBuf draw_list, draw_count, skip, feat, scan_state;
+    DevBuf large_list, seg_start, seg_len, sort_keys;      // sorted-search mode, large neighborhoods (kernels.hip)
     DevBuf org_scratch;           // kpl_estimate_normals_organized: change map, distance map, integral image
     int cells_cap = 0;            // capacity (cells) of cell_start
     DevState *h_state = nullptr;  // pinned copy of the device state (status read-back)
@@ -332,6 +333,16 @@ int sync_status(kpl_detector *h, hipStream_t st) {
         KPL_HIP(h, hipStreamSynchronize(st));
         return fail(h, KPL_ERR_INTERNAL, "keypoint compaction: the look-back of the single-pass scan timed out (call again)");
     }
+    if (h->h_state->status == kStatusKeyCapacity) {
+        // sorted-search mode: the neighbor keys of the points with large neighborhoods did not fit (kernels.hip)
+        const unsigned long long need = h->h_state->keys_needed;
+        if (need > 0xfffffff0ull)
+            return fail(h, KPL_ERR_CAPACITY, "sorted search: %llu neighbor keys in one view (limit 2^32)", need);
+        h->index_valid = false;
+        KPL_HIP(h, hipDeviceSynchronize());
+        KPL_HIP(h, h->sort_keys.ensure(sizeof(unsigned long long) * (size_t)(need + need / 16 + 4096)));
+        return fail(h, KPL_ERR_RETRY, "sorted search needs room for %llu neighbor keys: array grown, call again", need);
+    }
     if (h->h_state->status == kStatusCellCapacity) {
         const int64_t need = h->h_state->ncells_needed;
         h->index_valid = false;
@@ -379,6 +390,25 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
         }
         KPL_HIP(h, h->draw_list.ensure(sizeof(int) * nn * (2 + kDrawAdj)));     // list, adjacency counts, adjacency
         KPL_HIP(h, h->draw_count.ensure(sizeof(int)));
+    }
+    v.large_list = nullptr;
+    v.sort_keys = nullptr;
+    v.seg_start = nullptr;
+    v.seg_len = nullptr;
+    v.key_cap = 0;
+    if (h->prm.neighbor_order == KPL_NEIGHBORS_SORTED) {
+        // segments of sorted neighbor keys for the points with large neighborhoods: 64 keys per point to begin with; a
+        // view that needs more fails its first call with KPL_ERR_RETRY and finds the array grown (sync_status)
+        KPL_HIP(h, h->large_list.ensure(sizeof(int) * nn));
+        KPL_HIP(h, h->seg_start.ensure(sizeof(unsigned) * nn));
+        KPL_HIP(h, h->seg_len.ensure(sizeof(int) * nn));
+        if (h->sort_keys.cap < sizeof(unsigned long long) * 64 * nn) KPL_HIP(h, h->sort_keys.ensure(sizeof(unsigned long long) * 64 * nn));
+        v.large_list = h->large_list.as<int>();
+        v.sort_keys = h->sort_keys.as<unsigned long long>();
+        v.seg_start = h->seg_start.as<unsigned>();
+        v.seg_len = h->seg_len.as<int>();
+        v.key_cap = h->sort_keys.cap / sizeof(unsigned long long);
+        if (v.key_cap > 0xfffffffeull) v.key_cap = 0xfffffffeull;         // segment starts are 32-bit
     }
     v.f = make_feat(h->prm);
     v.forest = ForestDev{h->d_nodes.as<uint2>(), h->flat.ntrees, (int)h->flat.nodes.size(), (int)h->flat.ntop,
@@ -562,7 +592,7 @@ int detect_staged(kpl_detector *h, int n, float *scores_out, int *kp_idx_out, fl
         if (scores_out && n > 0)
             KPL_HIP(h, hipMemcpyAsync(scores_out, h->out_scores.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, st));
         rc = sync_status(h, st);
-        if (rc == KPL_ERR_RETRY && attempt == 0) continue;   // cell tables were grown: run again
+        if (rc == KPL_ERR_RETRY && attempt < 3) continue;    // cell tables / key segments were grown: run again
         if (rc) return rc;
         break;
     }
@@ -671,7 +701,8 @@ void kpl_destroy(kpl_detector *h) {
                       &h->dstate, &h->cid, &h->btable, &h->cell_start, &h->tmp_idx, &h->scan_tmp,
                       &h->pts, &h->nrm, &h->pos_of, &h->score_sorted, &h->flags, &h->prefix, &h->stats,
                       &h->out_scores, &h->out_kp, &h->out_count, &h->cand_list, &h->cand_count,
-                      &h->draw_list, &h->draw_count, &h->skip, &h->feat, &h->scan_state};
+                      &h->draw_list, &h->draw_count, &h->skip, &h->feat, &h->scan_state,
+                      &h->large_list, &h->seg_start, &h->seg_len, &h->sort_keys};
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->h_state) (void)hipHostFree(h->h_state);

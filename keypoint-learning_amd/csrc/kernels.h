@@ -109,6 +109,13 @@ struct ViewDev {
     int kp_cap;
     int *kp_count;
     StatsDev *stats;             // null unless counters are collected
+    // sorted-search mode, large neighborhoods (kernels.hip "sorted mode, large neighborhoods"): scoreable points whose search
+    // box holds more than kLargeCand candidates, their neighbor keys sorted by (d2, index) in one array, a segment per point
+    int *large_list;                 // [n] storage positions of those points (any order); their number: DevState::large_count
+    unsigned long long *sort_keys;   // [key_cap] the segments
+    unsigned *seg_start;             // [n] by storage position: first key of the point's segment
+    int *seg_len;                    // [n] its length (0: none, or the keys did not fit -> DevState::status)
+    unsigned long long key_cap;
 };
 
 constexpr int kMaxBatch = 8;     // views per batched launch (bounded by the 4 KB kernel argument block)
@@ -120,7 +127,7 @@ static_assert(sizeof(Batch) <= 4096, "a Batch travels as kernel arguments: 4 KB 
 
 // Device-resident state of one handle: the grid descriptor is computed ON the device from the
 // bounding box, so the host never waits between the kernels of a call.
-constexpr int kStatusOk = 0, kStatusGridTooLarge = 1, kStatusCellCapacity = 2, kStatusBadOrigin = 3;
+constexpr int kStatusOk = 0, kStatusGridTooLarge = 1, kStatusCellCapacity = 2, kStatusBadOrigin = 3, kStatusKeyCapacity = 4;
 constexpr long long kMaxGridCells = 1ll << 28;
 constexpr int kBuckets = 1024;   // buckets of the index sort (kernels.hip "Index build")
 constexpr int kDrawRounds = 8;       // parallel rounds of the draws pass, before the adjacency pass and the sequential rest (kernels.hip)
@@ -134,6 +141,12 @@ struct DevState {
     uint32_t scan_epoch;  // tag of the next detect call in the words of scan_state (advanced on the device, never 0)
     int scan_fail;        // set by a block of compact_scan_kernel whose look-back gave up: the call failed (kpl_sync_status -> KPL_ERR_INTERNAL, which clears it)
     int draws_left[kDrawRounds + 2];   // draws pass: [0] = listed maxima, [r + 1] = still undecided after round r, last: after the adjacency pass
+    // sorted-search mode, large neighborhoods: both counters are zero between calls (the compaction's last block re-arms them
+    // after copying the cursor to keys_needed, which is what kpl_sync_status grows ViewDev::sort_keys to on kStatusKeyCapacity)
+    int large_count;                   // points in ViewDev::large_list
+    int pad_;
+    unsigned long long key_cursor;     // keys handed out of ViewDev::sort_keys so far (counts on past key_cap)
+    unsigned long long keys_needed;    // key_cursor of the last call
 };
 void init_dev_state(DevState *host_copy);
 // look-back polls of the compaction's single-pass scan before the call is failed (default 2^22; < 0: every block but the

@@ -1950,6 +1950,26 @@ __device__ __forceinline__ WavePoint wave_point(const ViewDev &a, int chunk, int
     return w;
 }
 
+// Sorted-search mode: which points take the path for LARGE neighborhoods.  Decided from the index alone -- the number of
+// candidates in the rows of the point's search box (what RowSearch walks), an upper bound of K_f about three times K_f on
+// a surface -- so that every kernel of the stage comes to the same answer without a pass over the points.
+constexpr int kLargeCand = 1024;
+__device__ __forceinline__ int box_candidates(const GridDesc &g, const int *__restrict__ cell_start, const float4 &p, float rr) {
+    CellBox b = make_box(g, p.x, p.y, p.z, rr);
+    b.hi[1] = min(b.hi[1], b.lo[1] + 3);
+    b.hi[2] = min(b.hi[2], b.lo[2] + 3);
+    int c = 0;
+    for (int z = b.lo[2]; z <= b.hi[2]; ++z)
+        for (int y = b.lo[1]; y <= b.hi[1]; ++y) {
+            const int row = (z * g.dims[1] + y) * g.dims[0];
+            c += cell_start[row + b.hi[0] + 1] - cell_start[row + b.lo[0]];
+        }
+    return c;
+}
+__device__ __forceinline__ bool is_large_point(const GridDesc &g, const int *__restrict__ cell_start, const WavePoint &w, float rr) {
+    return w.scoreable && box_candidates(g, cell_start, w.p, rr) > kLargeCand;
+}
+
 // Several independent views per launch (blockIdx.y = view): one 200 k-point view is only a few waves per
 // SIMD; a batch of views fills the chip.  Workgroup (= wave) x handles the 64 / kGroup storage positions
 // x * 64 / kGroup ..; it writes its columns of the F x 64 feature block of its chunk of 64 positions.
@@ -1984,11 +2004,15 @@ __global__ __launch_bounds__(kLanes) void feature_sorted_kernel(Batch b, int max
     const int col = (blockIdx.x % G) * kPts + pi;
     if (chunk * kLanes + col - pi >= v.n) return;
     const WavePoint w = wave_point(v, chunk, col, true);
+    // a point with a large neighborhood is scored by sorted_collect_kernel + sorted_add_kernel (below): no rows here, and
+    // its column of the feature block is theirs
+    const bool large = is_large_point(v.ds->grid, v.cell_start, w, v.f.rr);
     uint2 *ent = reinterpret_cast<uint2 *>(H + maxF * kPts);
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(ent + ecap * kPts);
     const int kf = point_features_sorted<G>(v.pts, v.nrmsrc, v.ns, v.cell_start, v.ds->grid, v.f, w.p, w.np, H, ent, ecap,
-                                            keys, lcap, w.scoreable);
-    if (STATS && w.scoreable && gq == 0) atomicAdd(&v.stats->sum_kf, (unsigned long long)kf);
+                                            keys, lcap, w.scoreable && !large);
+    if (STATS && w.scoreable && !large && gq == 0) atomicAdd(&v.stats->sum_kf, (unsigned long long)kf);
+    if (large) return;
     float *o = v.feat + (size_t)chunk * v.f.F * kLanes + col;
     for (int c = gq; c < v.f.F; c += G) o[c * kLanes] = H[c * kPts + pi];
 }
@@ -2257,6 +2281,342 @@ __global__ __launch_bounds__(kLanes) void features_sorted_kernel(const float4 *_
     if (qi >= m) return;
     float *o = out + (size_t)qi * f.F;
     for (int c = gq; c < f.F; c += G) o[c] = s >= 0 ? H[c * kPts + pi] : NAN;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sorted-search mode, LARGE neighborhoods (the reference's own default operating point: radiusFeatures 20 on the cheff
+// views = 30 mesh resolutions, K_f ~ 2 300 -- /root/reference/src/main_test_detector.cpp:65).  The register sort of
+// point_features_sorted holds 128 keys per point and pass and searches again for every pass: 20 passes over ~10 000 candidates
+// per point there (46 ms per 63 k-point view against 1.8 ms in the canonical order).  Points whose search box holds more than
+// kLargeCand candidates take three kernels instead:
+//   sorted_plan_kernel     lists them (DevState::large_count, ViewDev::large_list)
+//   sorted_collect_kernel  ONE WORKGROUP PER POINT: its 256 threads walk the rows of the box together -- consecutive
+//                          storage positions, coalesced 16-byte loads, no lock step with other points --, the accepted
+//                          neighbors' keys (d2 bits << 32 | original index) go to a list in LDS, the list is sorted there
+//                          (one counting pass over 1024 buckets linear in d2 -- a surface has about equally many neighbors
+//                          per unit of d2 --, then every thread orders its four buckets by insertion; lists that defeat the
+//                          buckets -- many equal distances -- take a bitonic network), and the sorted keys are written to the
+//                          point's segment of ViewDev::sort_keys (bump allocation: one atomic per point).  A list longer
+//                          than the LDS holds (4096 keys) is cut into windows of d2, each collected, sorted and appended.
+//   sorted_add_kernel      the feature loop proper (hpp:334-359) over the sorted segment: two lanes per point, the
+//                          contributions of two neighbors per round computed side by side, the histogram updates in order.
+// Same keys, same arithmetic, same order as point_features_sorted: the results are the same bits.
+// Segments that do not fit ViewDev::key_cap set kStatusKeyCapacity: the call fails with KPL_ERR_RETRY after
+// kpl_sync_status has grown the array to DevState::keys_needed.
+// ---------------------------------------------------------------------------------------------
+constexpr int kCollectThreads = 256, kCollectKeys = 4096, kCollectBuckets = 1024, kCollectAhead = 4;
+constexpr int kInsertionMax = 48;        // keys a thread orders by insertion; more in its buckets: the whole list by the network
+
+__global__ __launch_bounds__(256) void sorted_plan_kernel(Batch b) {
+    const ViewDev &v = b.view[blockIdx.y];
+    if (!v.f.sorted) return;
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    const GridDesc g = v.ds->grid;
+    if (s >= v.n || s >= v.cell_start[g.ncells]) return;
+    if (v.nrm[s].w == 0.0f) return;                                               // not scoreable (hpp:277)
+    if (box_candidates(g, v.cell_start, v.pts[s], v.f.rr) > kLargeCand) v.large_list[atomicAdd(&v.ds->large_count, 1)] = s;
+}
+
+__global__ __launch_bounds__(kCollectThreads) void sorted_collect_kernel(Batch b) {
+    __shared__ unsigned long long keys[kCollectKeys];
+    __shared__ int hist[kCollectBuckets];
+    __shared__ int wsum[kCollectThreads / kWave];
+    __shared__ int s_cnt, s_fallback;
+    __shared__ unsigned long long s_off;
+    const ViewDev &v = b.view[blockIdx.y];
+    if (!v.f.sorted) return;
+    DevState *ds = v.ds;
+    const int nlarge = ds->large_count;
+    const GridDesc g = ds->grid;
+    const float4 *__restrict__ pts = v.pts;
+    const int *__restrict__ cell_start = v.cell_start;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
+    const float r2 = v.f.r2;
+    const unsigned long long key_end = (unsigned long long)__float_as_uint(r2) << 32;     // every key is below it (d2 < r2)
+    for (int li = blockIdx.x; li < nlarge; li += gridDim.x) {
+        const int s = v.large_list[li];
+        const float4 p = pts[s];
+        CellBox bx = make_box(g, p.x, p.y, p.z, v.f.rr);
+        bx.hi[1] = min(bx.hi[1], bx.lo[1] + 3);
+        bx.hi[2] = min(bx.hi[2], bx.lo[2] + 3);
+        // the keys of the window [lo, hi) -> keys[] (the first kCollectKeys of them); returns how many there are
+        auto collect = [&](unsigned long long lo, unsigned long long hi) -> int {
+            __syncthreads();
+            if (tid == 0) s_cnt = 0;
+            __syncthreads();
+            for (int z = bx.lo[2]; z <= bx.hi[2]; ++z)
+                for (int y = bx.lo[1]; y <= bx.hi[1]; ++y) {
+                    const int row = (z * g.dims[1] + y) * g.dims[0];
+                    const int r0 = cell_start[row + bx.lo[0]], r1 = cell_start[row + bx.hi[0] + 1];
+                    for (int t0 = r0; t0 < r1; t0 += kCollectThreads * kCollectAhead) {
+                        float4 q[kCollectAhead];
+#pragma unroll
+                        for (int a = 0; a < kCollectAhead; ++a) q[a] = pts[min(t0 + a * kCollectThreads + tid, r1 - 1)];
+                        unsigned long long key[kCollectAhead], bal[kCollectAhead];
+                        bool take[kCollectAhead];
+                        int mine = 0;
+#pragma unroll
+                        for (int a = 0; a < kCollectAhead; ++a) {
+                            const float d2 = dist2(p.x, p.y, p.z, q[a]);
+                            key[a] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)(unsigned)__float_as_int(q[a].w);
+                            take[a] = t0 + a * kCollectThreads + tid < r1 && d2 < r2 && key[a] >= lo && key[a] < hi;   // strict (KdTreeFLANN)
+                            bal[a] = __ballot(take[a]);
+                            mine += __popcll(bal[a]);
+                        }
+                        int base = 0;
+                        if (lane == 0 && mine > 0) base = atomicAdd(&s_cnt, mine);                // one LDS atomic per wave and step
+                        base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+                        for (int a = 0; a < kCollectAhead; ++a) {
+                            const int slot = base + __popcll(bal[a] & ((1ull << lane) - 1ull));
+                            if (take[a] && slot < kCollectKeys) keys[slot] = key[a];
+                            base += __popcll(bal[a]);
+                        }
+                    }
+                }
+            __syncthreads();
+            return s_cnt;
+        };
+        // ascending order of keys[0 .. cnt), cnt <= kCollectKeys; the d2 of the keys lie in [lo_d2, hi_d2)
+        auto sort_list = [&](int cnt, float lo_d2, float hi_d2) {
+            constexpr int kPer = kCollectKeys / kCollectThreads;                  // list elements per thread
+            constexpr int kBPer = kCollectBuckets / kCollectThreads;              // buckets per thread
+            const float span = hi_d2 - lo_d2;
+            const float scale = span > 0.0f ? (float)kCollectBuckets / span : 0.0f;
+            // bucket of a key: monotonic in d2 (float subtract, multiply by a positive constant, truncate, clamp)
+            auto bucket_of = [&](unsigned long long k) -> int {
+                const float t = (__uint_as_float((unsigned)(k >> 32)) - lo_d2) * scale;
+                return min(max((int)t, 0), kCollectBuckets - 1);
+            };
+            for (int k = tid; k < kCollectBuckets; k += kCollectThreads) hist[k] = 0;
+            if (tid == 0) s_fallback = 0;
+            __syncthreads();
+            unsigned long long mykey[kPer];
+#pragma unroll
+            for (int j = 0; j < kPer; ++j) {
+                const int i = tid + j * kCollectThreads;
+                mykey[j] = i < cnt ? keys[i] : ~0ull;
+                if (i < cnt) atomicAdd(&hist[bucket_of(mykey[j])], 1);
+            }
+            __syncthreads();
+            // exclusive scan of the bucket counts: kBPer consecutive buckets per thread
+            int local[kBPer], sum = 0;
+#pragma unroll
+            for (int k = 0; k < kBPer; ++k) {
+                local[k] = hist[tid * kBPer + k];
+                sum += local[k];
+            }
+            int incl = sum;
+            for (int off = 1; off < kWave; off <<= 1) {
+                const int o = __shfl_up(incl, off);
+                if (lane >= off) incl += o;
+            }
+            if (lane == kWave - 1) wsum[wid] = incl;
+            __syncthreads();
+            int run = incl - sum;
+            for (int w = 0; w < wid; ++w) run += wsum[w];
+#pragma unroll
+            for (int k = 0; k < kBPer; ++k) {
+                hist[tid * kBPer + k] = run;                                      // the bucket's cursor = its first position
+                run += local[k];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < kPer; ++j)                                      // (every key is in a register: the list may be overwritten)
+                if (tid + j * kCollectThreads < cnt) keys[atomicAdd(&hist[bucket_of(mykey[j])], 1)] = mykey[j];
+            __syncthreads();
+            // every thread orders the keys of its kBPer consecutive buckets (one contiguous piece of the list; a cursor has
+            // come to rest at the end of its bucket = the start of the next)
+            const int a0 = tid == 0 ? 0 : hist[tid * kBPer - 1], a1 = hist[tid * kBPer + kBPer - 1];
+            if (a1 - a0 > kInsertionMax) s_fallback = 1;
+            else
+                for (int i = a0 + 1; i < a1; ++i) {
+                    const unsigned long long x = keys[i];
+                    int j = i - 1;
+                    while (j >= a0 && keys[j] > x) {
+                        keys[j + 1] = keys[j];
+                        --j;
+                    }
+                    keys[j + 1] = x;
+                }
+            __syncthreads();
+            if (s_fallback) {                   // many equal or clustered distances: a bitonic network over the whole list
+                int N = 2;
+                while (N < cnt) N <<= 1;
+                for (int i = cnt + tid; i < N; i += kCollectThreads) keys[i] = ~0ull;
+                __syncthreads();
+                for (int k = 2; k <= N; k <<= 1)
+                    for (int j = k >> 1; j > 0; j >>= 1) {
+                        for (int i = tid; i < N; i += kCollectThreads) {
+                            const int ixj = i ^ j;
+                            if (ixj > i) {
+                                const unsigned long long x = keys[i], y = keys[ixj];
+                                const bool up = (i & k) == 0;
+                                if ((x > y) == up) {
+                                    keys[i] = y;
+                                    keys[ixj] = x;
+                                }
+                            }
+                        }
+                        __syncthreads();
+                    }
+            }
+        };
+        // ---- the whole neighborhood, or its first kCollectKeys keys and their number
+        const int total = collect(0ull, key_end);
+        if (tid == 0) {
+            const unsigned long long off = atomicAdd(&ds->key_cursor, (unsigned long long)total);
+            const bool fits = off + (unsigned long long)total <= v.key_cap;
+            if (!fits) atomicCAS(&ds->status, kStatusOk, kStatusKeyCapacity);
+            v.seg_start[s] = (unsigned)off;
+            v.seg_len[s] = fits ? total : 0;
+            s_off = fits ? off : ~0ull;
+        }
+        __syncthreads();
+        const unsigned long long off = s_off;
+        if (off == ~0ull) continue;                              // no room: this call fails, the next one has it (kpl_sync_status)
+        unsigned long long *out = v.sort_keys + off;
+        if (total <= kCollectKeys) {
+            sort_list(total, 0.0f, r2);
+            for (int i = tid; i < total; i += kCollectThreads) out[i] = keys[i];
+            continue;
+        }
+        // ---- more keys than the list holds: windows of d2, sized for an even spread of the neighbors over d2 and halved
+        // when one runs over (as point_features_sorted does)
+        unsigned long long lo = 0ull;
+        int done = 0;
+        const float step = r2 * ((float)(kCollectKeys * 3 / 4) / (float)total);
+        while (lo < key_end) {
+            const float lo_d2 = __uint_as_float((unsigned)(lo >> 32));
+            unsigned hb = __float_as_uint(lo_d2 + step);
+            if (hb <= (unsigned)(lo >> 32)) hb = (unsigned)(lo >> 32) + 1u;
+            unsigned long long hi = (unsigned long long)hb << 32;
+            if (hi > key_end) hi = key_end;
+            int cnt;
+            for (;;) {
+                cnt = collect(lo, hi);
+                if (cnt <= kCollectKeys) break;
+                const unsigned lb = (unsigned)(lo >> 32), hbb = (unsigned)(hi >> 32);
+                if (hbb - lb >= 2u) {
+                    const float ld = __uint_as_float(lb), hd = __uint_as_float(hbb);
+                    unsigned mb = __float_as_uint(ld + (hd - ld) * 0.5f);
+                    if (mb <= lb || mb >= hbb) mb = lb + (hbb - lb) / 2u;
+                    hi = (unsigned long long)mb << 32;
+                } else {
+                    hi = lo + (hi - lo) / 2ull;                  // one or two distances left: halve by the whole key
+                }
+            }
+            // (the keys of a window whose upper end is not a whole d2 start in the middle of one: the bucket range covers it)
+            const float w_lo = __uint_as_float((unsigned)(lo >> 32));
+            const float w_hi = (hi & 0xffffffffull) ? __uint_as_float((unsigned)(hi >> 32) + 1u) : __uint_as_float((unsigned)(hi >> 32));
+            sort_list(cnt, w_lo, fmaxf(w_hi, w_lo));
+            for (int i = tid; i < cnt; i += kCollectThreads) out[done + i] = keys[i];
+            done += cnt;
+            lo = hi;
+        }
+    }
+}
+
+// the feature loop (hpp:334-359) of the large points over their sorted segments; writes their columns of the feature block
+template <bool STATS>
+__global__ __launch_bounds__(kLanes) void sorted_add_kernel(Batch b, int maxF) {
+    extern __shared__ float H[];
+    constexpr int G = 2, kPts = kLanes / G;
+    const ViewDev &v = b.view[blockIdx.y];
+    if (!v.f.sorted) return;
+    if (v.ds->large_count == 0) return;
+    const int chunk = blockIdx.x / G, pi = threadIdx.x / G, gq = threadIdx.x % G;
+    const int col = (blockIdx.x % G) * kPts + pi;
+    if (chunk * kLanes + col - pi >= v.n) return;
+    const WavePoint w = wave_point(v, chunk, col, true);
+    const bool large = is_large_point(v.ds->grid, v.cell_start, w, v.f.rr);
+    if (!__any(large)) return;
+    if (v.ds->status != kStatusOk) return;                        // (segments incomplete: the call fails, kpl_sync_status)
+    FeatDesc f;
+    f.A = pin_i(v.f.A);
+    f.B = pin_i(v.f.B);
+    f.F = pin_i(v.f.F);
+    f.A1f = pin_f(v.f.A1f);
+    f.B1f = pin_f(v.f.B1f);
+    f.support = v.f.support;
+    f.ann_dim = pin_f(v.f.ann_dim);
+    f.ann_half = pin_f(v.f.ann_half);
+    f.ann_rdim = pin_f(v.f.ann_rdim);
+    f.bin_dim = pin_f(v.f.bin_dim);
+    f.bin_half = pin_f(v.f.bin_half);
+    f.bin_rdim = pin_f(v.f.bin_rdim);
+    f.r2 = pin_f(v.f.r2);
+    f.rr = v.f.rr;
+    for (int c = gq; c < f.F; c += G) H[c * kPts + pi] = 0.0f;                     // hpp:325
+    wave_lds_fence();
+    const int len = large ? v.seg_len[w.s] : 0;
+    const unsigned long long *seg = v.sort_keys + (large ? v.seg_start[w.s] : 0u);
+    const char *__restrict__ nrmsrc = v.nrmsrc;
+    const unsigned ns = v.ns;
+    const float4 np = w.np;
+    const int col_address = lds_address(H + pi);
+    if (STATS && large && gq == 0) atomicAdd(&v.stats->sum_kf, (unsigned long long)len);
+    // element 0 of the order is dropped (hpp:336); keys two rounds ahead of their use, normals one
+    struct Slot {
+        bool valid;
+        float d2;
+        unsigned orig;
+        f32x3 n;
+    };
+    int k = 1 + gq;
+    auto fetch_key = [&](Slot &slot) {
+        slot.valid = k < len;
+        const unsigned long long key = seg[slot.valid ? k : 0];
+        k += G;
+        slot.d2 = __uint_as_float((unsigned)(key >> 32));
+        slot.orig = slot.valid ? (unsigned)key : 0u;
+    };
+    auto fetch_normal = [&](Slot &slot) { slot.n = *reinterpret_cast<const f32x3 *>(nrmsrc + (size_t)slot.orig * ns); };
+    Slot sa, sb, sc;
+    sa.valid = sb.valid = sc.valid = false;
+    sa.d2 = sb.d2 = sc.d2 = 0.f;
+    sa.orig = sb.orig = sc.orig = 0u;
+    sa.n = sb.n = sc.n = f32x3{0.f, 0.f, 0.f};
+    fetch_key(sa);
+    fetch_key(sb);
+    fetch_normal(sa);
+#define KPL_LARGE_ROUND(now, nxt, far)                                                             \
+    {                                                                                              \
+        fetch_key(far);                                                                            \
+        fetch_normal(nxt);                                                                         \
+        const bool has_ = now.valid & finite3(now.n.x, now.n.y, now.n.z);          /* hpp:338 */  \
+        Contribution c_;                                                                           \
+        if (has_) c_ = neighbor_contribution<kPts>(f, now.d2, np, now.n, col_address);             \
+        _Pragma("unroll") for (int sub_ = 0; sub_ < G; ++sub_) {                                   \
+            if (has_ & (gq == sub_)) apply_contribution(c_, request_cells(c_));                    \
+            wave_lds_fence();                                                                      \
+        }                                                                                          \
+    }
+    // (the loop runs while any lane's CURRENT slot is valid; slots are validated in key order, so a group is done when its is not)
+    while (__any(sa.valid)) {
+        KPL_LARGE_ROUND(sa, sb, sc)
+        if (!__any(sb.valid)) break;
+        KPL_LARGE_ROUND(sb, sc, sa)
+        if (!__any(sc.valid)) break;
+        KPL_LARGE_ROUND(sc, sa, sb)
+    }
+#undef KPL_LARGE_ROUND
+    wave_lds_fence();
+    for (int a = gq; a < f.A; a += G) {                                            // hpp:360-370, one row per lane
+        float *h = H + (a * f.B) * kPts + pi;
+        float ssum = 0.0f;
+        for (int kk = 0; kk < f.B; ++kk) {
+            float x = h[kk * kPts];
+            ssum += x * x;
+        }
+        const float nr = sqrtf(ssum);
+        if (nr > 0)
+            for (int kk = 0; kk < f.B; ++kk) h[kk * kPts] = h[kk * kPts] / nr;
+    }
+    wave_lds_fence();
+    if (!large) return;
+    float *o = v.feat + (size_t)chunk * v.f.F * kLanes + col;
+    for (int c = gq; c < v.f.F; c += G) o[c * kLanes] = H[c * kPts + pi];
 }
 
 // detectKeypoints, hpp:197-256 with draws_remove == false (order-independent predicate):
@@ -3085,6 +3445,9 @@ __global__ __launch_bounds__(kScanBlock) void compact_scan_kernel(Batch b, int p
                                     __hip_atomic_load(&v.ds->scan_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
                 *v.kp_count = failed ? -1 : before + total;     // -1: see kpl_sync_status
                 *v.cand.count = 0;
+                v.ds->keys_needed = v.ds->key_cursor;        // sorted mode, large neighborhoods: re-armed for the next call
+                v.ds->key_cursor = 0ull;
+                v.ds->large_count = 0;
                 // every block of this launch has published, hence started, hence read the tag: the next call's may be set
                 __hip_atomic_store(&v.ds->scan_epoch, epoch + 1u == 0u ? 1u : epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -3290,11 +3653,21 @@ void launch_feature_stage(const Batch &b, hipStream_t st) {
         else feature_kernel<false><<<grid, kLanes, lds, st>>>(b, maxF, ecap);
     }
     if (sorted) {       // the views in sorted-search mode (each kernel skips the views of the other mode)
+        // the points with large neighborhoods are listed first; the register-sort kernel leaves them out, the collect /
+        // add pair takes them (all three return at once where there are none)
+        sorted_plan_kernel<<<dim3(div_up(n, 256), b.nviews), 256, 0, st>>>(b);
         const int lcap = sorted_list_keys(maxF);
         const size_t lds = sorted_lds_bytes<kSortGroup>(maxF, kSortWords, lcap);
         const dim3 grid(div_up(n, kLanes) * kSortGroup, b.nviews);
         if (stats) feature_sorted_kernel<true><<<grid, kLanes, lds, st>>>(b, maxF, kSortWords, lcap);
         else feature_sorted_kernel<false><<<grid, kLanes, lds, st>>>(b, maxF, kSortWords, lcap);
+        int wgs = div_up(cu_count() * 4, b.nviews);             // persistent: four workgroups per CU (37 KB of LDS each)
+        if (wgs > n) wgs = n;
+        sorted_collect_kernel<<<dim3(wgs, b.nviews), kCollectThreads, 0, st>>>(b);
+        const dim3 agrid(div_up(n, kLanes) * 2, b.nviews);
+        const size_t alds = sizeof(float) * (size_t)maxF * (kLanes / 2);
+        if (stats) sorted_add_kernel<true><<<agrid, kLanes, alds, st>>>(b, maxF);
+        else sorted_add_kernel<false><<<agrid, kLanes, alds, st>>>(b, maxF);
     }
 }
 
