@@ -2723,9 +2723,13 @@ __global__ __launch_bounds__(256) void nms_kernel(Batch b, int many) {
 constexpr int kDrawKept = 1, kDrawDropped = 2, kDrawUndecided = 3;
 
 // one listed maximum, LANES lanes: does any draw lie within the threshold, is a lower-index neighbor kept / undecided
-template <int LANES>
+struct SkipStates {           // the states as the parallel rounds see them: skip[] in memory
+    const int *skip;
+    __device__ __forceinline__ int operator()(int qi) const { return __hip_atomic_load(&skip[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+};
+template <int LANES, class States>
 __device__ __forceinline__ void draws_sweep(const ViewDev &v, const GridDesc &g, int idx, int lane, bool &any_draw,
-                                            bool &lower_kept, bool &lower_undecided) {
+                                            bool &lower_kept, bool &lower_undecided, const States &state_of_point) {
     const NmsDesc nd = v.nd;
     const float4 *__restrict__ pts = v.pts;
     const int *__restrict__ cell_start = v.cell_start;
@@ -2749,7 +2753,7 @@ __device__ __forceinline__ void draws_sweep(const ViewDev &v, const GridDesc &g,
                         any_draw = true;
                         const int qi = __float_as_int(q.w);
                         if (qi < idx) {                                             // it comes first in the reference's loop
-                            const int sq = __hip_atomic_load(&v.skip[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const int sq = state_of_point(qi);
                             lower_kept |= sq == kDrawKept;
                             lower_undecided |= sq == kDrawUndecided;
                         }
@@ -2773,7 +2777,7 @@ __global__ __launch_bounds__(256) void draws_round_kernel(Batch b, int round) {
         const int idx = v.draw_list[k];
         if (__hip_atomic_load(&v.skip[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kDrawUndecided) continue;
         bool any_draw, lower_kept, lower_undecided;
-        draws_sweep<kDrawLanes>(v, g, idx, lane, any_draw, lower_kept, lower_undecided);
+        draws_sweep<kDrawLanes>(v, g, idx, lane, any_draw, lower_kept, lower_undecided, SkipStates{v.skip});
         any_draw = ((__ballot(any_draw) >> gbase) & gmask) != 0ull;
         lower_kept = ((__ballot(lower_kept) >> gbase) & gmask) != 0ull;
         lower_undecided = ((__ballot(lower_undecided) >> gbase) & gmask) != 0ull;
@@ -2861,13 +2865,22 @@ __global__ __launch_bounds__(256) void draws_adj_kernel(Batch b) {
     }
 }
 
-// ... and draws_rest_kernel, one wave per view, in index order: the states of all listed maxima as 2-bit fields in LDS,
-// the adjacency rows of 64 entries at a time through LDS; an entry costs two LDS round trips (its row, the states of its
-// neighbors -- all of them decided by then, they come first in the list) instead of a sweep through memory.  An
-// entry with more than kDrawAdj waiting neighbors takes the sweep (draws_sweep reads the states from skip[], which is
-// kept up to date).  lds_words = state words that fit (16 entries each); a longer list reads its states from skip[].
-__global__ __launch_bounds__(64) void draws_rest_kernel(Batch b, int lds_words) {
+// ... and draws_rest_kernel, ONE WORKGROUP per view, in index order: the states of all listed maxima as 2-bit fields in
+// LDS, the list cut into chunks of 64 entries.  Chunk c belongs to wave c mod W.  What does not depend on earlier decisions
+// -- the adjacency rows of the chunk, which neighbors lie inside it -- is prepared by the wave at once; then it waits until
+// every chunk before its own is final (a counter in LDS, advanced chunk by chunk), reads the states of the neighbors before
+// the chunk, settles the chunk on scalars and hands on.  Scan order makes this a pipeline: a maximum of a plateau waits for
+// its left neighbor (the same chunk, or the one before) and for the row above (a chunk or two back), so the serial part
+// per chunk is a few LDS reads and one scalar loop over the entries that are KEPT -- a kept entry strikes every entry of the
+// chunk that waits for it from the candidates with one ballot, so an entry still standing when its turn comes is kept.
+// One wave alone (round 3) spent its time fetching rows between the serial parts: 5 ms per 200 k-point view in scan order.
+// An entry with more than kDrawAdj waiting neighbors sweeps its neighborhood again (draws_sweep, states from LDS through
+// prefix[]: position in the list).  lds_words = state words that fit (16 entries each); a longer list falls back to ONE wave
+// reading the states from skip[].
+constexpr int kRestWaves = 8;
+__global__ __launch_bounds__(kRestWaves *kWave) void draws_rest_kernel(Batch b, int lds_words) {
     extern __shared__ uint32_t dlds[];
+    __shared__ int done;                                                 // chunks that are final
     const ViewDev &v = b.view[blockIdx.y];
     if (!v.nd.draws_remove) return;
     DevState *ds = v.ds;
@@ -2875,13 +2888,13 @@ __global__ __launch_bounds__(64) void draws_rest_kernel(Batch b, int lds_words) 
     const int count = *v.draw_count;
     const int *list = v.draw_list, *adjn = v.draw_list + v.n, *adj = v.draw_list + 2 * (size_t)v.n;
     const GridDesc g = ds->grid;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
     const int nwords = (count + 15) / 16;
     const bool in_lds = nwords <= lds_words;
     uint32_t *state = dlds;
-    int *rows = reinterpret_cast<int *>(dlds + lds_words);               // [64][kDrawAdj]
+    int *rows = reinterpret_cast<int *>(dlds + lds_words) + wid * (kWave * kDrawAdj);      // [64][kDrawAdj] per wave
     if (in_lds) {
-        for (int w = lane; w < nwords; w += 64) {
+        for (int w = threadIdx.x; w < nwords; w += blockDim.x) {
             uint32_t word = 0u;
             for (int e = 0; e < 16; ++e) {
                 const int k = w * 16 + e;
@@ -2890,17 +2903,43 @@ __global__ __launch_bounds__(64) void draws_rest_kernel(Batch b, int lds_words) 
             state[w] = word;
         }
     }
-    wave_lds_fence();
+    if (threadIdx.x == 0) done = 0;
+    __syncthreads();
+    const int nwaves = in_lds ? kRestWaves : 1;                          // states in memory: one wave, its own stores in order
+    if (wid >= nwaves) return;
     auto state_of = [&](int pos) -> int {
         if (in_lds) return (int)((state[pos >> 4] >> ((pos & 15) * 2)) & 3u);
         return __hip_atomic_load(&v.skip[list[pos]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
+    // the state of POINT qi for a sweep: through its position in the list when the states live in LDS
+    auto state_of_point = [&](int qi) -> int {
+        if (!in_lds) return __hip_atomic_load(&v.skip[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int pos = v.prefix[qi];
+        return (pos < count && list[pos] == qi) ? state_of(pos) : 0;
+    };
+    auto wait_for_turn = [&](int chunk) {                                // every chunk before this one is final
+        if (nwaves == 1) return;
+        while (__hip_atomic_load(&done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < chunk) __builtin_amdgcn_s_sleep(1);
+        wave_lds_fence();
+    };
+    auto hand_on = [&](int chunk) {                                      // (a wave's LDS operations execute in order: the states first)
+        if (nwaves == 1) return;
+        wave_lds_fence();
+        if (lane == 0) __hip_atomic_store(&done, chunk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
     const size_t adj_len = (size_t)v.n * kDrawAdj;
-    for (int k0 = 0; k0 < count; k0 += 64) {
+    const int nchunks = (count + 63) / 64;
+    for (int chunk = wid; chunk < nchunks; chunk += nwaves) {
+        const int k0 = chunk * 64;
         const int kk = k0 + lane;
+        // (the entries of a chunk are decided by this wave only: their states do not change before its turn)
         const int my_state = kk < count ? state_of(kk) : kDrawDropped;
         unsigned long long todo = __ballot(my_state == kDrawUndecided);
-        if (todo == 0ull) continue;
+        if (todo == 0ull) {
+            wait_for_turn(chunk);
+            hand_on(chunk);
+            continue;
+        }
         const int my_idx = kk < count ? list[kk] : 0, my_n = kk < count ? adjn[kk] : 0;
         wave_lds_fence();
         for (int r = 0; r < kDrawAdj; ++r) {                             // the rows of the chunk, contiguous in memory
@@ -2911,31 +2950,39 @@ __global__ __launch_bounds__(64) void draws_rest_kernel(Batch b, int lds_words) 
         const bool mine = my_state == kDrawUndecided;
         const int n_mine = my_n & 0xffffff;
         if (in_lds && !__any(mine && n_mine > kDrawAdj)) {
-            // the usual chunk: every lane walks the row of ITS entry once -- neighbors before the chunk are decided, their
-            // states are read now; neighbors inside the chunk become a 64-bit mask -- and the sequential part runs on
-            // scalars: an entry is dropped iff a neighbor before the chunk is kept or one inside it has been kept so far
-            bool kept_before = false;
+            // the usual chunk.  Before its turn: which neighbors lie inside the chunk
             unsigned long long inside = 0ull;
+            bool any_before = false;
             if (mine)
                 for (int q = 0; q < n_mine; ++q) {
                     const int pos = rows[lane * kDrawAdj + q];
                     if (pos >= k0) inside |= 1ull << (pos - k0);
-                    else kept_before |= state_of(pos) == kDrawKept;
+                    else any_before = true;
                 }
-            const int may_keep = (mine && !kept_before && ((my_n >> 30) & 1)) ? 1 : 0;
-            const int in_lo = (int)(unsigned)inside, in_hi = (int)(unsigned)(inside >> 32);
+            wait_for_turn(chunk);
+            // its turn: the neighbors before the chunk are decided
+            bool kept_before = false;
+            if (mine && any_before)
+                for (int q = 0; q < n_mine; ++q) {
+                    const int pos = rows[lane * kDrawAdj + q];
+                    if (pos < k0) kept_before |= state_of(pos) == kDrawKept;
+                }
+            // (a neighbor inside the chunk may have been decided by its own group while the adjacency pass listed it: kept
+            // already, it strikes the entries that wait for it here)
             unsigned long long kept_mask = __ballot(my_state == kDrawKept);
-            for (unsigned long long t = todo; t != 0ull; t &= t - 1ull) {
-                const int j = __builtin_ctzll(t);
-                const unsigned long long in_j = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(in_hi, j) << 32) |
-                                                (unsigned)__builtin_amdgcn_readlane(in_lo, j);
-                if (__builtin_amdgcn_readlane(may_keep, j) != 0 && (in_j & kept_mask) == 0ull) kept_mask |= 1ull << j;
+            const bool may_keep = mine && !kept_before && ((my_n >> 30) & 1) && (inside & kept_mask) == 0ull;
+            const unsigned in_lo = (unsigned)inside, in_hi = (unsigned)(inside >> 32);
+            // entries in ascending order: one that is still a candidate when its turn comes has no kept neighbor before it
+            // in the chunk -- it is kept, and every entry that waits for it is struck
+            unsigned long long cand = __ballot(may_keep);
+            while (cand != 0ull) {
+                const int j = __builtin_ctzll(cand);
+                cand &= cand - 1ull;
+                kept_mask |= 1ull << j;
+                const unsigned wj = j < 32 ? in_lo : in_hi;
+                cand &= ~__ballot(((wj >> (j & 31)) & 1u) != 0u);
             }
             const int final_state = mine ? (((kept_mask >> lane) & 1ull) ? kDrawKept : kDrawDropped) : my_state;
-            if (mine) {
-                v.flags[my_idx] = final_state == kDrawKept ? 1 : 0;                 // hpp:245-248
-                __hip_atomic_store(&v.skip[my_idx], final_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
             const unsigned long long b0 = __ballot((final_state & 1) != 0), b1 = __ballot((final_state & 2) != 0);
             if (lane < 4 && (k0 >> 4) + lane < nwords) {                            // the chunk's four state words
                 const unsigned lo = (unsigned)(b0 >> (16 * lane)) & 0xffffu, hi = (unsigned)(b1 >> (16 * lane)) & 0xffffu;
@@ -2943,9 +2990,14 @@ __global__ __launch_bounds__(64) void draws_rest_kernel(Batch b, int lds_words) 
                 for (int e = 0; e < 16; ++e) word |= (((lo >> e) & 1u) | (((hi >> e) & 1u) << 1)) << (2 * e);
                 state[(k0 >> 4) + lane] = word;
             }
-            wave_lds_fence();
+            hand_on(chunk);
+            if (mine) {                                                             // (nobody in this kernel reads these)
+                v.flags[my_idx] = final_state == kDrawKept ? 1 : 0;                 // hpp:245-248
+                __hip_atomic_store(&v.skip[my_idx], final_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             continue;
         }
+        wait_for_turn(chunk);
         while (todo != 0ull) {                                           // a chunk with an entry that has to sweep: one by one
             const int j = __builtin_ctzll(todo);
             todo &= todo - 1ull;
@@ -2953,9 +3005,9 @@ __global__ __launch_bounds__(64) void draws_rest_kernel(Batch b, int lds_words) 
             const int n = nraw & 0xffffff;
             bool any_draw = ((nraw >> 30) & 1) != 0, kept;
             if (n > kDrawAdj) {                                          // more neighbors than the row holds: sweep
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (this wave's decisions must be in skip[])
+                if (!in_lds) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (this wave's decisions must be in skip[])
                 bool a, lk, lu;
-                draws_sweep<64>(v, g, idx, lane, a, lk, lu);
+                draws_sweep<64>(v, g, idx, lane, a, lk, lu, state_of_point);
                 any_draw = __any(a);
                 kept = __any(lk);
             } else {
@@ -2974,6 +3026,7 @@ __global__ __launch_bounds__(64) void draws_rest_kernel(Batch b, int lds_words) 
             if (!in_lds) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             wave_lds_fence();
         }
+        hand_on(chunk);
     }
 }
 
@@ -3802,8 +3855,9 @@ void launch_post(const Batch &b, hipStream_t st) {
             for (int r = 0; r < kDrawRounds; ++r) draws_round_kernel<<<dim3(dblocks, nv), 256, 0, st>>>(b, r);
             draws_adj_kernel<<<dim3(dblocks, nv), 256, 0, st>>>(b);
             int lds_words = div_up(n, 16);                                    // 2 bits of state per listed maximum
-            if (lds_words > 36 * 1024) lds_words = 36 * 1024;                 // 144 KB
-            draws_rest_kernel<<<dim3(1, nv), 64, sizeof(uint32_t) * (size_t)lds_words + sizeof(int) * 64 * kDrawAdj, st>>>(b, lds_words);
+            if (lds_words > 20 * 1024) lds_words = 20 * 1024;                 // 80 KB of states (327 k listed maxima) + 8 x 8 KB of rows
+            draws_rest_kernel<<<dim3(1, nv), kRestWaves * kWave,
+                                sizeof(uint32_t) * (size_t)lds_words + sizeof(int) * (size_t)kRestWaves * kWave * kDrawAdj, st>>>(b, lds_words);
         }
     }
     compact_scan_kernel<<<dim3(n > 0 ? div_up(n, kScanChunk) : 1, nv), kScanBlock, 0, st>>>(b, g_scan_poll_limit);

@@ -186,3 +186,72 @@ def test_sorted_mode_counters_and_device_features(kpl, oracle, cases):
     fa = forest_yaml.load_forest(forest)
     c = oracle.Grid(xyz, r).alg_counters(nrm, 5, 6, r, rn, thr, cases.oracle_forest(fa))
     assert stats[False]["sum_kf"] == c["sum_kf"] and stats[False]["sum_depth"] == c["sum_depth"]
+
+
+# ---- large neighborhoods: sorted_plan / sorted_collect / sorted_add (kernels.hip), against the oracle AND against the
+# register-sort path (computePointsForTrainingFeatures still takes that one for every neighborhood size)
+
+def _score_both_ways(kpl, oracle, cases, xyz, nrm, A, B, r, seed):
+    from tools import synth
+    fa = synth.random_forest(A * B, ntrees=6, max_depth=8, seed=seed, target_nodes_per_tree=120)
+    det = make_det(kpl, A, B, r, 0.0, 0.0, fa)
+    det.setNonMaxima(False)
+    det.setInputCloud(xyz)
+    det.setNormals(nrm)
+    _, scores = det.compute()
+    o_scores, _ = oracle.detect(xyz, nrm, A, B, r, 0.0, 0.0, cases.oracle_forest(fa), non_maxima=False, order=oracle.ORDER_SORTED,
+                                threads=cases.usable_cores())
+    assert cases.same_bits(scores, o_scores)
+    st = det.collectStats()
+    q = np.arange(0, len(xyz), max(1, len(xyz) // 300), dtype=np.int32)
+    q = q[np.isfinite(nrm[q]).all(axis=1)]
+    want = oracle.Grid(xyz, r).features(nrm, A, B, r, q, order=oracle.ORDER_SORTED)
+    assert cases.same_bits(det.computePointsForTrainingFeatures(q), want)
+    return st["sum_kf"] / max(st["n_scored"], 1)
+
+
+def test_sorted_large_neighborhoods_with_many_equal_distances(kpl, oracle, cases):
+    """a regular lattice at a large radius: ~1 500 neighbors per point, a few dozen distinct distances -- the bucket pass
+    of sorted_collect_kernel cannot separate them, the bitonic network takes the lists"""
+    xyz, nrm = lattice(48, 44, dup=60)
+    kf = _score_both_ways(kpl, oracle, cases, xyz, nrm, 5, 6, 21.3, 11)
+    assert kf > 1000, kf
+
+
+def test_sorted_neighborhoods_longer_than_the_lds_list(kpl, oracle, cases):
+    """a random volume, r = 0.36 of its edge: ~5 000 neighbors per interior point -- more than the 4 096 keys
+    sorted_collect_kernel holds: windows of d2, each collected, sorted and appended; non-finite points and normals mixed in"""
+    rng = np.random.default_rng(5)
+    xyz = rng.uniform(0, 1, size=(30000, 3)).astype(np.float32)
+    nrm = rng.normal(size=(30000, 3)).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    xyz[::997] = np.nan
+    nrm[5::811] = np.nan
+    kf = _score_both_ways(kpl, oracle, cases, xyz, nrm, 3, 4, 0.36, 12)
+    assert kf > 3000, kf
+
+
+def test_sorted_key_segments_grow_through_retry(kpl, oracle, cases):
+    """the device entry point cannot grow the key array itself: the first call on a fresh handle reports KPL_ERR_RETRY through
+    kpl_sync_status (count -1), the second one has room"""
+    import torch
+    rng = np.random.default_rng(6)
+    xyz = rng.uniform(0, 1, size=(20000, 3)).astype(np.float32) * np.float32([1, 1, 0.02])
+    nrm = np.tile(np.float32([[0, 0, 1]]), (len(xyz), 1))
+    from tools import synth
+    fa = synth.random_forest(30, ntrees=5, max_depth=6, seed=3, target_nodes_per_tree=60)
+    det = make_det(kpl, 5, 6, 0.12, 0.0, 0.0, fa)                    # ~900 neighbors per point: 64 keys per point do not hold them
+    det.setNonMaxima(False)
+    dev = torch.device("cuda", 0)
+    dx, dn = torch.from_numpy(xyz).to(dev), torch.from_numpy(nrm).to(dev)
+    ds = torch.empty(len(xyz), dtype=torch.float32, device=dev)
+    dk = torch.zeros(len(xyz) + 1, dtype=torch.int32, device=dev)
+    det.bindCloudDevice(dx.data_ptr(), 12, dn.data_ptr(), 12, len(xyz))
+    det.computeDevice(ds.data_ptr(), dk[1:].data_ptr(), len(xyz), dk[0:1].data_ptr())
+    assert det.syncStatus(None) == kpl.ERR_RETRY and int(dk[0].item()) == -1
+    assert "neighbor keys" in det.lastError()
+    det.computeDevice(ds.data_ptr(), dk[1:].data_ptr(), len(xyz), dk[0:1].data_ptr())
+    assert det.syncStatus(None) == kpl.OK and int(dk[0].item()) == len(xyz)
+    o_scores, _ = oracle.detect(xyz, nrm, 5, 6, 0.12, 0.0, 0.0, cases.oracle_forest(fa), non_maxima=False, order=oracle.ORDER_SORTED,
+                                threads=cases.usable_cores())
+    assert cases.same_bits(ds.cpu().numpy(), o_scores)
