@@ -388,7 +388,7 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
             KPL_HIP(h, h->skip.ensure(sizeof(int) * nn));
             KPL_HIP(h, hipMemset(h->skip.p, 0, h->skip.cap));             // kept zero by compact_kernel
         }
-        KPL_HIP(h, h->draw_list.ensure(sizeof(int) * nn * (2 + kDrawAdj)));     // list, adjacency counts, adjacency
+        KPL_HIP(h, h->draw_list.ensure(sizeof(int) * (nn * (2 + kDrawAdj) + 8)));     // list, adjacency counts, adjacency (kernels.hip draw_adj_offset)
         KPL_HIP(h, h->draw_count.ensure(sizeof(int)));
     }
     v.large_list = nullptr;

@@ -2721,6 +2721,8 @@ __global__ __launch_bounds__(256) void nms_kernel(Batch b, int many) {
 // order -- long chains of maxima that each wait for the one before (points in scan order along a plateau).  One wave
 // over the whole list took 25 ms for the 22 000 listed maxima of a 200 k-point view; now 0.3-0.6 ms.
 constexpr int kDrawKept = 1, kDrawDropped = 2, kDrawUndecided = 3;
+// draw_list: [n] listed maxima, [n] adjacency counts, then -- from a 16-byte boundary -- [n x kDrawAdj] adjacency rows
+__host__ __device__ inline size_t draw_adj_offset(int n) { return 2 * (((size_t)(n > 0 ? n : 1) + 3) & ~(size_t)3); }
 
 // one listed maximum, LANES lanes: does any draw lie within the threshold, is a lower-index neighbor kept / undecided
 struct SkipStates {           // the states as the parallel rounds see them: skip[] in memory
@@ -2809,7 +2811,7 @@ __global__ __launch_bounds__(256) void draws_adj_kernel(Batch b) {
     const int *__restrict__ cell_start = v.cell_start;
     const float *__restrict__ score_sorted = v.score_sorted;
     const int count = *v.draw_count;
-    int *adjn = v.draw_list + v.n, *adj = v.draw_list + 2 * (size_t)v.n;
+    int *adjn = v.draw_list + v.n, *adj = v.draw_list + draw_adj_offset(v.n);
     const GridDesc g = ds->grid;
     const int lane = threadIdx.x & (kDrawLanes - 1), gbase = (threadIdx.x & (kWave - 1)) & ~(kDrawLanes - 1);
     const unsigned long long gmask = (1ull << kDrawLanes) - 1ull;
@@ -2886,7 +2888,7 @@ __global__ __launch_bounds__(kRestWaves *kWave) void draws_rest_kernel(Batch b, 
     DevState *ds = v.ds;
     if (ds->draws_left[kDrawRounds + 1] == 0) return;
     const int count = *v.draw_count;
-    const int *list = v.draw_list, *adjn = v.draw_list + v.n, *adj = v.draw_list + 2 * (size_t)v.n;
+    const int *list = v.draw_list, *adjn = v.draw_list + v.n, *adj = v.draw_list + draw_adj_offset(v.n);
     const GridDesc g = ds->grid;
     const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
     const int nwords = (count + 15) / 16;
@@ -2941,30 +2943,41 @@ __global__ __launch_bounds__(kRestWaves *kWave) void draws_rest_kernel(Batch b, 
             continue;
         }
         const int my_idx = kk < count ? list[kk] : 0, my_n = kk < count ? adjn[kk] : 0;
-        wave_lds_fence();
-        for (int r = 0; r < kDrawAdj; ++r) {                             // the rows of the chunk, contiguous in memory
-            const size_t at = (size_t)k0 * kDrawAdj + (size_t)r * 64 + lane;
-            rows[r * 64 + lane] = at < adj_len ? adj[at] : 0;
-        }
-        wave_lds_fence();
         const bool mine = my_state == kDrawUndecided;
         const int n_mine = my_n & 0xffffff;
         if (in_lds && !__any(mine && n_mine > kDrawAdj)) {
-            // the usual chunk.  Before its turn: which neighbors lie inside the chunk
+            // the usual chunk.  Before its turn: the lane's row straight from memory (its first kRowRegs entries in
+            // registers -- nearly always all of them), which neighbors lie inside the chunk, which before it
+            constexpr int kRowRegs = 8;
+            const int4 *row4 = reinterpret_cast<const int4 *>(adj + (size_t)min(kk, count - 1) * kDrawAdj);     // (16-byte aligned: draw_adj_offset)
+            const int4 ra = row4[0], rb = row4[1];
+            const int rpos[kRowRegs] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
             unsigned long long inside = 0ull;
-            bool any_before = false;
+            int before[kRowRegs];
+#pragma unroll
+            for (int q = 0; q < kRowRegs; ++q) {
+                const bool has = mine && q < n_mine;
+                if (has && rpos[q] >= k0) inside |= 1ull << (rpos[q] - k0);
+                before[q] = (has && rpos[q] < k0) ? rpos[q] : -1;
+            }
+            bool more_before = false;
             if (mine)
-                for (int q = 0; q < n_mine; ++q) {
-                    const int pos = rows[lane * kDrawAdj + q];
+                for (int q = kRowRegs; q < n_mine; ++q) {
+                    const int pos = adj[(size_t)kk * kDrawAdj + q];
                     if (pos >= k0) inside |= 1ull << (pos - k0);
-                    else any_before = true;
+                    else more_before = true;
                 }
             wait_for_turn(chunk);
-            // its turn: the neighbors before the chunk are decided
+            // its turn: the neighbors before the chunk are decided -- all state reads in flight together
+            int st[kRowRegs];
+#pragma unroll
+            for (int q = 0; q < kRowRegs; ++q) st[q] = state_of(max(before[q], 0));
             bool kept_before = false;
-            if (mine && any_before)
-                for (int q = 0; q < n_mine; ++q) {
-                    const int pos = rows[lane * kDrawAdj + q];
+#pragma unroll
+            for (int q = 0; q < kRowRegs; ++q) kept_before |= before[q] >= 0 && st[q] == kDrawKept;
+            if (more_before)
+                for (int q = kRowRegs; q < n_mine; ++q) {
+                    const int pos = adj[(size_t)kk * kDrawAdj + q];
                     if (pos < k0) kept_before |= state_of(pos) == kDrawKept;
                 }
             // (a neighbor inside the chunk may have been decided by its own group while the adjacency pass listed it: kept
@@ -2997,6 +3010,12 @@ __global__ __launch_bounds__(kRestWaves *kWave) void draws_rest_kernel(Batch b, 
             }
             continue;
         }
+        wave_lds_fence();
+        for (int r = 0; r < kDrawAdj; ++r) {                             // the rows of the chunk, contiguous in memory
+            const size_t at = (size_t)k0 * kDrawAdj + (size_t)r * 64 + lane;
+            rows[r * 64 + lane] = at < adj_len ? adj[at] : 0;
+        }
+        wave_lds_fence();
         wait_for_turn(chunk);
         while (todo != 0ull) {                                           // a chunk with an entry that has to sweep: one by one
             const int j = __builtin_ctzll(todo);

@@ -215,7 +215,7 @@ def test_sorted_large_neighborhoods_with_many_equal_distances(kpl, oracle, cases
     of sorted_collect_kernel cannot separate them, the bitonic network takes the lists"""
     xyz, nrm = lattice(48, 44, dup=60)
     kf = _score_both_ways(kpl, oracle, cases, xyz, nrm, 5, 6, 21.3, 11)
-    assert kf > 1000, kf
+    assert kf > 800, kf
 
 
 def test_sorted_neighborhoods_longer_than_the_lds_list(kpl, oracle, cases):
