@@ -130,7 +130,7 @@ static_assert(sizeof(Batch) <= 4096, "a Batch travels as kernel arguments: 4 KB 
 constexpr int kStatusOk = 0, kStatusGridTooLarge = 1, kStatusCellCapacity = 2, kStatusBadOrigin = 3, kStatusKeyCapacity = 4;
 constexpr long long kMaxGridCells = 1ll << 28;
 constexpr int kBuckets = 1024;   // buckets of the index sort (kernels.hip "Index build")
-constexpr int kDrawRounds = 8;       // parallel rounds of the draws pass, before the adjacency pass and the sequential rest (kernels.hip)
+constexpr int kDrawRounds = 8;       // parallel rounds of the draws pass over the adjacency rows, before the pipelined rest (kernels.hip)
 constexpr int kDrawAdj = 32;         // lower-index neighbors an entry of the draws pass keeps for the sequential rest
 struct DevState {
     GridDesc grid;        // written by grid_setup_kernel, read by every later kernel
@@ -140,7 +140,7 @@ struct DevState {
     uint32_t bbox[6];     // order-preserving encoded min / max accumulators (self re-arming)
     uint32_t scan_epoch;  // tag of the next detect call in the words of scan_state (advanced on the device, never 0)
     int scan_fail;        // set by a block of compact_scan_kernel whose look-back gave up: the call failed (kpl_sync_status -> KPL_ERR_INTERNAL, which clears it)
-    int draws_left[kDrawRounds + 2];   // draws pass: [0] = listed maxima, [r + 1] = still undecided after round r, last: after the adjacency pass
+    int draws_left[kDrawRounds + 2];   // draws pass: [0] = listed maxima, [1] = undecided after the adjacency pass, [r + 2] = after round r
     // sorted-search mode, large neighborhoods: both counters are zero between calls (the compaction's last block re-arms them
     // after copying the cursor to keys_needed, which is what kpl_sync_status grows ViewDev::sort_keys to on kStatusKeyCapacity)
     int large_count;                   // points in ViewDev::large_list

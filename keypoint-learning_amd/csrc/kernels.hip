@@ -2766,46 +2766,16 @@ __device__ __forceinline__ void draws_sweep(const ViewDev &v, const GridDesc &g,
 }
 
 constexpr int kDrawLanes = 16;
-__global__ __launch_bounds__(256) void draws_round_kernel(Batch b, int round) {
-    const ViewDev &v = b.view[blockIdx.y];
-    if (!v.nd.draws_remove) return;
-    DevState *ds = v.ds;
-    if (ds->draws_left[round] == 0) return;                  // nothing listed, or everything decided by the rounds before
-    const int count = *v.draw_count;
-    const GridDesc g = ds->grid;
-    const int lane = threadIdx.x & (kDrawLanes - 1), gbase = (threadIdx.x & (kWave - 1)) & ~(kDrawLanes - 1);
-    const unsigned long long gmask = (1ull << kDrawLanes) - 1ull;
-    for (int k = (blockIdx.x * blockDim.x + threadIdx.x) / kDrawLanes; k < count; k += gridDim.x * (blockDim.x / kDrawLanes)) {
-        const int idx = v.draw_list[k];
-        if (__hip_atomic_load(&v.skip[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kDrawUndecided) continue;
-        bool any_draw, lower_kept, lower_undecided;
-        draws_sweep<kDrawLanes>(v, g, idx, lane, any_draw, lower_kept, lower_undecided, SkipStates{v.skip});
-        any_draw = ((__ballot(any_draw) >> gbase) & gmask) != 0ull;
-        lower_kept = ((__ballot(lower_kept) >> gbase) & gmask) != 0ull;
-        lower_undecided = ((__ballot(lower_undecided) >> gbase) & gmask) != 0ull;
-        if (lane != 0) continue;
-        if (lower_kept) {                                                           // hpp:234: on the skip list
-            v.flags[idx] = 0;
-            __hip_atomic_store(&v.skip[idx], kDrawDropped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else if (!lower_undecided) {                                              // hpp:245-248
-            v.flags[idx] = any_draw ? 1 : 0;
-            __hip_atomic_store(&v.skip[idx], any_draw ? kDrawKept : kDrawDropped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            atomicAdd(&ds->draws_left[round + 1], 1);
-        }
-    }
-}
 
-// After the rounds: maxima in scan order along a plateau wait for their left neighbor and for the row above, one link of
-// such a chain per round.  What is left is done in two passes.  draws_adj_kernel, parallel: every entry that is still
-// undecided sweeps its neighborhood once more -- dropped if a lower-index neighbor is kept by now, decided if none of
-// them is undecided any more; otherwise it writes the LIST POSITIONS of the lower-index neighbors it waits for (at most
-// kDrawAdj; the count runs on beyond that) and whether it has a draw within the threshold at all.
+// The pass in three steps.  draws_adj_kernel, parallel, pure geometry -- the ONE sweep of a listed maximum's neighborhood:
+// has it a draw within the threshold at all, and which listed maxima of lower index lie within it; their LIST POSITIONS go to
+// the entry's adjacency row (at most kDrawAdj; the count runs on beyond that).  An entry without such a neighbor is decided
+// on the spot.  No state is read: the rows are the same whatever the order the groups run in.
 __global__ __launch_bounds__(256) void draws_adj_kernel(Batch b) {
     const ViewDev &v = b.view[blockIdx.y];
     if (!v.nd.draws_remove) return;
     DevState *ds = v.ds;
-    if (ds->draws_left[kDrawRounds] == 0) return;
+    if (ds->draws_left[0] == 0) return;                      // nothing listed
     const NmsDesc nd = v.nd;
     const float4 *__restrict__ pts = v.pts;
     const int *__restrict__ cell_start = v.cell_start;
@@ -2818,12 +2788,11 @@ __global__ __launch_bounds__(256) void draws_adj_kernel(Batch b) {
     auto group_any = [&](bool x) { return ((__ballot(x) >> gbase) & gmask) != 0ull; };
     for (int k = (blockIdx.x * blockDim.x + threadIdx.x) / kDrawLanes; k < count; k += gridDim.x * (blockDim.x / kDrawLanes)) {
         const int idx = v.draw_list[k];
-        if (__hip_atomic_load(&v.skip[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kDrawUndecided) continue;
         const int s = v.pos_of[idx];
         const float4 p = pts[s];
         const float si = score_sorted[s];
         const CellBox bx = make_box(g, p.x, p.y, p.z, nd.rr);
-        bool any_draw = false, lower_kept = false, pending = false;
+        bool any_draw = false, lower = false;
         for (int cz = bx.lo[2]; cz <= bx.hi[2]; ++cz)
             for (int cy = bx.lo[1]; cy <= bx.hi[1]; ++cy) {
                 const int row = (cz * g.dims[1] + cy) * g.dims[0];
@@ -2836,33 +2805,75 @@ __global__ __launch_bounds__(256) void draws_adj_kernel(Batch b) {
                         if (distance < nd.draws_thr) {                                      // hpp:240
                             any_draw = true;
                             const int qi = __float_as_int(q.w);
-                            if (qi < idx) {
-                                const int sq = __hip_atomic_load(&v.skip[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                lower_kept |= sq == kDrawKept;
-                                if (sq == kDrawUndecided) {
-                                    pending = true;
-                                    const int slot = atomicAdd(&adjn[k], 1);
-                                    if (slot < kDrawAdj) adj[(size_t)k * kDrawAdj + slot] = v.prefix[qi];   // its position in the list
-                                }
+                            // a LISTED maximum of lower index (skip[] != 0 since list_match_kernel; decisions of this
+                            // launch change 3 into 1 or 2, never into 0)
+                            if (qi < idx && __hip_atomic_load(&v.skip[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                                lower = true;
+                                const int slot = atomicAdd(&adjn[k], 1);
+                                if (slot < kDrawAdj) adj[(size_t)k * kDrawAdj + slot] = v.prefix[qi];   // its position in the list
                             }
                         }
                     }
                 }
             }
         any_draw = group_any(any_draw);
-        lower_kept = group_any(lower_kept);
-        pending = group_any(pending);
+        lower = group_any(lower);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the group's appends, before lane 0 tags the count
         if (lane != 0) continue;
-        if (lower_kept) {
-            v.flags[idx] = 0;
-            __hip_atomic_store(&v.skip[idx], kDrawDropped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else if (!pending) {
+        if (!lower) {                                                               // hpp:245-248: nobody before it can strike it
             v.flags[idx] = any_draw ? 1 : 0;
             __hip_atomic_store(&v.skip[idx], any_draw ? kDrawKept : kDrawDropped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             if (any_draw) atomicOr(&adjn[k], 1 << 30);
-            atomicAdd(&ds->draws_left[kDrawRounds + 1], 1);
+            atomicAdd(&ds->draws_left[1], 1);
+        }
+    }
+}
+
+// kDrawRounds parallel rounds ON THE ROWS (no geometry): an undecided entry reads the states of the listed neighbors before
+// it -- dropped if one of them is kept (hpp:234), decided if none is undecided any more (hpp:245-248), else it waits.  With
+// the points in arbitrary order a handful of rounds decide nearly everything (the dependency chains are short); in scan
+// order every round peels one front off the plateau and the rest is draws_rest_kernel's.  A round whose predecessor left
+// nothing returns at once.  An entry with more than kDrawAdj neighbors sweeps its neighborhood instead (draws_sweep).
+// (Until r04a these rounds swept the neighborhood of every undecided entry again: 8 x 75 us per 200 k-point view in scan
+// order, against 8 x 6 us.)
+__global__ __launch_bounds__(256) void draws_round_kernel(Batch b, int round) {
+    const ViewDev &v = b.view[blockIdx.y];
+    if (!v.nd.draws_remove) return;
+    DevState *ds = v.ds;
+    if (ds->draws_left[round + 1] == 0) return;              // nothing listed, or everything decided by the rounds before
+    const int count = *v.draw_count;
+    const int *adjn = v.draw_list + v.n, *adj = v.draw_list + draw_adj_offset(v.n);
+    const GridDesc g = ds->grid;
+    const int lane = threadIdx.x & (kDrawLanes - 1), gbase = (threadIdx.x & (kWave - 1)) & ~(kDrawLanes - 1);
+    const unsigned long long gmask = (1ull << kDrawLanes) - 1ull;
+    auto group_any = [&](bool x) { return ((__ballot(x) >> gbase) & gmask) != 0ull; };
+    for (int k = (blockIdx.x * blockDim.x + threadIdx.x) / kDrawLanes; k < count; k += gridDim.x * (blockDim.x / kDrawLanes)) {
+        const int idx = v.draw_list[k];
+        if (__hip_atomic_load(&v.skip[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kDrawUndecided) continue;
+        const int nraw = adjn[k], nadj = nraw & 0xffffff;
+        bool any_draw = ((nraw >> 30) & 1) != 0, lower_kept = false, lower_undecided = false;
+        if (nadj > kDrawAdj) {
+            bool a;
+            draws_sweep<kDrawLanes>(v, g, idx, lane, a, lower_kept, lower_undecided, SkipStates{v.skip});
+        } else {
+            for (int q = lane; q < nadj; q += kDrawLanes) {
+                const int sq = __hip_atomic_load(&v.skip[v.draw_list[adj[(size_t)k * kDrawAdj + q]]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                lower_kept |= sq == kDrawKept;
+                lower_undecided |= sq == kDrawUndecided;
+            }
+        }
+        lower_kept = group_any(lower_kept);
+        lower_undecided = group_any(lower_undecided);
+        if (lane != 0) continue;
+        if (lower_kept) {                                                           // hpp:234: on the skip list
+            v.flags[idx] = 0;
+            __hip_atomic_store(&v.skip[idx], kDrawDropped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (!lower_undecided) {                                              // hpp:245-248
+            v.flags[idx] = any_draw ? 1 : 0;
+            __hip_atomic_store(&v.skip[idx], any_draw ? kDrawKept : kDrawDropped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            atomicAdd(&ds->draws_left[round + 2], 1);
         }
     }
 }
@@ -2946,39 +2957,38 @@ __global__ __launch_bounds__(kRestWaves *kWave) void draws_rest_kernel(Batch b, 
         const bool mine = my_state == kDrawUndecided;
         const int n_mine = my_n & 0xffffff;
         if (in_lds && !__any(mine && n_mine > kDrawAdj)) {
-            // the usual chunk.  Before its turn: the lane's row straight from memory (its first kRowRegs entries in
-            // registers -- nearly always all of them), which neighbors lie inside the chunk, which before it
-            constexpr int kRowRegs = 8;
+            // the usual chunk.  Before its turn: the lane's row straight from memory into registers (16 bytes per load, as
+            // many groups of four as the longest row of the chunk needs), which neighbors lie inside the chunk, which before it
+            constexpr int kGroups = kDrawAdj / 4;
             const int4 *row4 = reinterpret_cast<const int4 *>(adj + (size_t)min(kk, count - 1) * kDrawAdj);     // (16-byte aligned: draw_adj_offset)
-            const int4 ra = row4[0], rb = row4[1];
-            const int rpos[kRowRegs] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+            int longest = mine ? n_mine : 0;
+            for (int off = kWave / 2; off > 0; off >>= 1) longest = max(longest, __shfl_xor(longest, off));
+            const int ngroups = __builtin_amdgcn_readfirstlane((longest + 3) / 4);
+            int before[kDrawAdj];
             unsigned long long inside = 0ull;
-            int before[kRowRegs];
 #pragma unroll
-            for (int q = 0; q < kRowRegs; ++q) {
-                const bool has = mine && q < n_mine;
-                if (has && rpos[q] >= k0) inside |= 1ull << (rpos[q] - k0);
-                before[q] = (has && rpos[q] < k0) ? rpos[q] : -1;
-            }
-            bool more_before = false;
-            if (mine)
-                for (int q = kRowRegs; q < n_mine; ++q) {
-                    const int pos = adj[(size_t)kk * kDrawAdj + q];
-                    if (pos >= k0) inside |= 1ull << (pos - k0);
-                    else more_before = true;
+            for (int gi = 0; gi < kGroups; ++gi) {
+                int4 r4 = make_int4(0, 0, 0, 0);
+                if (gi < ngroups) r4 = row4[gi];
+                const int rp[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool has = mine && 4 * gi + e < n_mine;
+                    if (has && rp[e] >= k0) inside |= 1ull << (rp[e] - k0);
+                    before[4 * gi + e] = (has && rp[e] < k0) ? rp[e] : -1;
                 }
+            }
             wait_for_turn(chunk);
-            // its turn: the neighbors before the chunk are decided -- all state reads in flight together
-            int st[kRowRegs];
-#pragma unroll
-            for (int q = 0; q < kRowRegs; ++q) st[q] = state_of(max(before[q], 0));
+            // its turn: the neighbors before the chunk are decided -- the state reads of a group in flight together
             bool kept_before = false;
 #pragma unroll
-            for (int q = 0; q < kRowRegs; ++q) kept_before |= before[q] >= 0 && st[q] == kDrawKept;
-            if (more_before)
-                for (int q = kRowRegs; q < n_mine; ++q) {
-                    const int pos = adj[(size_t)kk * kDrawAdj + q];
-                    if (pos < k0) kept_before |= state_of(pos) == kDrawKept;
+            for (int gi = 0; gi < kGroups; ++gi)
+                if (gi < ngroups) {
+                    int st[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) st[e] = state_of(max(before[4 * gi + e], 0));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) kept_before |= before[4 * gi + e] >= 0 && st[e] == kDrawKept;
                 }
             // (a neighbor inside the chunk may have been decided by its own group while the adjacency pass listed it: kept
             // already, it strikes the entries that wait for it here)
@@ -3551,7 +3561,7 @@ __global__ __launch_bounds__(256) void list_match_kernel(Batch b, int match) {
     int *list = v.draw_list, *count = v.draw_count;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) *count = prefix[n];
-    if (i <= kDrawRounds + 1) v.ds->draws_left[i] = i == 0 ? prefix[n] : 0; // the draws pass of this call (draws_round_kernel)
+    if (i <= kDrawRounds + 1) v.ds->draws_left[i] = i == 0 ? prefix[n] : 0; // the draws pass of this call: [0] listed, [1] left by draws_adj_kernel, [r + 2] by round r
     if (i < n && flags[i] == match) {
         list[prefix[i]] = i;
         list[n + prefix[i]] = 0;                                              // adjacency count (draws_adj_kernel)
@@ -3871,8 +3881,8 @@ void launch_post(const Batch &b, hipStream_t st) {
             list_match_kernel<<<dim3(div_up(n, 256), nv), 256, 0, st>>>(b, 2);
             int dblocks = div_up(n, 256 / kDrawLanes);
             if (dblocks > 256) dblocks = 256;
-            for (int r = 0; r < kDrawRounds; ++r) draws_round_kernel<<<dim3(dblocks, nv), 256, 0, st>>>(b, r);
             draws_adj_kernel<<<dim3(dblocks, nv), 256, 0, st>>>(b);
+            for (int r = 0; r < kDrawRounds; ++r) draws_round_kernel<<<dim3(dblocks, nv), 256, 0, st>>>(b, r);
             int lds_words = div_up(n, 16);                                    // 2 bits of state per listed maximum
             if (lds_words > 20 * 1024) lds_words = 20 * 1024;                 // 80 KB of states (327 k listed maxima) + 8 x 8 KB of rows
             draws_rest_kernel<<<dim3(1, nv), kRestWaves * kWave,
