@@ -128,12 +128,22 @@ def main():
     args = ap.parse_args()
     repeats = max(1, args.repeats)
 
-    import torch
-    import torch.distributed as dist
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # N > 1: every rank process onto the CPUs next to ITS GPU, before the first HIP call of the process (sysfs only)
+    affinity = None
+    if world > 1:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("kpl_dist_early", os.path.join(ROOT, "keypoint-learning_amd", "dist.py"))
+        # (dist.py imports torch, not torch.cuda: importing torch does not initialise the GPU)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        affinity = mod.pin_to_gpu_numa(local_rank)
+
+    import torch
+    import torch.distributed as dist
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     local_rank %= torch.cuda.device_count()      # (only matters for the 1-GPU gloo smoke run)
@@ -306,8 +316,12 @@ def main():
         rep_enq.append(t_enq - t0)
     timing = dets[0].getTiming()
     dets[0].enableTiming(False)
-    if use_dist:        # every repetition: the slowest rank counts
+    per_rank = None
+    if use_dist:        # every repetition: the slowest rank counts; every rank's own times travel too
         tt = torch.tensor(rep_s, dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        allt = [torch.empty_like(tt) for _ in range(world)]
+        dist.all_gather(allt, tt)
+        per_rank = [[float(x) for x in t.tolist()] for t in allt]
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         rep_s = [float(x) for x in tt.tolist()]
     order = sorted(range(repeats), key=lambda k: rep_s[k])
@@ -574,6 +588,12 @@ def main():
                        "exchange": ("one all-gather of the packed keypoint lists per step (%s)" %
                                     ("RCCL" if args.backend == "nccl" else args.backend)) if use_dist else "none (one rank)"},
             "repeats": {"n": repeats, "reported": "median", "ms_per_step": [round(x * 1e3 / args.steps, 5) for x in rep_s]},
+            # N > 1: the median repetition's ms per step of EVERY rank (the reported one is their maximum), the size of the
+            # RCCL communicator the gathers ran in, and where rank 0's process was pinned before its first HIP call
+            "per_rank_ms_per_step": [round(r[med] * 1e3 / args.steps, 5) for r in per_rank] if per_rank else None,
+            "collective": {"backend": "RCCL" if args.backend == "nccl" else args.backend, "world_size": dist.get_world_size()}
+            if use_dist else None,
+            "cpu_affinity": affinity,
             # SURVEY 8(d) contract figure: gather-model bytes of the dominant kernel / its launch time / 8 TB/s (most of
             # those bytes are L1 / L2 hits: the HBM traffic by counters is hbm_counter_frac of peak).  `bound` is set from
             # counters of exactly these kernel sources (profiles/counters.json, matched by hash; null when stale):

@@ -8,6 +8,50 @@ import torch
 import torch.distributed as dist
 
 
+def pin_to_gpu_numa(local_rank):
+    """Binds the calling process to the CPUs of the NUMA node its GPU hangs off -- BEFORE anything touches the GPU (no HIP
+    call, no torch.cuda call: the rank processes of an 8-GPU node otherwise start on whatever cores the launcher left them
+    and enqueue across the socket interconnect).  The GPU's PCI address comes from the KFD topology in sysfs (GPU nodes in
+    enumeration order = HIP device order; HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES given as a list of integers are
+    honoured), its CPUs from the PCI device's local_cpulist.  Best effort: returns a dict for the bench line
+    ({"numa_node": k, "cpus": n, "pci": "0000:..."}) or {"skipped": reason}; never raises."""
+    import glob
+    import os
+    try:
+        nodes = []
+        for d in sorted(glob.glob("/sys/class/kfd/kfd/topology/nodes/*"), key=lambda x: int(os.path.basename(x))):
+            props = dict(line.split()[:2] for line in open(os.path.join(d, "properties")) if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0 and int(props.get("vendor_id", "0")) != 0:      # a GPU node
+                nodes.append(props)
+        order = list(range(len(nodes)))
+        for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES"):
+            val = os.environ.get(var)
+            if val:
+                try:
+                    order = [order[int(x)] for x in val.split(",") if x.strip() != ""]
+                except (ValueError, IndexError):
+                    return {"skipped": "%s=%s is not a list of device ordinals" % (var, val)}
+        if not order:
+            return {"skipped": "no GPU node in the KFD topology"}
+        props = nodes[order[local_rank % len(order)]]
+        loc, dom = int(props["location_id"]), int(props.get("domain", "0"))
+        pci = "%04x:%02x:%02x.%d" % (dom, (loc >> 8) & 0xff, (loc >> 3) & 0x1f, loc & 7)
+        base = "/sys/bus/pci/devices/" + pci
+        cpus = set()
+        for part in open(base + "/local_cpulist").read().strip().split(","):
+            if part:
+                a, _, b = part.partition("-")
+                cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)             # never outside what the launcher / cgroup allows
+        if not cpus:
+            return {"skipped": "no usable CPU local to %s" % pci}
+        os.sched_setaffinity(0, cpus)
+        numa = int(open(base + "/numa_node").read().strip())
+        return {"numa_node": numa, "cpus": len(cpus), "pci": pci}
+    except (OSError, KeyError, ValueError) as e:
+        return {"skipped": "%s: %s" % (type(e).__name__, e)}
+
+
 def shard(n_items, world, rank):
     """Round-robin assignment of `n_items` independent views to `world` ranks."""
     return list(range(rank, n_items, world))

@@ -102,3 +102,14 @@ def test_slab_plan_covers_every_finite_point_once_and_keeps_halos():
     for p, k in zip(plans, kps):
         mine = p["idx"][k[p["interior"][k]]]
         assert np.isin(mine, kp).all()
+
+
+def test_pin_to_gpu_numa_is_best_effort():
+    """no GPU here: the helper reports why it did nothing, leaves the affinity alone and never raises"""
+    kd = importlib.import_module("keypoint-learning_amd.dist")
+    before = os.sched_getaffinity(0)
+    out = kd.pin_to_gpu_numa(0)
+    assert isinstance(out, dict) and (("skipped" in out) != ("numa_node" in out))
+    if "skipped" in out:
+        assert os.sched_getaffinity(0) == before
+    os.sched_setaffinity(0, before)

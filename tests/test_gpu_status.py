@@ -109,3 +109,19 @@ def test_fuzz_31337_regression(kpl, oracle, cases):
         _, sc = det.compute()
         assert cases.same_bits(sc, o_scores), "iteration %d: scores differ" % it
         assert np.array_equal(det.getKeypointsIndices(), o_kp), "iteration %d: keypoints differ" % it
+
+
+def test_rank_process_is_pinned_next_to_its_gpu():
+    """bench.py --gpus N pins every rank to the CPUs local to its GPU before the first HIP call (sysfs only): on the GPU box
+    the helper finds the KFD node of device 0, its PCI address and a non-empty CPU set inside the allowed one"""
+    code = ("import importlib.util, os, json; spec = importlib.util.spec_from_file_location('d', %r); "
+            "m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m); a = os.sched_getaffinity(0); "
+            "o = m.pin_to_gpu_numa(0); print(json.dumps([o, len(a), len(os.sched_getaffinity(0))]))"
+            % os.path.join(ROOT, "keypoint-learning_amd", "dist.py"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    info, before, after = json.loads(out.stdout.strip().splitlines()[-1])
+    assert "numa_node" in info or "skipped" in info
+    if "numa_node" in info:
+        assert info["cpus"] == after and 0 < after <= before and info["pci"].count(":") == 2
