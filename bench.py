@@ -25,6 +25,7 @@ before timing counts and (b) as the timed `cpu_baseline` -- never on the measure
 import argparse
 import hashlib
 import importlib
+import importlib.util
 import json
 import os
 import sys
@@ -134,7 +135,6 @@ def main():
     # N > 1: every rank process onto the CPUs next to ITS GPU, before the first HIP call of the process (sysfs only)
     affinity = None
     if world > 1:
-        import importlib.util
         spec = importlib.util.spec_from_file_location("kpl_dist_early", os.path.join(ROOT, "keypoint-learning_amd", "dist.py"))
         # (dist.py imports torch, not torch.cuda: importing torch does not initialise the GPU)
         mod = importlib.util.module_from_spec(spec)
