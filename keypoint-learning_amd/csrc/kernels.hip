@@ -1130,12 +1130,10 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts, co
 // ---------------------------------------------------------------------------------------------
 constexpr int kSortGroup = 4;
 constexpr int kSortWords = 8;        // accept words per point between two collect rounds
-constexpr int kSortBucketsLds = 32;  // = kSmallBuckets (sort_key_lists): counters per point
 
 template <int G>
 __host__ __device__ inline size_t sorted_lds_bytes(int F, int ecap, int lcap) {
-    return (sizeof(float) * (size_t)F + sizeof(uint2) * (size_t)ecap + sizeof(unsigned long long) * (size_t)lcap +
-            sizeof(int) * (size_t)kSortBucketsLds) * (size_t)(kLanes / G);
+    return (sizeof(float) * (size_t)F + sizeof(uint2) * (size_t)ecap + sizeof(unsigned long long) * (size_t)lcap) * (size_t)(kLanes / G);
 }
 
 // the rows of cells of a point's search box, walked by the G lanes of its group together (the search phase of
@@ -1225,70 +1223,91 @@ struct RowSearch {
     }
 };
 
-// Ascending sort of every point's key list (keys[e * kPts + point], cnt <= G * E keys) by the G lanes of its group: one
-// counting pass over kSmallBuckets buckets LINEAR IN d2 (a surface has about equally many neighbors per unit of d2: two keys
-// per bucket at K_f = 70), then every lane orders the keys of its kSmallBuckets / G consecutive buckets -- one contiguous
-// piece of the list -- by insertion.  Lane g holds the keys g, g + G, ... in registers while the list is rewritten in place.
-//   hist[b * kPts + point]   counts, then the buckets' cursors
-// ~600 instructions per wave at K_f = 70 against ~2 500 for the bitonic network over 128 (virtually padded) keys that did
-// this until r04 -- whose 64 + 64 key registers and pinned comparators also capped the kernel at 2 waves per SIMD.  Many
-// equal distances (lattices) put more keys into a bucket and the insertion takes longer; the order is the same.
-constexpr int kSmallBuckets = 32;
-
-template <int CTRL>
-__device__ __forceinline__ int quad_bcast(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, true); }
+// Ascending sort of every point's key list (keys[e * kPts + point], cnt <= G * E keys) by the G lanes of its group, in
+// REGISTERS: lane g holds the elements g E .. g E + E - 1 (the list is padded with +infinity to N = G E), and the whole
+// bitonic network runs on them -- all comparators ascending (the first step of a merge pairs an element with its mirror
+// image in the block), comparators inside a lane are a 64-bit compare and four selects on fixed registers, comparators
+// across lanes fetch the partner's element with two DPP moves (quad_perm: the lanes of a group are a quad).  No LDS
+// traffic, no index arithmetic: ~2.5 k instructions per wave at E = 32 against ~6-16 k for the same network walked
+// over the lists in LDS (profiles/r03_notes.md).
+template <int MASK>
+__device__ __forceinline__ unsigned long long quad_fetch(unsigned long long x) {
+    static_assert(MASK >= 1 && MASK <= 3, "partner inside the quad");
+    constexpr int ctrl = MASK == 1 ? 0xB1 : MASK == 2 ? 0x4E : 0x1B;      // quad_perm [1,0,3,2] / [2,3,0,1] / [3,2,1,0]
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)x, ctrl, 0xf, 0xf, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(x >> 32), ctrl, 0xf, 0xf, true);
+    return ((unsigned long long)hi << 32) | lo;
+}
 
 template <int G, int E>
-__device__ __forceinline__ void sort_key_lists(unsigned long long *keys, int *hist, int pi, int gq, int cnt, float lo_d2, float hi_d2) {
+__device__ __forceinline__ void sort_key_lists(unsigned long long *keys, int pi, int gq, int cnt) {
     static_assert(G == 4, "the lanes of a group are a DPP quad");
-    constexpr int kPts = kLanes / G, NB = kSmallBuckets, BPL = NB / G;
-    const float span = hi_d2 - lo_d2;
-    const float scale = span > 0.0f ? (float)NB / span : 0.0f;
-    // monotonic in d2: float subtract, multiply by a positive constant, truncate, clamp
-    auto bucket_of = [&](unsigned long long k) -> int {
-        const float t = (__uint_as_float((unsigned)(k >> 32)) - lo_d2) * scale;
-        return min(max((int)t, 0), NB - 1);
-    };
-    wave_lds_fence();
-#pragma unroll
-    for (int k = 0; k < BPL; ++k) hist[(gq * BPL + k) * kPts + pi] = 0;
-    wave_lds_fence();
+    constexpr int kPts = kLanes / G, N = G * E;
     unsigned long long r[E];
+    wave_lds_fence();
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        const int idx = gq + G * e;
+        const int idx = gq * E + e;
         r[e] = idx < cnt ? keys[idx * kPts + pi] : ~0ull;
-        if (idx < cnt) atomicAdd(&hist[bucket_of(r[e]) * kPts + pi], 1);
     }
-    wave_lds_fence();
-    int local[BPL], sum = 0;
+    // (the empty asm statements pin every comparator's results in place, in program order: left alone the scheduler
+    // overlaps dozens of comparators and needs 250-300 registers for a network that lives in 64)
+    auto inside = [](unsigned long long &a, unsigned long long &b) {          // a <- min, b <- max
+        const bool sw = b < a;
+        const unsigned long long lo = sw ? b : a, hi = sw ? a : b;
+        a = lo;
+        b = hi;
+        asm volatile("" : "+v"(a), "+v"(b));
+    };
+    auto across = [](unsigned long long mine, unsigned long long other, bool upper) {   // the lower lane keeps the minimum
+        const bool lt = other < mine;
+        unsigned long long res = (lt != upper) ? other : mine;
+        asm volatile("" : "+v"(res));
+        return res;
+    };
 #pragma unroll
-    for (int k = 0; k < BPL; ++k) {
-        local[k] = hist[(gq * BPL + k) * kPts + pi];
-        sum += local[k];
-    }
-    // first position of the lane's buckets: the totals of the lanes before it in the quad
-    const int t0 = quad_bcast<0x00>(sum), t1 = quad_bcast<0x55>(sum), t2 = quad_bcast<0xAA>(sum);
-    const int a0 = (gq > 0 ? t0 : 0) + (gq > 1 ? t1 : 0) + (gq > 2 ? t2 : 0), a1 = a0 + sum;
-    int run = a0;
+    for (int k = 2; k <= N; k <<= 1) {
+        if (k <= E) {                                   // merge step 1 inside the lane: i against its mirror image
 #pragma unroll
-    for (int k = 0; k < BPL; ++k) {
-        hist[(gq * BPL + k) * kPts + pi] = run;                  // the bucket's cursor
-        run += local[k];
-    }
-    wave_lds_fence();
+            for (int blk = 0; blk < E; blk += k)
 #pragma unroll
-    for (int e = 0; e < E; ++e)                                  // (every key is in a register: the list may be overwritten)
-        if (gq + G * e < cnt) keys[atomicAdd(&hist[bucket_of(r[e]) * kPts + pi], 1) * kPts + pi] = r[e];
-    wave_lds_fence();
-    for (int i = a0 + 1; i < a1; ++i) {                          // the lane's piece of the list, by insertion
-        const unsigned long long x = keys[i * kPts + pi];
-        int j = i - 1;
-        while (j >= a0 && keys[j * kPts + pi] > x) {
-            keys[(j + 1) * kPts + pi] = keys[j * kPts + pi];
-            --j;
+                for (int off = 0; off < k / 2; ++off) inside(r[blk + off], r[blk + k - 1 - off]);
+        } else {                                        // ... across lanes: partner lane g ^ (k / E - 1), its element E - 1 - e
+            const bool upper = (gq & (k / E / 2)) != 0;
+#pragma unroll
+            for (int e = 0; e < E / 2; ++e) {
+                unsigned long long o1, o2;
+                if (k / E - 1 == 1) {
+                    o1 = quad_fetch<1>(r[E - 1 - e]);
+                    o2 = quad_fetch<1>(r[e]);
+                } else {
+                    o1 = quad_fetch<3>(r[E - 1 - e]);
+                    o2 = quad_fetch<3>(r[e]);
+                }
+                r[e] = across(r[e], o1, upper);
+                r[E - 1 - e] = across(r[E - 1 - e], o2, upper);
+            }
         }
-        keys[(j + 1) * kPts + pi] = x;
+#pragma unroll
+        for (int j = k / 4; j > 0; j >>= 1) {
+            if (j < E) {
+#pragma unroll
+                for (int a = 0; a < E; ++a)
+                    if ((a & j) == 0) inside(r[a], r[a + j]);
+            } else {                                    // partner lane g ^ (j / E), the same element
+                const bool upper = (gq & (j / E)) != 0;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const unsigned long long o = j / E == 1 ? quad_fetch<1>(r[e]) : quad_fetch<2>(r[e]);
+                    r[e] = across(r[e], o, upper);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int idx = gq * E + e;
+        if (idx < cnt) keys[idx * kPts + pi] = r[e];
     }
     wave_lds_fence();
 }
@@ -1321,8 +1340,6 @@ __device__ __forceinline__ int point_features_sorted(const float4 *__restrict__ 
                                                      const FeatDesc &fin, float4 p, float4 np, float *H, uint2 *ent, int ecap,
                                                      unsigned long long *keys, int lcap, bool active) {
     constexpr int kPts = kLanes / G;
-    static_assert(kSortBucketsLds == kSmallBuckets, "LDS layout of the sorted-search kernels");
-    int *hist = reinterpret_cast<int *>(keys + (size_t)lcap * kPts);      // [kSmallBuckets x kPts], behind the key lists
     const int tid = threadIdx.x, pi = tid / G, gq = tid % G;
     FeatDesc f;
     f.A = pin_i(fin.A);
@@ -1430,12 +1447,8 @@ __device__ __forceinline__ int point_features_sorted(const float4 *__restrict__ 
             }
             if (rs.exhausted()) break;
         }
-        // ---- sort the lists: the keys of the pass lie in [lo, hi)
-        {
-            const float lo_d2 = __uint_as_float((unsigned)(lo >> 32));
-            const float hi_d2 = (hi & 0xffffffffull) ? __uint_as_float((unsigned)(hi >> 32) + 1u) : __uint_as_float((unsigned)(hi >> 32));
-            sort_key_lists<G, kSortedListKeys / G>(keys, hist, pi, gq, cnt, lo_d2, fmaxf(hi_d2, lo_d2));
-        }
+        // ---- sort the lists (the one place where the network is instantiated)
+        sort_key_lists<G, kSortedListKeys / G>(keys, pi, gq, cnt);
         // ---- add the neighbors in order, G per round; hpp:336: element 0 of the whole order is dropped
         {
             struct Next {
@@ -3668,8 +3681,6 @@ static int cu_count() {
 // Fewer words for the largest histograms so that a handful of waves still fit a CU (160 KB of LDS).
 constexpr int kLdsPerCu = 160 * 1024;
 static int accept_words(int F) {
-    static const int forced = getenv("KPL_EXP_ECAP") ? atoi(getenv("KPL_EXP_ECAP")) : 0;      // (experiments only)
-    if (forced > 0) return forced;
     int e = 24;
     while (e > 4 && feature_lds_bytes<kGroup>(F, e) * 6 > (size_t)kLdsPerCu) e -= 4;
     return e;
