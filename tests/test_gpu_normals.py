@@ -168,3 +168,15 @@ def test_organized_normals_on_device_buffers_in_pcl_layouts(kpl, oracle):
     assert same_nan(out[:, :3], o_nrm)
     assert np.isnan(out[:, 4]).all()                                   # curvature
     assert (out[:, 3] == 7.0).all() and (out[:, 5:] == 7.0).all()       # nothing else of the records is touched
+
+
+def test_organized_normals_equal_the_committed_golden(kpl):
+    """the device kernels against tests/golden/organized_case.npz (tools/make_organized_golden.py; README item 6)"""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "organized_case.npz"))
+    from tests.test_oracle_organized_normals import same_bits
+    det = kpl.KeypointLearningDetector()
+    W, H = int(z["width"]), int(z["height"])
+    for name in ("origin", "off"):
+        nrm, curv = det.estimateNormalsOrganized(z["xyz"], W, H, float(z["smoothing"]), tuple(float(x) for x in z["viewpoint_" + name]))
+        assert same_bits(nrm, z["normals_" + name]) and np.isnan(curv).all()

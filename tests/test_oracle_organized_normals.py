@@ -152,3 +152,17 @@ def test_too_small_or_empty_images_are_all_nan():
     assert np.isnan(nrm).all() and np.isnan(curv).all()
     nrm, _ = kplo.integral_image_normals(np.zeros((0, 3), np.float32), 0, 0, 5.0)
     assert nrm.shape == (0, 3)
+
+
+def test_oracle_reproduces_the_committed_organized_golden():
+    """tests/golden/organized_case.npz (tools/make_organized_golden.py): the array a PCL 1.8 run must reproduce; the oracle
+    and -- tests/test_gpu_normals.py -- the device kernels are held to it bit for bit"""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "organized_case.npz"))
+    W, H = int(z["width"]), int(z["height"])
+    for name in ("origin", "off"):
+        nrm, curv = kplo.integral_image_normals(z["xyz"], W, H, float(z["smoothing"]), tuple(float(x) for x in z["viewpoint_" + name]))
+        assert same_bits(nrm, z["normals_" + name]) and np.isnan(curv).all()
+    fin = np.isfinite(z["normals_origin"]).all(axis=1)
+    assert 0.5 < fin.mean() < 0.98                       # borders, holes and the depth step are left without a normal
+    assert not np.array_equal(z["normals_origin"][fin], z["normals_off"][fin])       # the viewpoint flips some of them
