@@ -512,7 +512,7 @@ def main():
     iso_ms = max(t_iso["feature_ms"] / max(t_iso["calls"], 1), 1e-9) if t_iso else None
     # measured counters of exactly these kernels (rocprofv3, profiles/counters.json) -- or null
     prof, why_not = load_profile(nb)
-    traffic = valu_busy = ta_busy = hbm_counter_frac = waves_per_simd = valu_issue_frac = valu_model = None
+    traffic = valu_busy = ta_busy = hbm_counter_frac = waves_per_simd = valu_issue_frac = valu_model = lane_frac = None
     forest_prof = None
     if prof:
         pk = prof["kernels"].get("feature_kernel", {})
@@ -522,6 +522,7 @@ def main():
         waves_per_simd = pk.get("waves_per_simd")
         valu_issue_frac = pk.get("valu_issue_frac")
         valu_model = pk.get("valu_model")
+        lane_frac = pk.get("valu_active_lane_frac")
         forest_prof = prof["kernels"].get("forest_kernel")
         if traffic and feat_ms > 0:
             hbm_counter_frac = round(traffic / (feat_ms * 1e-3) / HBM_PEAK, 5)
@@ -608,7 +609,7 @@ def main():
                          "valu_issue_model": {k: valu_model[k] for k in ("valu_issue_frac_bounds", "class_cycles_per_instruction",
                                                                          "avg_cycles_per_instruction_at_ceiling", "static_fast_share")}
                          if valu_model else None,
-                         "valu_busy": valu_busy, "ta_busy": ta_busy, "hbm_counter_frac": hbm_counter_frac,
+                         "valu_busy": valu_busy, "valu_active_lane_frac": lane_frac, "ta_busy": ta_busy, "hbm_counter_frac": hbm_counter_frac,
                          "waves_per_simd": waves_per_simd,
                          "counters": {"file": "profiles/counters.json", "source_sha256": kernel_source_sha256()[:16],
                                       "matches_these_kernels": prof is not None, "note": why_not},

@@ -205,11 +205,27 @@ protected:
         // pcl::Keypoint::initCompute (hpp:119) restated WITHOUT its search tree: PCL's version allocates a
         // pcl::search::KdTree and builds a FLANN index over the whole cloud on the host at every compute() --
         // tens of milliseconds that this engine, which searches its own index on the device, would never use.
+        // What of it survives: pcl::PCLBase::initCompute (the input must be set; the (fake) indices are set up, so
+        // getIndices() answers as it does in the reference), the radius / K checks with PCL's own messages, the reset of
+        // keypoints_indices_.  tree_ stays whatever the caller set with setSearchMethod (only its getSortedResults() is
+        // looked at); getSearchMethod() of a detector nobody gave a tree returns null and searchForNeighbors() is not
+        // served -- INTEGRATION.md, section A.
+#ifdef KPL_USE_PCL
+        if (!pcl::PCLBase<PointInT>::initCompute()) {
+            PCL_ERROR("[pcl::%s::initCompute] init failed!\n", this->name_.c_str());
+            return false;
+        }
+#endif
         if (!this->input_) {
             PCL_ERROR("[pcl::%s::initCompute] init failed!\n", this->name_.c_str());
             return false;
         }
         if (!this->surface_) this->surface_ = this->input_;
+        if (this->search_radius_ == 0.0 && this->k_ == 0) {
+            PCL_ERROR("[pcl::%s::initCompute] Neither radius nor K defined! Set one of them to a positive value (using setRadiusSearch or setKSearch) and then re-run compute ().\n",
+                      this->name_.c_str());
+            return false;
+        }
         if (this->search_radius_ != 0.0 && this->k_ != 0) {
             PCL_ERROR("[pcl::%s::initCompute] Both radius (%f) and K (%d) defined! Set one of them to zero first and then re-run compute ().\n",
                       this->name_.c_str(), this->search_radius_, this->k_);

@@ -48,7 +48,7 @@ def main():
                     avg_ns[k] = float(r["AverageNs"])
                     calls[k] = int(r["Calls"])
     pmc = {}
-    for suffix in ("fetch", "write", "sq", "ta", "valu", "lds"):
+    for suffix in ("fetch", "write", "sq", "ta", "valu", "lds", "lanes"):
         agg, meta = summarize(os.path.join(out_dir, "pmc_%s_%s" % (tag, suffix)))
         for k, counters in agg.items():
             for c, vals in counters.items():
@@ -96,6 +96,12 @@ def main():
                            "forest_pair_kernel<false, 2, 5>": "forest_pair_kernelILb0ELi2ELi5"}[k]
                 e["valu_model"] = valu_model.model(c, c.get("GRBM_GUI_ACTIVE_valu", c["GRBM_GUI_ACTIVE"]) / XCDS, ceiling, mangled)
                 e["valu_issue_frac"] = e["valu_model"]["valu_issue_frac"]
+            # enabled lanes per VALU instruction-cycle / 64 (round-3 verdict: what the issue model hides -- lanes that are
+            # masked off or belong to points that have run out of work)
+            if c.get("SQ_THREAD_CYCLES_VALU") is not None and c.get("SQ_INST_CYCLES_VALU"):
+                e["valu_active_lane_frac"] = round(c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_INST_CYCLES_VALU"]), 4)
+            elif c.get("SQ_THREAD_CYCLES_VALU") is not None and c.get("SQ_ACTIVE_INST_VALU"):
+                e["valu_active_lane_frac"] = round(c["SQ_THREAD_CYCLES_VALU"] / (64.0 * 4.0 * c["SQ_ACTIVE_INST_VALU"]), 4)
             if c.get("SQ_LDS_BANK_CONFLICT") is not None and c.get("SQ_ACTIVE_INST_LDS"):
                 # SQ_ACTIVE_INST_LDS / SQ_LDS_BANK_CONFLICT count quad-cycles summed over the SIMDs (MI355X_MICROARCH.md)
                 e["lds_busy"] = round(c["SQ_ACTIVE_INST_LDS"] * 4.0 / (SIMDS * c.get("GRBM_GUI_ACTIVE_lds", c["GRBM_GUI_ACTIVE"]) / XCDS), 4)
@@ -106,6 +112,7 @@ def main():
                             "valu_busy": "SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * GRBM_GUI_ACTIVE / 8): an UPPER bound (4 cycles per instruction)",
                             "valu_issue_frac": "tools/valu_model.py: sum over instruction classes of count x measured issue cycles (tools/valu_ceiling.hip on this box) / (1024 SIMDs x kernel cycles)",
                             "waves_per_simd": "SQ_WAVE_CYCLES * 4 / (1024 SIMDs * GRBM_GUI_ACTIVE / 8)",
+                            "valu_active_lane_frac": "SQ_THREAD_CYCLES_VALU / (64 x SQ_INST_CYCLES_VALU): enabled lanes per VALU instruction cycle",
                             "ta_busy": "TA_BUSY_avr / (GRBM_GUI_ACTIVE / 8): the texture-addresser's busy cycles, average over its instances"},
                "files": [tag + "_kernel_stats.csv", tag + "_pmc.json", tag + "_bench.json", tag + "_valu_ceiling.json"]},
               open(os.path.join(prof, "counters.json"), "w"), indent=1)
