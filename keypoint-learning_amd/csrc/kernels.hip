@@ -1952,8 +1952,11 @@ __device__ __forceinline__ WavePoint wave_point(const ViewDev &a, int chunk, int
 
 // Sorted-search mode: which points take the path for LARGE neighborhoods.  Decided from the index alone -- the number of
 // candidates in the rows of the point's search box (what RowSearch walks), an upper bound of K_f about three times K_f on
-// a surface -- so that every kernel of the stage comes to the same answer without a pass over the points.
-constexpr int kLargeCand = 1024;
+// a surface -- so that every kernel of the stage comes to the same answer without a pass over the points.  512 candidates
+// are ~170 neighbors: up to there the register sort needs two passes at most (with 1 024 the few points of the cheff view at
+// the default radius that stayed below it -- outliers with 200 to 340 neighbors, 3 to 8 passes each -- kept the register-sort
+// kernel running for 0.68 ms after everybody else had left).
+constexpr int kLargeCand = 512;
 __device__ __forceinline__ int box_candidates(const GridDesc &g, const int *__restrict__ cell_start, const float4 &p, float rr) {
     CellBox b = make_box(g, p.x, p.y, p.z, rr);
     b.hi[1] = min(b.hi[1], b.lo[1] + 3);
@@ -2321,7 +2324,7 @@ __global__ __launch_bounds__(kCollectThreads) void sorted_collect_kernel(Batch b
     __shared__ unsigned long long keys[kCollectKeys];
     __shared__ int hist[kCollectBuckets];
     __shared__ int wsum[kCollectThreads / kWave];
-    __shared__ int s_cnt, s_fallback;
+    __shared__ int s_cnt, s_fallback, s_r0[16], s_r1[16];
     __shared__ unsigned long long s_off;
     const ViewDev &v = b.view[blockIdx.y];
     if (!v.f.sorted) return;
@@ -2339,41 +2342,70 @@ __global__ __launch_bounds__(kCollectThreads) void sorted_collect_kernel(Batch b
         CellBox bx = make_box(g, p.x, p.y, p.z, v.f.rr);
         bx.hi[1] = min(bx.hi[1], bx.lo[1] + 3);
         bx.hi[2] = min(bx.hi[2], bx.lo[2] + 3);
-        // the keys of the window [lo, hi) -> keys[] (the first kCollectKeys of them); returns how many there are
+        // the rows of the box once per point: first position and end of each (thread r < 16: row r; empty where the box
+        // has none) -- the walk below reads them from LDS instead of waiting for cell_start[] row after row
+        __syncthreads();
+        if (tid < 16) {
+            const int z = bx.lo[2] + tid / 4, y = bx.lo[1] + tid % 4;
+            const bool valid = z <= bx.hi[2] && y <= bx.hi[1];
+            const int row = valid ? (z * g.dims[1] + y) * g.dims[0] : 0;
+            s_r0[tid] = valid ? cell_start[row + bx.lo[0]] : 0;
+            s_r1[tid] = valid ? cell_start[row + bx.hi[0] + 1] : 0;
+        }
+        __syncthreads();
+        // the keys of the window [lo, hi) -> keys[] (the first kCollectKeys of them); returns how many there are.  The rows are
+        // walked in pieces of 1 024 consecutive candidates (4 per thread, coalesced 16-byte loads); the loads of the next
+        // piece are in flight while the current one is tested
         auto collect = [&](unsigned long long lo, unsigned long long hi) -> int {
             __syncthreads();
             if (tid == 0) s_cnt = 0;
             __syncthreads();
-            for (int z = bx.lo[2]; z <= bx.hi[2]; ++z)
-                for (int y = bx.lo[1]; y <= bx.hi[1]; ++y) {
-                    const int row = (z * g.dims[1] + y) * g.dims[0];
-                    const int r0 = cell_start[row + bx.lo[0]], r1 = cell_start[row + bx.hi[0] + 1];
-                    for (int t0 = r0; t0 < r1; t0 += kCollectThreads * kCollectAhead) {
-                        float4 q[kCollectAhead];
-#pragma unroll
-                        for (int a = 0; a < kCollectAhead; ++a) q[a] = pts[min(t0 + a * kCollectThreads + tid, r1 - 1)];
-                        unsigned long long key[kCollectAhead], bal[kCollectAhead];
-                        bool take[kCollectAhead];
-                        int mine = 0;
-#pragma unroll
-                        for (int a = 0; a < kCollectAhead; ++a) {
-                            const float d2 = dist2(p.x, p.y, p.z, q[a]);
-                            key[a] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)(unsigned)__float_as_int(q[a].w);
-                            take[a] = t0 + a * kCollectThreads + tid < r1 && d2 < r2 && key[a] >= lo && key[a] < hi;   // strict (KdTreeFLANN)
-                            bal[a] = __ballot(take[a]);
-                            mine += __popcll(bal[a]);
-                        }
-                        int base = 0;
-                        if (lane == 0 && mine > 0) base = atomicAdd(&s_cnt, mine);                // one LDS atomic per wave and step
-                        base = __builtin_amdgcn_readfirstlane(base);
-#pragma unroll
-                        for (int a = 0; a < kCollectAhead; ++a) {
-                            const int slot = base + __popcll(bal[a] & ((1ull << lane) - 1ull));
-                            if (take[a] && slot < kCollectKeys) keys[slot] = key[a];
-                            base += __popcll(bal[a]);
-                        }
-                    }
+            constexpr int kPiece = kCollectThreads * kCollectAhead;
+            int row = -1, t0 = 0, r1 = 0;                    // (uniform) the piece [t0, min(t0 + kPiece, r1)) of row `row`
+            auto advance = [&]() -> bool {
+                t0 += kPiece;
+                while (t0 >= r1) {
+                    if (++row >= 16) return false;
+                    t0 = s_r0[row];
+                    r1 = s_r1[row];
                 }
+                return true;
+            };
+            auto load_piece = [&](float4 (&q)[kCollectAhead]) {
+#pragma unroll
+                for (int a = 0; a < kCollectAhead; ++a) q[a] = pts[min(t0 + a * kCollectThreads + tid, r1 - 1)];
+            };
+            float4 cur[kCollectAhead], nxt[kCollectAhead];
+            bool have = advance();
+            if (have) load_piece(cur);
+            while (have) {
+                const int c_t0 = t0, c_r1 = r1;
+                const bool have_next = advance();
+                if (have_next) load_piece(nxt);
+                unsigned long long key[kCollectAhead], bal[kCollectAhead];
+                bool take[kCollectAhead];
+                int mine = 0;
+#pragma unroll
+                for (int a = 0; a < kCollectAhead; ++a) {
+                    const float d2 = dist2(p.x, p.y, p.z, cur[a]);
+                    key[a] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)(unsigned)__float_as_int(cur[a].w);
+                    take[a] = c_t0 + a * kCollectThreads + tid < c_r1 && d2 < r2 && key[a] >= lo && key[a] < hi;   // strict (KdTreeFLANN)
+                    bal[a] = __ballot(take[a]);
+                    mine += __popcll(bal[a]);
+                }
+                int base = 0;
+                if (lane == 0 && mine > 0) base = atomicAdd(&s_cnt, mine);                // one LDS atomic per wave and piece
+                base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+                for (int a = 0; a < kCollectAhead; ++a) {
+                    const int slot = base + __popcll(bal[a] & ((1ull << lane) - 1ull));
+                    if (take[a] && slot < kCollectKeys) keys[slot] = key[a];
+                    base += __popcll(bal[a]);
+                }
+#pragma unroll
+                for (int a = 0; a < kCollectAhead; ++a) cur[a] = nxt[a];
+                have = have_next;
+            }
             __syncthreads();
             return s_cnt;
         };
@@ -2517,21 +2549,16 @@ __global__ __launch_bounds__(kCollectThreads) void sorted_collect_kernel(Batch b
     }
 }
 
-// the feature loop (hpp:334-359) of the large points over their sorted segments; writes their columns of the feature block
-template <bool STATS>
-__global__ __launch_bounds__(kLanes) void sorted_add_kernel(Batch b, int maxF) {
-    extern __shared__ float H[];
-    constexpr int G = 2, kPts = kLanes / G;
-    const ViewDev &v = b.view[blockIdx.y];
-    if (!v.f.sorted) return;
-    if (v.ds->large_count == 0) return;
-    const int chunk = blockIdx.x / G, pi = threadIdx.x / G, gq = threadIdx.x % G;
-    const int col = (blockIdx.x % G) * kPts + pi;
-    if (chunk * kLanes + col - pi >= v.n) return;
-    const WavePoint w = wave_point(v, chunk, col, true);
-    const bool large = is_large_point(v.ds->grid, v.cell_start, w, v.f.rr);
-    if (!__any(large)) return;
-    if (v.ds->status != kStatusOk) return;                        // (segments incomplete: the call fails, kpl_sync_status)
+// the feature loop (hpp:334-359) of the large points over their sorted segments; writes their columns of the feature block.
+// Persistent waves over ViewDev::large_list, G lanes per point: two when the large points alone fill the chip, four when
+// they are few (a 63 k-point view with 2 300 neighbors per point is 2 000 waves of two lanes per point -- two per SIMD,
+// each alive for the whole kernel; four lanes per point are twice the waves and half the rounds per wave).
+constexpr int kAddWideBelow = 160 * 1024;       // large points of a view below which four lanes take a point
+
+template <bool STATS, int G>
+__device__ __forceinline__ void sorted_add_points(const ViewDev &v, float *H, int nlarge) {
+    constexpr int kPts = kLanes / G;
+    const int pi = threadIdx.x / G, gq = threadIdx.x % G;
     FeatDesc f;
     f.A = pin_i(v.f.A);
     f.B = pin_i(v.f.B);
@@ -2547,39 +2574,43 @@ __global__ __launch_bounds__(kLanes) void sorted_add_kernel(Batch b, int maxF) {
     f.bin_rdim = pin_f(v.f.bin_rdim);
     f.r2 = pin_f(v.f.r2);
     f.rr = v.f.rr;
-    for (int c = gq; c < f.F; c += G) H[c * kPts + pi] = 0.0f;                     // hpp:325
-    wave_lds_fence();
-    const int len = large ? v.seg_len[w.s] : 0;
-    const unsigned long long *seg = v.sort_keys + (large ? v.seg_start[w.s] : 0u);
     const char *__restrict__ nrmsrc = v.nrmsrc;
     const unsigned ns = v.ns;
-    const float4 np = w.np;
     const int col_address = lds_address(H + pi);
-    if (STATS && large && gq == 0) atomicAdd(&v.stats->sum_kf, (unsigned long long)len);
-    // element 0 of the order is dropped (hpp:336); keys two rounds ahead of their use, normals one
-    struct Slot {
-        bool valid;
-        float d2;
-        unsigned orig;
-        f32x3 n;
-    };
-    int k = 1 + gq;
-    auto fetch_key = [&](Slot &slot) {
-        slot.valid = k < len;
-        const unsigned long long key = seg[slot.valid ? k : 0];
-        k += G;
-        slot.d2 = __uint_as_float((unsigned)(key >> 32));
-        slot.orig = slot.valid ? (unsigned)key : 0u;
-    };
-    auto fetch_normal = [&](Slot &slot) { slot.n = *reinterpret_cast<const f32x3 *>(nrmsrc + (size_t)slot.orig * ns); };
-    Slot sa, sb, sc;
-    sa.valid = sb.valid = sc.valid = false;
-    sa.d2 = sb.d2 = sc.d2 = 0.f;
-    sa.orig = sb.orig = sc.orig = 0u;
-    sa.n = sb.n = sc.n = f32x3{0.f, 0.f, 0.f};
-    fetch_key(sa);
-    fetch_key(sb);
-    fetch_normal(sa);
+    for (int first = blockIdx.x * kPts; first < nlarge; first += gridDim.x * kPts) {
+        const bool has_point = first + pi < nlarge;
+        const int s = has_point ? v.large_list[first + pi] : 0;
+        wave_lds_fence();
+        for (int c = gq; c < f.F; c += G) H[c * kPts + pi] = 0.0f;                 // hpp:325
+        wave_lds_fence();
+        const int len = has_point ? v.seg_len[s] : 0;
+        const unsigned long long *seg = v.sort_keys + (has_point ? v.seg_start[s] : 0u);
+        const float4 np = has_point ? v.nrm[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (STATS && has_point && gq == 0) atomicAdd(&v.stats->sum_kf, (unsigned long long)len);
+        // element 0 of the order is dropped (hpp:336); keys two rounds ahead of their use, normals one
+        struct Slot {
+            bool valid;
+            float d2;
+            unsigned orig;
+            f32x3 n;
+        };
+        int k = 1 + gq;
+        auto fetch_key = [&](Slot &slot) {
+            slot.valid = k < len;
+            const unsigned long long key = seg[slot.valid ? k : 0];
+            k += G;
+            slot.d2 = __uint_as_float((unsigned)(key >> 32));
+            slot.orig = slot.valid ? (unsigned)key : 0u;
+        };
+        auto fetch_normal = [&](Slot &slot) { slot.n = *reinterpret_cast<const f32x3 *>(nrmsrc + (size_t)slot.orig * ns); };
+        Slot sa, sb, sc;
+        sa.valid = sb.valid = sc.valid = false;
+        sa.d2 = sb.d2 = sc.d2 = 0.f;
+        sa.orig = sb.orig = sc.orig = 0u;
+        sa.n = sb.n = sc.n = f32x3{0.f, 0.f, 0.f};
+        fetch_key(sa);
+        fetch_key(sb);
+        fetch_normal(sa);
 #define KPL_LARGE_ROUND(now, nxt, far)                                                             \
     {                                                                                              \
         fetch_key(far);                                                                            \
@@ -2592,31 +2623,45 @@ __global__ __launch_bounds__(kLanes) void sorted_add_kernel(Batch b, int maxF) {
             wave_lds_fence();                                                                      \
         }                                                                                          \
     }
-    // (the loop runs while any lane's CURRENT slot is valid; slots are validated in key order, so a group is done when its is not)
-    while (__any(sa.valid)) {
-        KPL_LARGE_ROUND(sa, sb, sc)
-        if (!__any(sb.valid)) break;
-        KPL_LARGE_ROUND(sb, sc, sa)
-        if (!__any(sc.valid)) break;
-        KPL_LARGE_ROUND(sc, sa, sb)
-    }
-#undef KPL_LARGE_ROUND
-    wave_lds_fence();
-    for (int a = gq; a < f.A; a += G) {                                            // hpp:360-370, one row per lane
-        float *h = H + (a * f.B) * kPts + pi;
-        float ssum = 0.0f;
-        for (int kk = 0; kk < f.B; ++kk) {
-            float x = h[kk * kPts];
-            ssum += x * x;
+        // (slots become invalid in key order: a group is done when its current slot is)
+        while (__any(sa.valid)) {
+            KPL_LARGE_ROUND(sa, sb, sc)
+            if (!__any(sb.valid)) break;
+            KPL_LARGE_ROUND(sb, sc, sa)
+            if (!__any(sc.valid)) break;
+            KPL_LARGE_ROUND(sc, sa, sb)
         }
-        const float nr = sqrtf(ssum);
-        if (nr > 0)
-            for (int kk = 0; kk < f.B; ++kk) h[kk * kPts] = h[kk * kPts] / nr;
+#undef KPL_LARGE_ROUND
+        wave_lds_fence();
+        for (int a = gq; a < f.A; a += G) {                                        // hpp:360-370, one row per lane
+            float *h = H + (a * f.B) * kPts + pi;
+            float ssum = 0.0f;
+            for (int kk = 0; kk < f.B; ++kk) {
+                float x = h[kk * kPts];
+                ssum += x * x;
+            }
+            const float nr = sqrtf(ssum);
+            if (nr > 0)
+                for (int kk = 0; kk < f.B; ++kk) h[kk * kPts] = h[kk * kPts] / nr;
+        }
+        wave_lds_fence();
+        if (has_point) {
+            float *o = v.feat + (size_t)(s / kLanes) * f.F * kLanes + (s % kLanes);
+            for (int c = gq; c < f.F; c += G) o[c * kLanes] = H[c * kPts + pi];
+        }
     }
-    wave_lds_fence();
-    if (!large) return;
-    float *o = v.feat + (size_t)chunk * v.f.F * kLanes + col;
-    for (int c = gq; c < v.f.F; c += G) o[c * kLanes] = H[c * kPts + pi];
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(kLanes) void sorted_add_kernel(Batch b, int maxF) {
+    extern __shared__ float H[];
+    const ViewDev &v = b.view[blockIdx.y];
+    if (!v.f.sorted) return;
+    const int nlarge = v.ds->large_count;
+    if (nlarge == 0) return;
+    if (v.ds->status != kStatusOk) return;                        // (segments incomplete: the call fails, kpl_sync_status)
+    if (nlarge < kAddWideBelow) sorted_add_points<STATS, 4>(v, H, nlarge);
+    else sorted_add_points<STATS, 2>(v, H, nlarge);
 }
 
 // detectKeypoints, hpp:197-256 with draws_remove == false (order-independent predicate):
@@ -3748,7 +3793,9 @@ void launch_feature_stage(const Batch &b, hipStream_t st) {
         int wgs = div_up(cu_count() * 4, b.nviews);             // persistent: four workgroups per CU (37 KB of LDS each)
         if (wgs > n) wgs = n;
         sorted_collect_kernel<<<dim3(wgs, b.nviews), kCollectThreads, 0, st>>>(b);
-        const dim3 agrid(div_up(n, kLanes) * 2, b.nviews);
+        int awgs = div_up(n, kLanes / 4);                         // a wave per 16 points at most, persistent beyond 16 per CU
+        if (awgs > cu_count() * 16) awgs = cu_count() * 16;
+        const dim3 agrid(awgs, b.nviews);
         const size_t alds = sizeof(float) * (size_t)maxF * (kLanes / 2);
         if (stats) sorted_add_kernel<true><<<agrid, kLanes, alds, st>>>(b, maxF);
         else sorted_add_kernel<false><<<agrid, kLanes, alds, st>>>(b, maxF);
