@@ -1334,11 +1334,14 @@ __device__ __forceinline__ int keep_keys_below(unsigned long long *keys, int pi,
     return out;
 }
 
-template <int G>
+// DEFER (the kernel over whole views): a point whose list runs full is not cut into windows here -- it takes no further
+// part, `deferred` comes back true and the caller hands it to the kernels for large neighborhoods (one search wasted, none
+// repeated).  Without DEFER (the sparse query kernel, which has no such kernels behind it) the windows below do the work.
+template <int G, bool DEFER>
 __device__ __forceinline__ int point_features_sorted(const float4 *__restrict__ pts, const char *__restrict__ nrmsrc,
                                                      unsigned ns, const int *__restrict__ cell_start, const GridDesc &g,
                                                      const FeatDesc &fin, float4 p, float4 np, float *H, uint2 *ent, int ecap,
-                                                     unsigned long long *keys, int lcap, bool active) {
+                                                     unsigned long long *keys, int lcap, bool active, bool &deferred) {
     constexpr int kPts = kLanes / G;
     const int tid = threadIdx.x, pi = tid / G, gq = tid % G;
     FeatDesc f;
@@ -1368,6 +1371,7 @@ __device__ __forceinline__ int point_features_sorted(const float4 *__restrict__ 
     // still ends with ALL keys of [lo, hi), and the next pass takes [hi, key_end).
     unsigned long long lo = 0ull, hi = key_end;
     bool dropped = false;                          // hpp:336: element 0 of the whole order has been dropped
+    deferred = false;
     int kf = 0;
     for (int pass = 0;; ++pass) {
         int cnt = 0;                               // keys in the point's list (the same in the lanes of the group)
@@ -1412,8 +1416,14 @@ __device__ __forceinline__ int point_features_sorted(const float4 *__restrict__ 
                     slot.q = pts[tt];
                 };
                 auto collect = [&](Taken &now) {
+                    if (DEFER) {           // no room for the keys of this round: the point leaves (its list is not used any more)
+                        if (cnt > lcap - G) {
+                            deferred = true;
+                            cnt = 0;
+                        }
+                    }
                     // room for the G keys of this round in every list, else: a pivot inside the window, the list filtered
-                    while (__any(cnt > lcap - G)) {
+                    while (!DEFER && __any(cnt > lcap - G)) {
                         if (cnt > lcap - G) {
                             const unsigned lb = (unsigned)(lo >> 32), hb = (unsigned)(hi >> 32);
                             if (hb - lb >= 2u) {           // halve the window in d2 (its values, not its bits: even counts on a surface)
@@ -1429,7 +1439,7 @@ __device__ __forceinline__ int point_features_sorted(const float4 *__restrict__ 
                     }
                     const unsigned long long key = ((unsigned long long)__float_as_uint(dist2(p.x, p.y, p.z, now.q)) << 32) |
                                                    (unsigned long long)(unsigned)__float_as_int(now.q.w);
-                    const bool app = now.valid & (key >= lo) & (key < hi);
+                    const bool app = now.valid & (key >= lo) & (key < hi) & !(DEFER && deferred);
                     const unsigned gb = (unsigned)(__ballot(app) >> group_shift) & ((1u << G) - 1u);
                     if (app) keys[(cnt + __popc(gb & ((1u << gq) - 1u))) * kPts + pi] = key;
                     cnt += __popc(gb);
@@ -2012,8 +2022,13 @@ __global__ __launch_bounds__(kLanes) void feature_sorted_kernel(Batch b, int max
     const bool large = is_large_point(v.ds->grid, v.cell_start, w, v.f.rr);
     uint2 *ent = reinterpret_cast<uint2 *>(H + maxF * kPts);
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(ent + ecap * kPts);
-    const int kf = point_features_sorted<G>(v.pts, v.nrmsrc, v.ns, v.cell_start, v.ds->grid, v.f, w.p, w.np, H, ent, ecap,
-                                            keys, lcap, w.scoreable && !large);
+    bool deferred;
+    const int kf = point_features_sorted<G, true>(v.pts, v.nrmsrc, v.ns, v.cell_start, v.ds->grid, v.f, w.p, w.np, H, ent, ecap,
+                                                  keys, lcap, w.scoreable && !large, deferred);
+    if (deferred) {             // more neighbors than the list holds: one more point for sorted_collect_kernel / sorted_add_kernel
+        if (gq == 0) v.large_list[atomicAdd(&v.ds->large_count, 1)] = w.s;
+        return;
+    }
     if (STATS && w.scoreable && !large && gq == 0) atomicAdd(&v.stats->sum_kf, (unsigned long long)kf);
     if (large) return;
     float *o = v.feat + (size_t)chunk * v.f.F * kLanes + col;
@@ -2280,7 +2295,8 @@ __global__ __launch_bounds__(kLanes) void features_sorted_kernel(const float4 *_
     }
     const float4 p = s >= 0 ? pts[s] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 np = s >= 0 ? nrm[s] : make_float4(0.f, 0.f, 0.f, 0.f);
-    point_features_sorted<G>(pts, nrmsrc, ns, cell_start, g, f, p, np, H, ent, ecap, keys, lcap, s >= 0);
+    bool deferred_unused;
+    point_features_sorted<G, false>(pts, nrmsrc, ns, cell_start, g, f, p, np, H, ent, ecap, keys, lcap, s >= 0, deferred_unused);
     if (qi >= m) return;
     float *o = out + (size_t)qi * f.F;
     for (int c = gq; c < f.F; c += G) o[c] = s >= 0 ? H[c * kPts + pi] : NAN;
@@ -2361,6 +2377,7 @@ __global__ __launch_bounds__(kCollectThreads) void sorted_collect_kernel(Batch b
             if (tid == 0) s_cnt = 0;
             __syncthreads();
             constexpr int kPiece = kCollectThreads * kCollectAhead;
+            const bool whole = lo == 0ull && hi == key_end;  // (the usual call: no window to test the keys against)
             int row = -1, t0 = 0, r1 = 0;                    // (uniform) the piece [t0, min(t0 + kPiece, r1)) of row `row`
             auto advance = [&]() -> bool {
                 t0 += kPiece;
@@ -2389,7 +2406,8 @@ __global__ __launch_bounds__(kCollectThreads) void sorted_collect_kernel(Batch b
                 for (int a = 0; a < kCollectAhead; ++a) {
                     const float d2 = dist2(p.x, p.y, p.z, cur[a]);
                     key[a] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)(unsigned)__float_as_int(cur[a].w);
-                    take[a] = c_t0 + a * kCollectThreads + tid < c_r1 && d2 < r2 && key[a] >= lo && key[a] < hi;   // strict (KdTreeFLANN)
+                    take[a] = c_t0 + a * kCollectThreads + tid < c_r1 && d2 < r2;                  // strict (KdTreeFLANN)
+                    if (!whole) take[a] = take[a] && key[a] >= lo && key[a] < hi;
                     bal[a] = __ballot(take[a]);
                     mine += __popcll(bal[a]);
                 }
@@ -2423,12 +2441,18 @@ __global__ __launch_bounds__(kCollectThreads) void sorted_collect_kernel(Batch b
             for (int k = tid; k < kCollectBuckets; k += kCollectThreads) hist[k] = 0;
             if (tid == 0) s_fallback = 0;
             __syncthreads();
+            const int nper = (cnt + kCollectThreads - 1) / kCollectThreads;      // (uniform) rounds of the list that hold keys
             unsigned long long mykey[kPer];
 #pragma unroll
             for (int j = 0; j < kPer; ++j) {
-                const int i = tid + j * kCollectThreads;
-                mykey[j] = i < cnt ? keys[i] : ~0ull;
-                if (i < cnt) atomicAdd(&hist[bucket_of(mykey[j])], 1);
+                mykey[j] = ~0ull;
+                if (j < nper) {
+                    const int i = tid + j * kCollectThreads;
+                    if (i < cnt) {
+                        mykey[j] = keys[i];
+                        atomicAdd(&hist[bucket_of(mykey[j])], 1);
+                    }
+                }
             }
             __syncthreads();
             // exclusive scan of the bucket counts: kBPer consecutive buckets per thread
@@ -2455,7 +2479,7 @@ __global__ __launch_bounds__(kCollectThreads) void sorted_collect_kernel(Batch b
             __syncthreads();
 #pragma unroll
             for (int j = 0; j < kPer; ++j)                                      // (every key is in a register: the list may be overwritten)
-                if (tid + j * kCollectThreads < cnt) keys[atomicAdd(&hist[bucket_of(mykey[j])], 1)] = mykey[j];
+                if (j < nper && tid + j * kCollectThreads < cnt) keys[atomicAdd(&hist[bucket_of(mykey[j])], 1)] = mykey[j];
             __syncthreads();
             // every thread orders the keys of its kBPer consecutive buckets (one contiguous piece of the list; a cursor has
             // come to rest at the end of its bucket = the start of the next)
