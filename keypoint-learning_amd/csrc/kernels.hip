@@ -2025,12 +2025,11 @@ __global__ __launch_bounds__(kLanes) void feature_sorted_kernel(Batch b, int max
     bool deferred;
     const int kf = point_features_sorted<G, true>(v.pts, v.nrmsrc, v.ns, v.cell_start, v.ds->grid, v.f, w.p, w.np, H, ent, ecap,
                                                   keys, lcap, w.scoreable && !large, deferred);
-    if (deferred) {             // more neighbors than the list holds: one more point for sorted_collect_kernel / sorted_add_kernel
+    if (deferred || large) {    // a large box, or more neighbors than the list holds: a point for sorted_collect_kernel / sorted_add_kernel
         if (gq == 0) v.large_list[atomicAdd(&v.ds->large_count, 1)] = w.s;
         return;
     }
-    if (STATS && w.scoreable && !large && gq == 0) atomicAdd(&v.stats->sum_kf, (unsigned long long)kf);
-    if (large) return;
+    if (STATS && w.scoreable && gq == 0) atomicAdd(&v.stats->sum_kf, (unsigned long long)kf);
     float *o = v.feat + (size_t)chunk * v.f.F * kLanes + col;
     for (int c = gq; c < v.f.F; c += G) o[c * kLanes] = H[c * kPts + pi];
 }
@@ -2308,7 +2307,8 @@ __global__ __launch_bounds__(kLanes) void features_sorted_kernel(const float4 *_
 // point_features_sorted holds 128 keys per point and pass and searches again for every pass: 20 passes over ~10 000 candidates
 // per point there (46 ms per 63 k-point view against 1.8 ms in the canonical order).  Points whose search box holds more than
 // kLargeCand candidates take three kernels instead:
-//   sorted_plan_kernel     lists them (DevState::large_count, ViewDev::large_list)
+//   feature_sorted_kernel  lists them instead of scoring them (DevState::large_count, ViewDev::large_list), and with them
+//                          the points whose register list ran full (DEFER)
 //   sorted_collect_kernel  ONE WORKGROUP PER POINT: its 256 threads walk the rows of the box together -- consecutive
 //                          storage positions, coalesced 16-byte loads, no lock step with other points --, the accepted
 //                          neighbors' keys (d2 bits << 32 | original index) go to a list in LDS, the list is sorted there
@@ -2325,16 +2325,6 @@ __global__ __launch_bounds__(kLanes) void features_sorted_kernel(const float4 *_
 // ---------------------------------------------------------------------------------------------
 constexpr int kCollectThreads = 256, kCollectKeys = 4096, kCollectBuckets = 1024, kCollectAhead = 4;
 constexpr int kInsertionMax = 48;        // keys a thread orders by insertion; more in its buckets: the whole list by the network
-
-__global__ __launch_bounds__(256) void sorted_plan_kernel(Batch b) {
-    const ViewDev &v = b.view[blockIdx.y];
-    if (!v.f.sorted) return;
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    const GridDesc g = v.ds->grid;
-    if (s >= v.n || s >= v.cell_start[g.ncells]) return;
-    if (v.nrm[s].w == 0.0f) return;                                               // not scoreable (hpp:277)
-    if (box_candidates(g, v.cell_start, v.pts[s], v.f.rr) > kLargeCand) v.large_list[atomicAdd(&v.ds->large_count, 1)] = s;
-}
 
 __global__ __launch_bounds__(kCollectThreads) void sorted_collect_kernel(Batch b) {
     __shared__ unsigned long long keys[kCollectKeys];
@@ -3806,9 +3796,8 @@ void launch_feature_stage(const Batch &b, hipStream_t st) {
         else feature_kernel<false><<<grid, kLanes, lds, st>>>(b, maxF, ecap);
     }
     if (sorted) {       // the views in sorted-search mode (each kernel skips the views of the other mode)
-        // the points with large neighborhoods are listed first; the register-sort kernel leaves them out, the collect /
-        // add pair takes them (all three return at once where there are none)
-        sorted_plan_kernel<<<dim3(div_up(n, 256), b.nviews), 256, 0, st>>>(b);
+        // the register-sort kernel lists the points with large neighborhoods instead of scoring them, the collect / add pair
+        // takes them (both return at once where there are none)
         const int lcap = sorted_list_keys(maxF);
         const size_t lds = sorted_lds_bytes<kSortGroup>(maxF, kSortWords, lcap);
         const dim3 grid(div_up(n, kLanes) * kSortGroup, b.nviews);

@@ -188,7 +188,7 @@ def test_sorted_mode_counters_and_device_features(kpl, oracle, cases):
     assert stats[False]["sum_kf"] == c["sum_kf"] and stats[False]["sum_depth"] == c["sum_depth"]
 
 
-# ---- large neighborhoods: sorted_plan / sorted_collect / sorted_add (kernels.hip), against the oracle AND against the
+# ---- large neighborhoods: feature_sorted_kernel lists them, sorted_collect / sorted_add score them (kernels.hip); against the oracle AND against the
 # register-sort path (computePointsForTrainingFeatures still takes that one for every neighborhood size)
 
 def _score_both_ways(kpl, oracle, cases, xyz, nrm, A, B, r, seed):
