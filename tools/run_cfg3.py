@@ -84,7 +84,7 @@ def main():
     A, B, thr = 5, 6, float(np.float32(0.85))
     mine = kd.shard(args.views, world, rank)
     n = args.nx * args.ny
-    cap = min(16384, n)                      # keypoints per view that travel (a 63 k view has 7-10 k; a strict unpack refuses a cut list)
+    cap = min(32768, n)                      # keypoints per view that travel (the 63 k views have 7-23 k; a strict unpack refuses a cut list)
     dets, bufs, host = [], [], []
     packed = torch.zeros(len(mine), n + 1, dtype=torch.int32, device=dev)
     for k, v in enumerate(mine):
