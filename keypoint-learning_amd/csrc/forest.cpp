@@ -421,53 +421,9 @@ bool flatten_forest(const ForestModel &m, FlatForest &out, std::string &err) {
         return 1;
     };
     out.nnodes = nn;
-    // Which tree takes which slot.  Blocked layout: tree t, slot t.  Chained layout: the walks of a lane follow the chains
-    // slot c, c + chain, c + 2 chain, ... in step with each other, so a wave is busy for as long as its LONGEST chain -- the
-    // trees are dealt to the chains by expected depth (a fair coin at every split: all a loader knows), round by round, the
-    // deepest tree of a round to the chain that is shortest so far.  The sum of such a forest is exact in any order.
-    out.tree_of_slot.resize((size_t)m.ntrees());
-    for (int t = 0; t < m.ntrees(); ++t) out.tree_of_slot[(size_t)t] = t;
-    if (out.chain != 0) {
-        std::vector<double> cost((size_t)m.ntrees(), 0.0);
-        for (int t = 0; t < m.ntrees(); ++t) {
-            // expected nodes on a root-to-leaf path = sum over the nodes of 2^-(depth - 1); bounded walk (the structure is
-            // validated below, not yet here)
-            struct Open { int node; double w; };
-            std::vector<Open> open;
-            if (m.root[t] >= 0 && m.root[t] < nn) open.push_back({m.root[t], 1.0});
-            int64_t visited = 0;
-            double c = 0.0;
-            while (!open.empty() && visited++ <= nn) {
-                const Open o = open.back();
-                open.pop_back();
-                c += o.w;
-                if (m.var[o.node] >= 0) {
-                    const int l = m.left[o.node], rr = m.right[o.node];
-                    if (l >= 0 && l < nn) open.push_back({l, 0.5 * o.w});
-                    if (rr >= 0 && rr < nn) open.push_back({rr, 0.5 * o.w});
-                }
-            }
-            cost[(size_t)t] = c;
-        }
-        std::vector<int> by_cost((size_t)m.ntrees());
-        for (int t = 0; t < m.ntrees(); ++t) by_cost[(size_t)t] = t;
-        std::stable_sort(by_cost.begin(), by_cost.end(), [&](int a, int b) { return cost[(size_t)a] > cost[(size_t)b]; });
-        std::vector<double> load((size_t)out.chain, 0.0);
-        for (int first = 0; first < m.ntrees(); first += out.chain) {
-            const int cnt = std::min(out.chain, m.ntrees() - first);      // slots first .. first + cnt - 1 = chains 0 .. cnt - 1
-            std::vector<int> chains((size_t)cnt);
-            for (int c = 0; c < cnt; ++c) chains[(size_t)c] = c;
-            std::stable_sort(chains.begin(), chains.end(), [&](int a, int b) { return load[(size_t)a] < load[(size_t)b]; });
-            for (int k = 0; k < cnt; ++k) {                               // the round's k-th deepest tree -> the k-th shortest chain
-                const int tree = by_cost[(size_t)(first + k)], c = chains[(size_t)k];
-                out.tree_of_slot[(size_t)(first + c)] = tree;
-                load[(size_t)c] += cost[(size_t)tree];
-            }
-        }
-    }
     std::vector<Item> level, next;
     for (int t = 0; t < m.ntrees(); ++t) {
-        const int r = m.root[(size_t)out.tree_of_slot[(size_t)t]];
+        const int r = m.root[t];
         if (r < 0 || r >= nn) { err = "root index out of range"; return false; }
         level.push_back(Item{r, (uint32_t)out.nodes.size(), 1, t});      // the root of tree t is slot t
         out.nodes.push_back(FlatNode{0, 0});

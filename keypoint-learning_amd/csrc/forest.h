@@ -42,9 +42,8 @@ struct ForestModel {
 //    child's block; the right child's block is 8 slots further.  Slots that hold no node are never referenced.
 //  * chained (chain == kChainStride; forests of >= kChainMinTrees trees and >= kChainMinVars variables whose sum is
 //    exact in any order -- what forest_split_kernel takes): level-major THROUGHOUT (ntop = all slots), and the record
-//    of a leaf of the tree in slot t holds the root in slot t + chain as its "child" (the resting leaf past the last one): a
-//    walk that just follows the records goes through the slots t, t + chain, t + 2 chain, ... and then rests.  Which tree of
-//    the model sits in which slot: FlatForest::tree_of_slot (balanced chains).
+//    of a leaf of tree t holds the root of tree t + chain as its "child" (the resting leaf past the last tree): a walk
+//    that just follows the records goes through the trees t, t + chain, t + 2 chain, ... and then rests.
 struct FlatNode {
     uint32_t x;
     uint32_t y;
@@ -63,8 +62,6 @@ struct FlatForest {
     bool order_free = false;         // every leaf value is an integer of magnitude <= 2^15 and there are at most 2^15
                                      // trees: the sum of leaf values is exact in any order (and fits an int32)
     int chain = 0;                   // kChainStride: chained layout (see above); 0: blocked layout
-    std::vector<int> tree_of_slot;   // slot t (node t = its root) holds this tree of the model: the identity unless chained,
-                                     // where the trees are dealt to the chains by expected depth (forest.cpp)
     std::vector<FlatNode> nodes;     // slots
     uint32_t ntop = 0;               // slots of the level-major part; every slot >= ntop belongs to a block
     int64_t nnodes = 0;              // nodes of the model (nodes.size() counts padding slots too)

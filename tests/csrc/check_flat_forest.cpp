@@ -101,22 +101,12 @@ int main(int argc, char **argv) {
         // the resting leaf: slot ntrees, value 0, points at itself
         const kpl::FlatNode rest = f.nodes[ntrees];
         if (rest.y != ((kpl::kLeafVar << 24) | (uint32_t)ntrees) || rest.x != 0u) { fprintf(stderr, "resting leaf\n"); return 1; }
-        // which tree sits in which slot: a permutation, the identity unless the forest is chained
-        {
-            std::vector<char> used((size_t)ntrees, 0);
-            if ((int)f.tree_of_slot.size() != ntrees) { fprintf(stderr, "tree_of_slot size\n"); return 1; }
-            for (int t = 0; t < ntrees; ++t) {
-                const int src = f.tree_of_slot[(size_t)t];
-                if (src < 0 || src >= ntrees || used[(size_t)src] || (!f.chain && src != t)) { fprintf(stderr, "tree_of_slot[%d] = %d\n", t, src); return 1; }
-                used[(size_t)src] = 1;
-            }
-        }
         std::vector<float> x(m.var_count);
         for (int q = 0; q < 40; ++q) {
             for (auto &v : x) v = unit();
             for (int t = 0; t < ntrees; ++t) {
                 int dm, df;
-                const double want = model_leaf(m, f.tree_of_slot[(size_t)t], x, dm);      // (chained: the trees are dealt to the chains by depth)
+                const double want = model_leaf(m, t, x, dm);
                 const uint32_t leaf = flat_leaf(f, t, x, df);
                 float got;
                 memcpy(&got, &f.nodes[leaf].x, 4);
