@@ -98,10 +98,10 @@ def main():
                 e["valu_issue_frac"] = e["valu_model"]["valu_issue_frac"]
             # enabled lanes per VALU instruction-cycle / 64 (round-3 verdict: what the issue model hides -- lanes that are
             # masked off or belong to points that have run out of work)
-            if c.get("SQ_THREAD_CYCLES_VALU") is not None and c.get("SQ_INST_CYCLES_VALU"):
-                e["valu_active_lane_frac"] = round(c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_INST_CYCLES_VALU"]), 4)
-            elif c.get("SQ_THREAD_CYCLES_VALU") is not None and c.get("SQ_ACTIVE_INST_VALU"):
-                e["valu_active_lane_frac"] = round(c["SQ_THREAD_CYCLES_VALU"] / (64.0 * 4.0 * c["SQ_ACTIVE_INST_VALU"]), 4)
+            # SQ_THREAD_CYCLES_VALU counts the ENABLED LANES of every VALU instruction (calibrated on this chip: 64.0 for
+            # kernels whose lanes are all enabled, 2.1 for the one-thread grid_setup_kernel -- profiles/r04_notes.md)
+            if c.get("SQ_THREAD_CYCLES_VALU") is not None and c.get("SQ_INSTS_VALU"):
+                e["valu_active_lane_frac"] = round(c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_INSTS_VALU"]), 4)
             if c.get("SQ_LDS_BANK_CONFLICT") is not None and c.get("SQ_ACTIVE_INST_LDS"):
                 # SQ_ACTIVE_INST_LDS / SQ_LDS_BANK_CONFLICT count quad-cycles summed over the SIMDs (MI355X_MICROARCH.md)
                 e["lds_busy"] = round(c["SQ_ACTIVE_INST_LDS"] * 4.0 / (SIMDS * c.get("GRBM_GUI_ACTIVE_lds", c["GRBM_GUI_ACTIVE"]) / XCDS), 4)
@@ -112,7 +112,7 @@ def main():
                             "valu_busy": "SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * GRBM_GUI_ACTIVE / 8): an UPPER bound (4 cycles per instruction)",
                             "valu_issue_frac": "tools/valu_model.py: sum over instruction classes of count x measured issue cycles (tools/valu_ceiling.hip on this box) / (1024 SIMDs x kernel cycles)",
                             "waves_per_simd": "SQ_WAVE_CYCLES * 4 / (1024 SIMDs * GRBM_GUI_ACTIVE / 8)",
-                            "valu_active_lane_frac": "SQ_THREAD_CYCLES_VALU / (64 x SQ_INST_CYCLES_VALU): enabled lanes per VALU instruction cycle",
+                            "valu_active_lane_frac": "SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU): enabled lanes per VALU instruction / 64 (own --pmc pass)",
                             "ta_busy": "TA_BUSY_avr / (GRBM_GUI_ACTIVE / 8): the texture-addresser's busy cycles, average over its instances"},
                "files": [tag + "_kernel_stats.csv", tag + "_pmc.json", tag + "_bench.json", tag + "_valu_ceiling.json"]},
               open(os.path.join(prof, "counters.json"), "w"), indent=1)
