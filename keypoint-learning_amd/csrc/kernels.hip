@@ -1960,27 +1960,21 @@ __device__ __forceinline__ WavePoint wave_point(const ViewDev &a, int chunk, int
     return w;
 }
 
-// Sorted-search mode: which points take the path for LARGE neighborhoods.  Decided from the index alone -- the number of
-// candidates in the rows of the point's search box (what RowSearch walks), an upper bound of K_f about three times K_f on
-// a surface -- so that every kernel of the stage comes to the same answer without a pass over the points.  512 candidates
-// are ~170 neighbors: up to there the register sort needs two passes at most (with 1 024 the few points of the cheff view at
-// the default radius that stayed below it -- outliers with 200 to 340 neighbors, 3 to 8 passes each -- kept the register-sort
-// kernel running for 0.68 ms after everybody else had left).
-constexpr int kLargeCand = 512;
-__device__ __forceinline__ int box_candidates(const GridDesc &g, const int *__restrict__ cell_start, const float4 &p, float rr) {
-    CellBox b = make_box(g, p.x, p.y, p.z, rr);
-    b.hi[1] = min(b.hi[1], b.lo[1] + 3);
-    b.hi[2] = min(b.hi[2], b.lo[2] + 3);
-    int c = 0;
-    for (int z = b.lo[2]; z <= b.hi[2]; ++z)
-        for (int y = b.lo[1]; y <= b.hi[1]; ++y) {
-            const int row = (z * g.dims[1] + y) * g.dims[0];
-            c += cell_start[row + b.hi[0] + 1] - cell_start[row + b.lo[0]];
-        }
-    return c;
-}
-__device__ __forceinline__ bool is_large_point(const GridDesc &g, const int *__restrict__ cell_start, const WavePoint &w, float rr) {
-    return w.scoreable && box_candidates(g, cell_start, w.p, rr) > kLargeCand;
+// Sorted-search mode: which points take the path for LARGE neighborhoods (sorted_collect_kernel / sorted_add_kernel) without
+// being searched here first.  A cheap test on the index alone -- the population of the point's own cell (one pair of
+// cell_start[] entries): the box of a point holds about nine such cells on a surface, so more than kLargeCell points in the
+// cell are about 170 neighbors or more, where the register sort of 128 keys is at its end.  The test only has to be
+// roughly right: a point it lets through whose list runs full is deferred to the same kernels (DEFER below).  (Summing
+// the candidates of the whole box -- 32 dependent loads per lane in a kernel with two waves per SIMD -- cost 7 % of the
+// stage on views that have no large point at all.)
+constexpr int kLargeCell = 57;
+__device__ __forceinline__ bool is_large_point(const GridDesc &g, const int *__restrict__ cell_start, const WavePoint &w, float) {
+    if (!w.scoreable) return false;
+    const int cx = cell_coord(w.p.x, g.mn[0], g.h, g.dims[0]);
+    const int cy = cell_coord(w.p.y, g.mn[1], g.h, g.dims[1]);
+    const int cz = cell_coord(w.p.z, g.mn[2], g.h, g.dims[2]);
+    const int c = (cz * g.dims[1] + cy) * g.dims[0] + cx;
+    return cell_start[c + 1] - cell_start[c] > kLargeCell;
 }
 
 // Several independent views per launch (blockIdx.y = view): one 200 k-point view is only a few waves per
@@ -2305,8 +2299,8 @@ __global__ __launch_bounds__(kLanes) void features_sorted_kernel(const float4 *_
 // Sorted-search mode, LARGE neighborhoods (the reference's own default operating point: radiusFeatures 20 on the cheff
 // views = 30 mesh resolutions, K_f ~ 2 300 -- /root/reference/src/main_test_detector.cpp:65).  The register sort of
 // point_features_sorted holds 128 keys per point and pass and searches again for every pass: 20 passes over ~10 000 candidates
-// per point there (46 ms per 63 k-point view against 1.8 ms in the canonical order).  Points whose search box holds more than
-// kLargeCand candidates take three kernels instead:
+// per point there (46 ms per 63 k-point view against 1.8 ms in the canonical order).  Points in crowded cells (is_large_point)
+// and points whose register list ran full take three kernels instead:
 //   feature_sorted_kernel  lists them instead of scoring them (DevState::large_count, ViewDev::large_list), and with them
 //                          the points whose register list ran full (DEFER)
 //   sorted_collect_kernel  ONE WORKGROUP PER POINT: its 256 threads walk the rows of the box together -- consecutive

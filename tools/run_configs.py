@@ -144,7 +144,12 @@ def cfg0():
     xyz, nrm = z["xyz"], z["nrm"]
     r, rn, thr = float(z["r_feat"]), float(z["r_nms"]), float(z["thr"])
     rows = {}
+    cores = helpers.usable_cores()
     for order in ("canonical", "sorted"):
+        t0 = time.perf_counter()
+        kplo.detect(xyz, nrm, 5, 10, r, rn, thr, helpers.oracle_forest(fa), threads=cores,
+                    order=kplo.ORDER_SORTED if order == "sorted" else kplo.ORDER_CANONICAL)
+        cpu_all = len(xyz) / (time.perf_counter() - t0) / 1e6
         det = make_detector(5, 10, r, rn, thr, forest, sorted_search=order == "sorted")
         mr = det.cloudResolution(xyz)
         t, sc, kp, phases, st = time_gpu(det, xyz, nrm, reps=10, batch=3)
@@ -156,7 +161,8 @@ def cfg0():
                        "gpu_ms": round(t * 1e3, 4), "phases_ms": {k: round(v, 4) for k, v in phases.items()},
                        "K_f": round(st["sum_kf"] / max(st["n_scored"], 1), 1), "keypoints": int(len(kp)),
                        "feature_kernel_alg_GBps": round(b_feat / (phases["feature_ms"] * 1e-3) / 1e9, 1),
-                       "feature_kernel_frac_of_8TBps": round(b_feat / (phases["feature_ms"] * 1e-3) / 8e12, 4), "parity": ok}
+                       "feature_kernel_frac_of_8TBps": round(b_feat / (phases["feature_ms"] * 1e-3) / 8e12, 4),
+                       "cpu_all_Mpts": round(cpu_all, 4), "cores": cores, "parity": ok}
         print(json.dumps(rows[order]), flush=True)
         assert ok, "PARITY FAILURE in cfg0 " + order
     print(json.dumps({"config": "cfg0 sorted / canonical", "compute_ratio": round(rows["sorted"]["gpu_ms"] / rows["canonical"]["gpu_ms"], 3),
