@@ -1420,6 +1420,8 @@ __device__ __forceinline__ int point_features_sorted(const float4 *__restrict__ 
                         if (cnt > lcap - G) {
                             deferred = true;
                             cnt = 0;
+                            rs.ny = 0;             // its rows are over: it does not hold up the others' walk any more
+                            rs.t1 = rs.t;
                         }
                     }
                     // room for the G keys of this round in every list, else: a pivot inside the window, the list filtered
@@ -1456,6 +1458,7 @@ __device__ __forceinline__ int point_features_sorted(const float4 *__restrict__ 
                 } while (__any((w != 0u) | (e < ecnt) | pa.valid | pb.valid));
             }
             if (rs.exhausted()) break;
+            if (DEFER && !__any(active && !deferred)) break;           // every point of the wave has left for the large path
         }
         // ---- sort the lists (the one place where the network is instantiated)
         sort_key_lists<G, kSortedListKeys / G>(keys, pi, gq, cnt);
