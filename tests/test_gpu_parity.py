@@ -267,6 +267,15 @@ def test_draws_remove_on_a_constant_score_plane(kpl, oracle, cases, order):
         _, o_kp = oracle.detect(xyz, nrm, A, B, r, rn, 0.5, cases.oracle_forest(fa), draws_remove=True, draws_threshold=dthr)
         assert np.array_equal(det.getKeypointsIndices(), o_kp)
         assert 0 < len(o_kp) < len(xyz) // 2
+    # a wide NMS radius and draw threshold: ~75 listed maxima of lower index within the threshold of every entry -- more
+    # than the 32 an adjacency row holds, so the rounds and the pipelined rest sweep the neighborhood instead (states
+    # through LDS by list position)
+    rn7, dthr7 = float(np.float32(7 * mr)), float(np.float32(6.5 * mr))
+    det.setNonMaxRadius(rn7)
+    det.setNonMaximaDrawsThreshold(dthr7)
+    det.compute()
+    _, o_kp = oracle.detect(xyz, nrm, A, B, r, rn7, 0.5, cases.oracle_forest(fa), draws_remove=True, draws_threshold=dthr7)
+    assert np.array_equal(det.getKeypointsIndices(), o_kp) and 0 < len(o_kp) < len(xyz) // 20
 
 
 def test_cloud_resolution_bit_exact(kpl, oracle, cases):
