@@ -181,7 +181,7 @@ int prepare(Worker &w, const Options &o) {
 int score(Worker &w, bool first) {
     CHECK_HIP(hipSetDevice(w.device));
     const int nv = (int)w.views.size();
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    for (int attempt = 0; attempt < 3; ++attempt) {          // (first round: the cell tables and, in sorted-search mode, the key array may each grow once)
         for (int b0 = 0, bi = 0; b0 < nv; b0 += 8, ++bi) {
             const int cnt = std::min(8, nv - b0);
             kpl_detector *hs[8];
@@ -201,7 +201,7 @@ int score(Worker &w, bool first) {
         bool retry = false;                                            // first round only: cell tables may have to grow once
         for (int k = 0; k < nv; ++k) {
             const int rc = kpl_sync_status(w.views[(size_t)k]->h, w.st[(k / 8) & 1]);
-            if (rc == KPL_ERR_RETRY && attempt == 0) retry = true;
+            if (rc == KPL_ERR_RETRY && attempt < 2) retry = true;
             else if (rc != KPL_OK) { fprintf(stderr, "%s: %s\n", w.views[(size_t)k]->path.c_str(), kpl_last_error(w.views[(size_t)k]->h)); return 1; }
         }
         if (!retry) break;

@@ -80,3 +80,23 @@ def test_test_detector_with_no_radius_options_runs_the_reference_defaults(tmp_pa
     assert info["keypoints"] == len(kp) == len(got)
     assert np.array_equal(got[:, :3], gold["xyz"][kp])
     assert np.array_equal(got[:, 3], gold["scores_" + order][kp])
+
+
+def test_detect_views_at_the_default_operating_point_sorted(tmp_path, gold):
+    """DetectViews (C++, batches + RCCL gather) with its defaults = the reference main's, sorted search: the first round needs
+    KPL_ERR_RETRY for the key array (kpl_sync_status grows it), the keypoint files equal the oracle's sorted result"""
+    exe = os.path.join(ROOT, "keypoint-learning_amd", "DetectViews")
+    clouds = []
+    for k in range(2):
+        path = str(tmp_path / ("view%d.pcd" % k))
+        _write_ascii_pcd(path, gold["xyz"])
+        clouds.append(path)
+    prefix = str(tmp_path / "kp")
+    out = subprocess.run([exe, "--pathRF", FOREST, "--sortedSearch", "--devices", "all", "--pathKP", prefix] + clouds,
+                         capture_output=True, text=True, timeout=900, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0, out.stdout[-1000:] + out.stderr[-3000:]
+    kp = gold["kp_sorted"]
+    for k in range(2):
+        got = _read_keypoints(prefix + "%d.pcd" % k)
+        assert len(got) == len(kp)
+        assert np.array_equal(got[:, :3], gold["xyz"][kp]) and np.array_equal(got[:, 3], gold["scores_sorted"][kp])
