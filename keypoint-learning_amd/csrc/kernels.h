@@ -137,7 +137,6 @@ struct DevState {
     int status;           // kStatus*: on failure the grid is empty and kp_count becomes -1
     int ncells_needed;    // what this view needs (to grow the cell tables before a retry)
     int bshift, nbuckets; // index sort: nbuckets buckets of 2^bshift consecutive cells
-    int occupied_cells;   // cells of the grid that hold a point (counted by the index build, read by feature_dual_kernel)
     uint32_t bbox[6];     // order-preserving encoded min / max accumulators (self re-arming)
     uint32_t scan_epoch;  // tag of the next detect call in the words of scan_state (advanced on the device, never 0)
     int scan_fail;        // set by a block of compact_scan_kernel whose look-back gave up: the call failed (kpl_sync_status -> KPL_ERR_INTERNAL, which clears it)

@@ -169,7 +169,6 @@ __global__ void grid_setup_kernel(Batch b) {
     while (nc > 0 && ((nc - 1) >> bshift) >= kBuckets) ++bshift;
     ds->bshift = bshift;
     ds->nbuckets = nc > 0 ? (int)((nc - 1) >> bshift) + 1 : 0;
-    ds->occupied_cells = 0;                            // counted by cell_sort_store_kernel
     for (int k = 0; k < 3; ++k) {
         ds->bbox[k] = 0xffffffffu;
         ds->bbox[3 + k] = 0u;
@@ -621,13 +620,6 @@ __global__ __launch_bounds__(kSortWaves *kWave) void cell_sort_store_kernel(Batc
                 tot[j] = run;
             }
             mine += tot[j];
-        }
-        {   // cells of the view that hold a point (feature_dual_kernel: how crowded the cells are); one atomic per wave
-            int occ = 0;
-#pragma unroll
-            for (int j = 0; j < kCellsPerThread; ++j) occ += tot[j] > 0 ? 1 : 0;
-            for (int off = kWave / 2; off > 0; off >>= 1) occ += __shfl_xor(occ, off);
-            if (lane == 0 && occ > 0) atomicAdd(&v.ds->occupied_cells, occ);
         }
         // exclusive scan of the cell totals over the workgroup (kCellsPerThread consecutive cells per thread)
         int incl = mine;
@@ -1991,49 +1983,23 @@ __device__ __forceinline__ bool is_large_point(const GridDesc &g, const int *__r
 // Several independent views per launch (blockIdx.y = view): one 200 k-point view is only a few waves per
 // SIMD; a batch of views fills the chip.  Workgroup (= wave) x handles the 64 / kGroup storage positions
 // x * 64 / kGroup ..; it writes its columns of the F x 64 feature block of its chunk of 64 positions.
-// part = which 64 / G points of the chunk this wave takes
-template <bool STATS, int G>
-__device__ __forceinline__ void feature_wave(const ViewDev &v, int chunk, int part, float *H, int maxF, int ecap) {
-    constexpr int kPts = kLanes / G;
-    const int pi = threadIdx.x / G, gq = threadIdx.x % G;
-    const int col = part * kPts + pi;                                 // the point's column of the chunk's F x 64 block
+template <bool STATS>
+__global__ __launch_bounds__(kLanes) void feature_kernel(Batch b, int maxF, int ecap) {
+    extern __shared__ float H[];
+    constexpr int kPts = kLanes / kGroup;
+    const ViewDev &v = b.view[blockIdx.y];
+    if (v.f.sorted) return;                                           // scored by feature_sorted_kernel
+    const int chunk = blockIdx.x / kGroup, pi = threadIdx.x / kGroup, gq = threadIdx.x % kGroup;
+    const int col = (blockIdx.x % kGroup) * kPts + pi;                // the point's column of the chunk's F x 64 block
     if (chunk * kLanes + col - pi >= v.n) return;
     const WavePoint w = wave_point(v, chunk, col, true);
     // every lane of the wave runs the feature code (wave-level votes inside); a group without a scoreable
     // point simply has no rows
-    const int kf = point_features<G>(v.pts, v.nrm, v.cell_start, v.ds->grid, v.f, w.p, w.np, H,
-                                     reinterpret_cast<uint2 *>(H + maxF * kPts), ecap, w.scoreable);
+    const int kf = point_features<kGroup>(v.pts, v.nrm, v.cell_start, v.ds->grid, v.f, w.p, w.np, H,
+                                          reinterpret_cast<uint2 *>(H + maxF * kPts), ecap, w.scoreable);
     if (STATS && w.scoreable && gq == 0) atomicAdd(&v.stats->sum_kf, (unsigned long long)kf);
     float *o = v.feat + (size_t)chunk * v.f.F * kLanes + col;
-    for (int c = gq; c < v.f.F; c += G) o[c * kLanes] = H[c * kPts + pi];
-}
-
-template <bool STATS>
-__global__ __launch_bounds__(kLanes) void feature_kernel(Batch b, int maxF, int ecap) {
-    extern __shared__ float H[];
-    const ViewDev &v = b.view[blockIdx.y];
-    if (v.f.sorted) return;                                           // scored by feature_sorted_kernel
-    feature_wave<STATS, kGroup>(v, blockIdx.x / kGroup, blockIdx.x % kGroup, H, maxF, ecap);
-}
-
-// The same for SMALL views (launch_feature_stage: fewer than kDualBelow points), launched with four waves per chunk:
-// a view whose cells are crowded -- more than kWideCellPop points per occupied cell of the grid, i.e. several hundred
-// neighbors per point: few waves, each alive for the whole kernel -- takes FOUR lanes per point (twice the waves, half the
-// rounds per wave: the reference's default operating point, 63 k points with 2 300 neighbors each, 1.76 -> 1.53 ms); every
-// other view takes two lanes per point as above and the odd waves leave at once (a 62 k-point view with 100 neighbors per
-// point is 15 % SLOWER with four lanes).  Decided per view on the device from what the index build counted.
-constexpr int kWideCellPop = 150;
-template <bool STATS>
-__global__ __launch_bounds__(kLanes) void feature_dual_kernel(Batch b, int maxF, int ecap) {
-    extern __shared__ float H[];
-    const ViewDev &v = b.view[blockIdx.y];
-    if (v.f.sorted) return;
-    const DevState *ds = v.ds;
-    const int chunk = blockIdx.x / 4, sub = blockIdx.x % 4;
-    const long long nfinite = v.cell_start[ds->grid.ncells];
-    const bool wide = nfinite > (long long)kWideCellPop * (long long)ds->occupied_cells;
-    if (wide) feature_wave<STATS, 4>(v, chunk, sub, H, maxF, ecap);
-    else if (sub < 2) feature_wave<STATS, 2>(v, chunk, sub, H, maxF, ecap);
+    for (int c = gq; c < v.f.F; c += kGroup) o[c * kLanes] = H[c * kPts + pi];
 }
 
 // the same for the views in sorted-search mode: kSortGroup lanes per point, 64 / kSortGroup points per wave
@@ -3770,7 +3736,6 @@ static int cu_count() {
 // and every launch with larger neighborhoods 10-25 % slower; the host cannot know the neighborhood size.
 // Fewer words for the largest histograms so that a handful of waves still fit a CU (160 KB of LDS).
 constexpr int kLdsPerCu = 160 * 1024;
-constexpr int kDualBelow = 128 * 1024;      // points of the largest view of a launch below which feature_dual_kernel is used
 static int accept_words(int F) {
     static const int forced = getenv("KPL_EXP_ECAP") ? atoi(getenv("KPL_EXP_ECAP")) : 0;      // (experiments only)
     if (forced > 0) return forced;
@@ -3823,15 +3788,9 @@ void launch_feature_stage(const Batch &b, hipStream_t st) {
     if (canonical) {
         const int ecap = accept_words(maxF);
         const size_t lds = feature_lds_bytes<kGroup>(maxF, ecap);
-        if (n < kDualBelow) {          // small views: two or four lanes per point, decided per view on the device
-            const dim3 grid(div_up(n, kLanes) * 4, b.nviews);
-            if (stats) feature_dual_kernel<true><<<grid, kLanes, lds, st>>>(b, maxF, ecap);
-            else feature_dual_kernel<false><<<grid, kLanes, lds, st>>>(b, maxF, ecap);
-        } else {
-            const dim3 grid(div_up(n, kLanes) * kGroup, b.nviews);
-            if (stats) feature_kernel<true><<<grid, kLanes, lds, st>>>(b, maxF, ecap);
-            else feature_kernel<false><<<grid, kLanes, lds, st>>>(b, maxF, ecap);
-        }
+        const dim3 grid(div_up(n, kLanes) * kGroup, b.nviews);
+        if (stats) feature_kernel<true><<<grid, kLanes, lds, st>>>(b, maxF, ecap);
+        else feature_kernel<false><<<grid, kLanes, lds, st>>>(b, maxF, ecap);
     }
     if (sorted) {       // the views in sorted-search mode (each kernel skips the views of the other mode)
         // the register-sort kernel lists the points with large neighborhoods instead of scoring them, the collect / add pair
