@@ -61,6 +61,23 @@ def build(force=False, verbose=False):
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
+    # test programs in C++ (tests/csrc): the hammer that scores one saved case again and again under co-running load
+    # (tools/soak.sh, profiles/r04_notes.md) and the probe of the runtime's pageable-copy path
+    tdir = os.path.join(HERE, "..", "tests", "csrc")
+    hsrc, hexe = os.path.join(tdir, "hammer_case.cpp"), os.path.join(tdir, "hammer_case")
+    if os.path.exists(hsrc) and (force or _stale(hexe, [hsrc, LIB, os.path.join(HERE, "..", "include", "kpl.h")])):
+        cmd = ["g++", "-O2", "-std=c++14", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(HERE, "..", "include"), "-I", "/opt/rocm/include",
+               hsrc, "-o", hexe, "-L", HERE, "-lkpl", "-L", "/opt/rocm/lib", "-lamdhip64", "-pthread",
+               "-Wl,-rpath,$ORIGIN/../../keypoint-learning_amd", "-Wl,-rpath,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    psrc, pexe = os.path.join(tdir, "pageable_copy_probe.cpp"), os.path.join(tdir, "pageable_copy_probe")
+    if os.path.exists(psrc) and (force or _stale(pexe, [psrc])):
+        cmd = [HIPCC, "-O2", "-o", pexe, psrc]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
     # stand-alone HIP diagnostics (not part of libkpl): the VALU issue-ceiling microbenchmark behind bench.py's
     # `valu_issue_frac` (tools/valu_ceiling.hip -> profiles/*_valu_ceiling.json)
     vsrc = os.path.join(HERE, "..", "tools", "valu_ceiling.hip")
