@@ -125,3 +125,22 @@ def test_rank_process_is_pinned_next_to_its_gpu():
     assert "numa_node" in info or "skipped" in info
     if "numa_node" in info:
         assert info["cpus"] == after and 0 < after <= before and info["pci"].count(":") == 2
+
+
+def test_hammer_and_probe_run_clean(tmp_path):
+    """the C++ hammer (tests/csrc/hammer_case.cpp: the saved round-3 case scored again and again, compared with the ORACLE's
+    result, next to a co-running 200 k-point load on a second handle) and the probe of the runtime's pageable-copy path:
+    a few seconds of each here, the long runs are in profiles/r04_notes.md"""
+    from tools import case_blob
+    c = _load_fuzz_case()
+    scores, kp = case_blob.oracle_result(c)
+    blob = str(tmp_path / "case.blob")
+    case_blob.write_blob(c, scores, kp, blob)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)          # (where the hammer would dump a mismatch)
+    for mode in (["host", "load"], ["device", "load"], ["host", "fresh"]):
+        out = subprocess.run([os.path.join(ROOT, "tests", "csrc", "hammer_case"), blob, "4"] + mode, capture_output=True, text=True,
+                             timeout=300, cwd=ROOT)
+        assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+        assert "mismatches 0" in out.stdout
+    out = subprocess.run([os.path.join(ROOT, "tests", "csrc", "pageable_copy_probe"), "20"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "PROBE: clean" in out.stdout, out.stdout[-1500:] + out.stderr[-500:]
