@@ -82,7 +82,8 @@ typedef struct kpl_params {
  *              pcl::search::KdTree constructed with sorted = true to setSearchMethod (FLANN sorts its radius
  *              result set by (distance, index)).  Element 0 is then the query itself (or a duplicate of it with a
  *              lower index).  This is the order in which results can be compared bit for bit with a PCL build of
- *              the reference.  About 2-3x the cost of CANONICAL (per-point sort of the neighbor list). */
+ *              the reference.  Cost against CANONICAL: ~3.5x at 70 neighbors per point (per-point sort in registers), ~1.5x
+ *              at the ~2 300 of the reference's default radius (a workgroup per point collects and sorts the keys). */
 enum { KPL_NEIGHBORS_CANONICAL = 0, KPL_NEIGHBORS_SORTED = 1 };
 
 /* Counters for the algorithmic-bytes model of SURVEY.md 8(d), filled by kpl_collect_stats. */
@@ -208,11 +209,14 @@ int kpl_compute_batch_keypoints_device(kpl_detector *const *handles, int count, 
                                        float *const *d_kp_scores, const int *kp_caps, int *const *d_kp_counts,
                                        void *stream);
 /* The device entry points never wait for the GPU: the grid descriptor is computed on the device.
- * Two conditions can therefore only be seen afterwards -- a view that needs more than 2^28 grid
- * cells, or more cells than the handle's tables currently hold (they start at 8*n + 65536 cells).
- * In both cases the enqueued call wrote *d_kp_count = -1.  kpl_sync_status waits for `stream` and
- * returns KPL_OK, KPL_ERR_GRID_TOO_LARGE, or KPL_ERR_RETRY after growing the tables (enqueue the
- * call again).  kpl_detect / kpl_compute_features do this internally. */
+ * Some conditions can therefore only be seen afterwards -- a view that needs more than 2^28 grid
+ * cells; more cells than the handle's tables currently hold (they start at 8*n + 65536 cells); in
+ * sorted-search mode, more neighbor keys of points with large neighborhoods than the handle's key
+ * array holds (it starts at 64 keys per point; the reference's default radius on its own test views
+ * needs ~2 300); a device-side consistency check that failed.  In all of them the enqueued call wrote
+ * *d_kp_count = -1.  kpl_sync_status waits for `stream` and returns KPL_OK, KPL_ERR_GRID_TOO_LARGE,
+ * KPL_ERR_RETRY after growing the tables / the key array (enqueue the call again; a first call may need
+ * this twice), or KPL_ERR_INTERNAL (call again).  kpl_detect / kpl_compute_features do this internally. */
 int kpl_sync_status(kpl_detector *h, void *stream);
 
 /* Per-phase device timing with HIP events recorded on the caller's stream, around the kernels of
