@@ -208,15 +208,8 @@ int install_forest(kpl_detector *h, ForestModel &&m) {
     // the new device copy is complete before the handle sees any of it: a failure on the way
     // leaves the previous forest (host and device side) in place
     DevBuf nodes;                           // (the root of tree t is slot t: no table of roots)
-    // one allocation: the records, then -- for a forest that has them -- the compact records and the root variables
-    const size_t node_bytes = sizeof(FlatNode) * flat.nodes.size();
-    const size_t compact_bytes = sizeof(FlatNode) * flat.compact.size(), root_bytes = sizeof(uint32_t) * flat.root_var.size();
-    hipError_t e = nodes.ensure(node_bytes + compact_bytes + root_bytes);
-    if (e == hipSuccess) e = hipMemcpy(nodes.p, flat.nodes.data(), node_bytes, hipMemcpyHostToDevice);
-    if (e == hipSuccess && compact_bytes)
-        e = hipMemcpy((char *)nodes.p + node_bytes, flat.compact.data(), compact_bytes, hipMemcpyHostToDevice);
-    if (e == hipSuccess && root_bytes)
-        e = hipMemcpy((char *)nodes.p + node_bytes + compact_bytes, flat.root_var.data(), root_bytes, hipMemcpyHostToDevice);
+    hipError_t e = nodes.ensure(sizeof(FlatNode) * flat.nodes.size());
+    if (e == hipSuccess) e = hipMemcpy(nodes.p, flat.nodes.data(), sizeof(FlatNode) * flat.nodes.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         nodes.release();
         return fail(h, KPL_ERR_DEVICE, "forest upload failed: %s", hipGetErrorString(e));
@@ -421,11 +414,7 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
     }
     v.f = make_feat(h->prm);
     v.forest = ForestDev{h->d_nodes.as<uint2>(), h->flat.ntrees, (int)h->flat.nodes.size(), (int)h->flat.ntop,
-                         h->flat.order_free ? 1 : 0, h->flat.chain, nullptr, nullptr};
-    if (!h->flat.compact.empty()) {
-        v.forest.compact = h->d_nodes.as<uint2>() + h->flat.nodes.size();
-        v.forest.root_var = reinterpret_cast<const uint32_t *>(v.forest.compact + h->flat.compact.size());
-    }
+                         h->flat.order_free ? 1 : 0, h->flat.chain};
     v.nd = nd;
     v.feat = h->feat.as<float>();
     v.score_sorted = h->score_sorted.as<float>();

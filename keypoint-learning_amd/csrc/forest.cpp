@@ -461,25 +461,6 @@ bool flatten_forest(const ForestModel &m, FlatForest &out, std::string &err) {
         level.swap(next);
     }
     out.ntop = (uint32_t)out.nodes.size();
-    // compact records (forest.h): only for a forest that is level-major as a whole and small enough for 16-bit child slots
-    if (out.chain == 0 && pairs.empty() && out.nodes.size() <= (size_t)kTopNodes) {
-        const size_t ns = out.nodes.size();
-        out.compact.resize(ns);
-        for (size_t i = 0; i < ns; ++i) {
-            const FlatNode n = out.nodes[i];
-            FlatNode c;
-            c.x = n.x;
-            if ((n.y >> 24) == kLeafVar) {
-                c.y = (uint32_t)i | (kLeafVar << 16) | (kLeafVar << 24);
-            } else {
-                const uint32_t left = n.y & 0x00ffffffu;
-                c.y = left | ((out.nodes[left].y >> 24) << 16) | ((out.nodes[left + 1].y >> 24) << 24);
-            }
-            out.compact[i] = c;
-        }
-        out.root_var.resize((size_t)m.ntrees());
-        for (int t = 0; t < m.ntrees(); ++t) out.root_var[(size_t)t] = out.nodes[(size_t)t].y >> 24;
-    }
     // Blocked part: the two children of every pending internal node get one 128-byte line: two blocks of
     // kBlockSlots = 8 slots, the left child's at `base`, the right child's at base + 8.  A block holds a
     // subtree of three levels: slot 0 its root, slots 1 2 the root's children, slots 3 4 the children of

@@ -64,15 +64,6 @@ struct FlatForest {
     int chain = 0;                   // kChainStride: chained layout (see above); 0: blocked layout
     std::vector<FlatNode> nodes;     // slots
     uint32_t ntop = 0;               // slots of the level-major part; every slot >= ntop belongs to a block
-    // "Compact" records of a forest that lies level-major in at most kTopNodes slots (what the two-lanes-per-point forest
-    // kernel keeps in LDS), same slot numbering: x as above, y = [15:0] left child (a leaf: its own slot) [23:16] split
-    // variable of the LEFT child [31:24] of the RIGHT child (255 = that child is a leaf; a leaf: 255 255).  A record
-    // names the variables its children test, so the walk can ask for the next node AND the feature that node will test in
-    // one step: one dependent LDS round trip per level instead of two (kernels.hip, forest_sum_strided_compact).
-    // root_var[t] = the variable the root of tree t tests (255: the tree is a single leaf).  Empty when the forest does
-    // not qualify.
-    std::vector<FlatNode> compact;
-    std::vector<uint32_t> root_var;
     int64_t nnodes = 0;              // nodes of the model (nodes.size() counts padding slots too)
 };
 

@@ -63,8 +63,6 @@ struct ForestDev {
     int ntop;                // slots of the level-major top part; slots >= ntop are 8-slot blocks (forest.h)
     int order_free;          // FlatForest::order_free: the trees of a point may be summed in any order
     int chain;               // FlatForest::chain: the leaf records chain tree t to tree t + chain
-    const uint2 *compact;    // FlatForest::compact (same slots) or null; then root_var = FlatForest::root_var
-    const uint32_t *root_var;
 };
 
 struct StatsDev {
