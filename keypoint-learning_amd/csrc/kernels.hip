@@ -351,7 +351,10 @@ __global__ __launch_bounds__(kScanBlock) void scan_apply_kernel(ScanJobs jobs) {
 // "In index order" inside a wave: the 64 pairs of a round are ranked among the lanes with the same
 // key by lane number (match_rank) and the running count of the key is advanced once per round.
 // ---------------------------------------------------------------------------------------------
-constexpr int kSortChunk = 1024;         // points per chunk of level 1 (16 rounds of one wave)
+constexpr int kSortChunk = 1024;         // points per chunk of level 1 (16 rounds of one wave) ...
+constexpr int kSortChunkSmall = 512;     // ... or half of that when the whole launch is small (sort_chunk_points): twice the waves for
+                                         // kernels that are one wave per chunk (a 62 k-point view alone: index build 0.053 -> 0.043 ms;
+                                         // 8 x 200 k points per launch are 2 % SLOWER with the small chunks, 4 x the table traffic)
 constexpr int kInvalidBin = kBuckets;    // bin of the points without a cell
 constexpr int kTagSlots = 256;
 
@@ -395,23 +398,23 @@ __device__ __forceinline__ int point_cell(const GridDesc &g, const char *xyz, si
     return (cz * g.dims[1] + cy) * g.dims[0] + cx;
 }
 
-__host__ __device__ inline int sort_chunks(int n) { return (n + kSortChunk - 1) / kSortChunk; }
+__host__ __device__ inline int sort_chunks(int n, int chunk_pts) { return (n + chunk_pts - 1) / chunk_pts; }
 
 constexpr int kBins = kBuckets + 1;      // buckets + the bin of the points without a cell
 constexpr int kRoundsAhead = 8;          // rounds of a chunk whose loads are issued together
 
 // btable[bin * nchunks + chunk] = points of the chunk in the bin (a bin's chunks are contiguous: the
 // two kernels that turn counts into offsets give each bin to one wave); cid[i] = cell of point i (-1: none)
-__global__ __launch_bounds__(kWave) void bucket_hist_kernel(Batch b) {
+__global__ __launch_bounds__(kWave) void bucket_hist_kernel(Batch b, int chunk_pts) {
     const ViewDev &v = b.view[blockIdx.y];
-    const int n = v.n, chunk = blockIdx.x, i0 = chunk * kSortChunk, lane = threadIdx.x;
+    const int n = v.n, chunk = blockIdx.x, i0 = chunk * chunk_pts, lane = threadIdx.x;
     if (i0 >= n) return;
     __shared__ int hist[kBins];
     for (int k = lane; k < kBins; k += kWave) hist[k] = 0;
     __syncthreads();
     const GridDesc g = v.ds->grid;
     const int bshift = v.ds->bshift;
-    for (int r0 = 0; r0 < kSortChunk / kWave; r0 += kRoundsAhead) {
+    for (int r0 = 0; r0 < chunk_pts / kWave; r0 += kRoundsAhead) {
         int c[kRoundsAhead];
 #pragma unroll
         for (int k = 0; k < kRoundsAhead; ++k) {
@@ -428,16 +431,16 @@ __global__ __launch_bounds__(kWave) void bucket_hist_kernel(Batch b) {
         }
     }
     __syncthreads();
-    const int nchunks = sort_chunks(n);
+    const int nchunks = sort_chunks(n, chunk_pts);
     for (int k = lane; k < kBins; k += kWave) v.btable[(size_t)k * nchunks + chunk] = hist[k];
 }
 
 // points per bin over all chunks: one wave per bin
-__global__ __launch_bounds__(256) void bucket_total_kernel(Batch b) {
+__global__ __launch_bounds__(256) void bucket_total_kernel(Batch b, int chunk_pts) {
     const ViewDev &v = b.view[blockIdx.y];
     const int bin = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
     if (bin >= kBins) return;
-    const int nchunks = sort_chunks(v.n);
+    const int nchunks = sort_chunks(v.n, chunk_pts);
     const int *t = v.btable + (size_t)bin * nchunks;
     int sum = 0;
     for (int c = lane; c < nchunks; c += kWave) sum += t[c];
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(256) void bucket_total_kernel(Batch b) {
 // scans the kBins totals for itself (they are few); then one wave per bin scans the bin's chunks.
 // (Totals and starts are separate arrays: the blocks of this launch read ALL totals and finish at
 // different times.)
-__global__ __launch_bounds__(256) void bucket_offsets_kernel(Batch b) {
+__global__ __launch_bounds__(256) void bucket_offsets_kernel(Batch b, int chunk_pts) {
     const ViewDev &v = b.view[blockIdx.y];
     __shared__ int tot[kBins];
     __shared__ int wsum[256 / kWave];
@@ -481,7 +484,7 @@ __global__ __launch_bounds__(256) void bucket_offsets_kernel(Batch b) {
     __syncthreads();
     const int bin = blockIdx.x * (blockDim.x / kWave) + wid;
     if (bin >= kBins) return;
-    const int nchunks = sort_chunks(v.n);
+    const int nchunks = sort_chunks(v.n, chunk_pts);
     int *t = v.btable + (size_t)bin * nchunks;
     int pos = tot[bin];
     for (int c0 = 0; c0 < nchunks; c0 += kWave) {
@@ -499,17 +502,17 @@ __global__ __launch_bounds__(256) void bucket_offsets_kernel(Batch b) {
 }
 
 // rec[2 * position] = (x, y, z, index), rec[2 * position + 1] = (nx, ny, nz, cell): positions inside a bin in index order
-__global__ __launch_bounds__(kWave) void bucket_scatter_kernel(Batch b) {
+__global__ __launch_bounds__(kWave) void bucket_scatter_kernel(Batch b, int chunk_pts) {
     const ViewDev &v = b.view[blockIdx.y];
-    const int n = v.n, chunk = blockIdx.x, i0 = chunk * kSortChunk, lane = threadIdx.x;
+    const int n = v.n, chunk = blockIdx.x, i0 = chunk * chunk_pts, lane = threadIdx.x;
     if (i0 >= n) return;
     __shared__ int run[kBins];
     __shared__ int tag[kTagSlots];
     const int bshift = v.ds->bshift;
-    const int nchunks = sort_chunks(n);
+    const int nchunks = sort_chunks(n, chunk_pts);
     for (int k = lane; k < kBins; k += kWave) run[k] = v.btable[(size_t)k * nchunks + chunk];
     __syncthreads();
-    for (int r0 = 0; r0 < kSortChunk / kWave; r0 += kRoundsAhead) {
+    for (int r0 = 0; r0 < chunk_pts / kWave; r0 += kRoundsAhead) {
         int c[kRoundsAhead];
         float px[kRoundsAhead], py[kRoundsAhead], pz[kRoundsAhead], nx[kRoundsAhead], ny[kRoundsAhead], nz[kRoundsAhead];
 #pragma unroll
@@ -3662,7 +3665,14 @@ static void run_scan(const ScanJobs &jobs, int nviews, hipStream_t st) {
 
 // Index build ("initCompute") of every view of the batch: bounding box -> grid descriptor (on the
 // device) -> two-level stable counting sort.  7 launches whatever the batch size (8 with pos_of[]).
-size_t btable_ints(int n) { return (size_t)kBins * (size_t)sort_chunks(n > 0 ? n : 1) + 2 * kBins; }
+size_t btable_ints(int n) { return (size_t)kBins * (size_t)sort_chunks(n > 0 ? n : 1, kSortChunkSmall) + 2 * kBins; }     // (room for the small chunks)
+
+// points per chunk of the index sort's first level for this launch: both halves of the index build of a batch come here
+static int sort_chunk_points(const Batch &b) {
+    long long total = 0;
+    for (int v = 0; v < b.nviews; ++v) total += b.view[v].n;
+    return total <= 256 * 1024 ? kSortChunkSmall : kSortChunk;
+}
 
 void launch_index(const Batch &b, hipStream_t st) {
     launch_index_points(b, st);
@@ -3679,16 +3689,18 @@ void launch_index_points(const Batch &b, hipStream_t st) {
         bbox_kernel<<<dim3(blocks, nv), 256, 0, st>>>(b);
     }
     grid_setup_kernel<<<dim3(1, nv), 64, 0, st>>>(b);
-    if (n > 0) bucket_hist_kernel<<<dim3(sort_chunks(n), nv), kWave, 0, st>>>(b);
-    bucket_total_kernel<<<dim3(div_up(kBins, 256 / kWave), nv), 256, 0, st>>>(b);
-    bucket_offsets_kernel<<<dim3(div_up(kBins, 256 / kWave), nv), 256, 0, st>>>(b);
+    const int chunk_pts = sort_chunk_points(b);
+    if (n > 0) bucket_hist_kernel<<<dim3(sort_chunks(n, chunk_pts), nv), kWave, 0, st>>>(b, chunk_pts);
+    bucket_total_kernel<<<dim3(div_up(kBins, 256 / kWave), nv), 256, 0, st>>>(b, chunk_pts);
+    bucket_offsets_kernel<<<dim3(div_up(kBins, 256 / kWave), nv), 256, 0, st>>>(b, chunk_pts);
 }
 
 // second half: from the scatter on the NORMALS are read too (the 32-byte record travels with the key)
 void launch_index_records(const Batch &b, hipStream_t st) {
     const int nv = b.nviews, n = max_n(b);
     if (nv <= 0) return;
-    if (n > 0) bucket_scatter_kernel<<<dim3(sort_chunks(n), nv), kWave, 0, st>>>(b);
+    const int chunk_pts = sort_chunk_points(b);
+    if (n > 0) bucket_scatter_kernel<<<dim3(sort_chunks(n, chunk_pts), nv), kWave, 0, st>>>(b, chunk_pts);
     // cells of a bucket held in LDS at a time: what the largest cell table of the batch can need, at most
     // 1024 (two cells per thread in the workgroup's scan; kSortWaves counters per cell)
     int cap = 0;
