@@ -138,7 +138,6 @@ struct DevState {
     int ncells_needed;    // what this view needs (to grow the cell tables before a retry)
     int bshift, nbuckets; // index sort: nbuckets buckets of 2^bshift consecutive cells
     uint32_t bbox[6];     // order-preserving encoded min / max accumulators (self re-arming)
-    int bbox_ticket;      // workgroups of bbox_kernel that are done (fused launch: the last one sets up the grid; self re-arming)
     uint32_t scan_epoch;  // tag of the next detect call in the words of scan_state (advanced on the device, never 0)
     int scan_fail;        // set by a block of compact_scan_kernel whose look-back gave up: the call failed (kpl_sync_status -> KPL_ERR_INTERNAL, which clears it)
     int draws_left[kDrawRounds + 2];   // draws pass: [0] = listed maxima, [1] = undecided after the adjacency pass, [r + 2] = after round r

@@ -48,13 +48,7 @@ __device__ __forceinline__ const float *point_at(const char *base, size_t stride
 // ---------------------------------------------------------------------------------------------
 // bounding box of the finite points
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void grid_setup_view(const ViewDev &v);
-
-// fused (small launches, launch_index_points): the LAST workgroup of a view to finish also computes the grid descriptor
-// (grid_setup_view) and clears the bin totals that bucket_hist_kernel then adds up with atomics -- two launches less per
-// index build, ~9 us of a single-view call; in a batch of 8 x 200 k points the small kernels cost less than what replaces
-// them (round 2), so large launches keep them
-__global__ __launch_bounds__(256) void bbox_kernel(Batch b, int fused) {
+__global__ __launch_bounds__(256) void bbox_kernel(Batch b) {
     const ViewDev &v = b.view[blockIdx.y];
     const char *xyz = v.xyz;
     const size_t stride = v.xs;
@@ -100,19 +94,6 @@ __global__ __launch_bounds__(256) void bbox_kernel(Batch b, int fused) {
             atomicMax(&bbox[3 + k], enc_f32(b));
         }
     }
-    if (!fused) return;
-    __shared__ int s_last;
-    __threadfence();                                   // this workgroup's atomics before its ticket
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(&v.ds->bbox_ticket, 1) == (int)gridDim.x - 1 ? 1 : 0;
-    __syncthreads();
-    if (!s_last) return;
-    for (int k = threadIdx.x; k < kBuckets + 1; k += blockDim.x) v.btotal[k] = 0;
-    if (threadIdx.x == 0) {
-        __threadfence();                               // every other workgroup's atomics are in the L2 (they took a ticket)
-        v.ds->bbox_ticket = 0;                         // re-armed for the next call
-        grid_setup_view(v);
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -125,19 +106,18 @@ __device__ __forceinline__ float dec_f32_dev(uint32_t u) {
     return __uint_as_float(u);
 }
 
-__device__ __forceinline__ void grid_setup_view(const ViewDev &v) {
+__global__ void grid_setup_kernel(Batch b) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const ViewDev &v = b.view[blockIdx.y];
     DevState *ds = v.ds;
     float h = v.cell;
     const int n = v.n, cells_cap = v.cells_cap;
     GridDesc g;
-    // (the accumulators are read with atomic loads: in the fused launch other workgroups of THIS kernel wrote them)
-    uint32_t bb[6];
-    for (int k = 0; k < 6; ++k) bb[k] = __hip_atomic_load(&ds->bbox[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const bool any = n > 0 && bb[0] != 0xffffffffu;
+    const bool any = n > 0 && ds->bbox[0] != 0xffffffffu;
     if (!(h > 0.0f)) {
         // no radius given (cloud resolution): about two points per cell on a surface-like cloud
         float e[3];
-        for (int k = 0; k < 3; ++k) e[k] = any ? dec_f32_dev(bb[3 + k]) - dec_f32_dev(bb[k]) : 0.0f;
+        for (int k = 0; k < 3; ++k) e[k] = any ? dec_f32_dev(ds->bbox[3 + k]) - dec_f32_dev(ds->bbox[k]) : 0.0f;
         if (e[0] < e[1]) { float t = e[0]; e[0] = e[1]; e[1] = t; }
         if (e[1] < e[2]) { float t = e[1]; e[1] = e[2]; e[2] = t; }
         if (e[0] < e[1]) { float t = e[0]; e[0] = e[1]; e[1] = t; }
@@ -148,8 +128,8 @@ __device__ __forceinline__ void grid_setup_view(const ViewDev &v) {
     long long nc = any ? 1 : 0;
     int status = 0;
     for (int k = 0; k < 3; ++k) {
-        float mn = any ? dec_f32_dev(bb[k]) : 0.0f;
-        const float mx = any ? dec_f32_dev(bb[3 + k]) : 0.0f;
+        float mn = any ? dec_f32_dev(ds->bbox[k]) : 0.0f;
+        const float mx = any ? dec_f32_dev(ds->bbox[3 + k]) : 0.0f;
         if (v.has_origin) {             // the caller's grid frame (a slab of a larger cloud)
             if (any && !(v.origin[k] <= mn)) status = kStatusBadOrigin;
             mn = v.origin[k];
@@ -193,11 +173,6 @@ __device__ __forceinline__ void grid_setup_view(const ViewDev &v) {
         ds->bbox[k] = 0xffffffffu;
         ds->bbox[3 + k] = 0u;
     }
-}
-
-__global__ void grid_setup_kernel(Batch b) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    grid_setup_view(b.view[blockIdx.y]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -430,7 +405,7 @@ constexpr int kRoundsAhead = 8;          // rounds of a chunk whose loads are is
 
 // btable[bin * nchunks + chunk] = points of the chunk in the bin (a bin's chunks are contiguous: the
 // two kernels that turn counts into offsets give each bin to one wave); cid[i] = cell of point i (-1: none)
-__global__ __launch_bounds__(kWave) void bucket_hist_kernel(Batch b, int chunk_pts, int fused) {
+__global__ __launch_bounds__(kWave) void bucket_hist_kernel(Batch b, int chunk_pts) {
     const ViewDev &v = b.view[blockIdx.y];
     const int n = v.n, chunk = blockIdx.x, i0 = chunk * chunk_pts, lane = threadIdx.x;
     if (i0 >= n) return;
@@ -457,10 +432,7 @@ __global__ __launch_bounds__(kWave) void bucket_hist_kernel(Batch b, int chunk_p
     }
     __syncthreads();
     const int nchunks = sort_chunks(n, chunk_pts);
-    for (int k = lane; k < kBins; k += kWave) {
-        v.btable[(size_t)k * nchunks + chunk] = hist[k];
-        if (fused && hist[k] != 0) atomicAdd(&v.btotal[k], hist[k]);          // (integers: any order; cleared by bbox_kernel)
-    }
+    for (int k = lane; k < kBins; k += kWave) v.btable[(size_t)k * nchunks + chunk] = hist[k];
 }
 
 // points per bin over all chunks: one wave per bin
@@ -3711,16 +3683,15 @@ void launch_index(const Batch &b, hipStream_t st) {
 void launch_index_points(const Batch &b, hipStream_t st) {
     const int nv = b.nviews, n = max_n(b);
     if (nv <= 0) return;
-    const int chunk_pts = sort_chunk_points(b);
-    const int fused = (n > 0 && chunk_pts == kSortChunkSmall) ? 1 : 0;      // small launches: 5 instead of 7 kernels
     if (n > 0) {
         int blocks = div_up(n, 256);
         if (blocks > 64) blocks = 64;                   // 6 same-address atomics per block: keep them few
-        bbox_kernel<<<dim3(blocks, nv), 256, 0, st>>>(b, fused);
+        bbox_kernel<<<dim3(blocks, nv), 256, 0, st>>>(b);
     }
-    if (!fused) grid_setup_kernel<<<dim3(1, nv), 64, 0, st>>>(b);
-    if (n > 0) bucket_hist_kernel<<<dim3(sort_chunks(n, chunk_pts), nv), kWave, 0, st>>>(b, chunk_pts, fused);
-    if (!fused) bucket_total_kernel<<<dim3(div_up(kBins, 256 / kWave), nv), 256, 0, st>>>(b, chunk_pts);
+    grid_setup_kernel<<<dim3(1, nv), 64, 0, st>>>(b);
+    const int chunk_pts = sort_chunk_points(b);
+    if (n > 0) bucket_hist_kernel<<<dim3(sort_chunks(n, chunk_pts), nv), kWave, 0, st>>>(b, chunk_pts);
+    bucket_total_kernel<<<dim3(div_up(kBins, 256 / kWave), nv), 256, 0, st>>>(b, chunk_pts);
     bucket_offsets_kernel<<<dim3(div_up(kBins, 256 / kWave), nv), 256, 0, st>>>(b, chunk_pts);
 }
 
