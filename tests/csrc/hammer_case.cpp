@@ -8,6 +8,9 @@
 //     load     a second thread runs kpl_compute_device on a synthetic 200 k-point view on its own stream meanwhile
 //     fresh    host mode: the cloud is copied into freshly malloc'ed arrays before every call (what numpy does)
 //     syncdev  hipDeviceSynchronize between the calls
+//     newhandle host mode: a NEW handle for every call (kpl_create ... kpl_destroy): every call goes through the growth of the
+//              handle's tables -- for a view whose grid has 2.6e8 cells that is a 1 GB table, allocated and cleared, and
+//              the KPL_ERR_RETRY that follows (the round-3 / round-4 fuzz events were such views)
 // Exit code 0 = every iteration identical to the expectation, 1 = mismatches (reported, first ones dumped), 2 = setup error.
 #include <hip/hip_runtime.h>
 
@@ -204,13 +207,14 @@ int main(int argc, char **argv) {
         return 2;
     }
     const double budget = atof(argv[2]);
-    bool device = false, load = false, fresh = false, syncdev = false;
+    bool device = false, load = false, fresh = false, syncdev = false, newhandle = false;
     for (int a = 3; a < argc; ++a) {
         const std::string s = argv[a];
         device |= s == "device";
         load |= s == "load";
         fresh |= s == "fresh";
         syncdev |= s == "syncdev";
+        newhandle |= s == "newhandle";
     }
     kpl_detector *h = nullptr;
     if (kpl_create(&h, 0) != KPL_OK) {
@@ -246,7 +250,7 @@ int main(int argc, char **argv) {
     const auto t0 = std::chrono::steady_clock::now();
     auto elapsed = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
     while (elapsed() < budget) {
-        for (int rep = 0; rep < 64; ++rep, ++iters) {
+        for (int rep = 0; rep < (newhandle ? 4 : 64); ++rep, ++iters) {
             int cnt = -12345;
             const float *got_scores;
             const int *got_kp;
@@ -263,6 +267,17 @@ int main(int argc, char **argv) {
                 cnt = p_cnt[0];
                 got_scores = p_scores;
                 got_kp = p_kp;
+            } else if (newhandle) {
+                kpl_detector *hn = nullptr;
+                if (kpl_create(&hn, 0) != KPL_OK) {
+                    fprintf(stderr, "kpl_create failed\n");
+                    return 2;
+                }
+                configure(hn, c);
+                KPLCHECK(hn, kpl_detect(hn, c.xyz.data(), 12, c.nrm.data(), 12, n, scores.data(), kp.data(), n, &cnt));
+                kpl_destroy(hn);
+                got_scores = scores.data();
+                got_kp = kp.data();
             } else if (fresh) {
                 float *x = (float *)malloc(12 * (size_t)n + 4), *m = (float *)malloc(12 * (size_t)n + 4);
                 float *so = (float *)malloc(4 * (size_t)n + 4);
@@ -307,7 +322,7 @@ int main(int argc, char **argv) {
     g_stop = true;
     if (loader.joinable()) loader.join();
     printf("hammer: %ld iterations in %.1f s (%.1f us each), mode %s%s%s%s, load calls %ld, mismatches %ld\n", iters, secs,
-           1e6 * secs / (double)(iters ? iters : 1), device ? "device" : "host", load ? " +load" : "", fresh ? " +fresh" : "",
+           1e6 * secs / (double)(iters ? iters : 1), device ? "device" : "host", load ? " +load" : "", fresh ? " +fresh" : newhandle ? " +newhandle" : "",
            syncdev ? " +syncdev" : "", g_load_calls.load(), bad);
     kpl_destroy(h);
     return bad ? 1 : 0;
