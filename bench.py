@@ -230,11 +230,13 @@ def main():
         return g
 
     # ---- parity gate (rank 0): every view's keypoint list + scores must equal the oracle's --------
+    torch.cuda.synchronize()            # (the buffers above were filled on torch's default stream; the groups run on others)
     for g in range(ng):
         run_group(g)
     # first view of this size: cell tables may have to grow.  EVERY detector is synced (no short
     # circuit: a detector that is not synced keeps its small tables) until all of them report OK
     for attempt in range(4):
+        torch.cuda.synchronize()        # (syncStatus(None) waits for the NULL stream only: the groups' streams first)
         rcs = [d.syncStatus(None) for d in dets]
         if kpl.ERR_RETRY not in rcs:
             break

@@ -230,6 +230,13 @@ int ensure_cells(kpl_detector *h, int64_t cap) {
     KPL_HIP(h, hipDeviceSynchronize());
     KPL_HIP(h, h->cell_start.ensure(sizeof(int) * ((size_t)cap + 2)));
     KPL_HIP(h, hipMemset(h->cell_start.p, 0, sizeof(int) * ((size_t)cap + 2)));
+    // hipMemset returns BEFORE the clear is done (tests/csrc/memset_probe.cpp: 285 us whatever the size) and the null stream it
+    // runs on is not ordered against the handle's non-blocking stream: without this wait cell_sort_store_kernel of the call
+    // that follows wrote cell_start[] while the clear was still passing over it and lost its writes -- every point "outside
+    // the grid", every score NaN, no keypoint, status OK.  It took a 1 GB table (a view that needs ~2^28 cells) that no other
+    // reallocation of the same call happened to synchronise: the one fuzz event of round 3 and two of round 4
+    // (tools/repro_table_growth.py reproduces it in 7 of 20 tries on the old code; profiles/r04_notes.md section 1).
+    KPL_HIP(h, hipDeviceSynchronize());
     h->cells_cap = (int)cap;
     return KPL_OK;
 }
@@ -375,6 +382,7 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
         KPL_HIP(h, h->cand_count.ensure(sizeof(int)));
         KPL_HIP(h, hipMemset(h->flags.p, 0, h->flags.cap));       // kept zero by compact_kernel from here on
         KPL_HIP(h, hipMemset(h->cand_count.p, 0, sizeof(int)));
+        KPL_HIP(h, hipDeviceSynchronize());                      // (a null-stream clear is not ordered against the kernels' stream: ensure_cells)
     }
     KPL_HIP(h, h->cand_list.ensure(sizeof(int) * nn));
     KPL_HIP(h, h->prefix.ensure(sizeof(int) * (nn + 2)));
@@ -382,6 +390,7 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
         KPL_HIP(h, hipDeviceSynchronize());
         KPL_HIP(h, h->scan_state.ensure(scan_state_bytes(n)));
         KPL_HIP(h, hipMemset(h->scan_state.p, 0, h->scan_state.cap));     // tag 0 = "never written"
+        KPL_HIP(h, hipDeviceSynchronize());
     }
     const NmsDesc nd = make_nms(h->prm);
     if (nd.draws_remove) {
@@ -389,6 +398,7 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
             KPL_HIP(h, hipDeviceSynchronize());
             KPL_HIP(h, h->skip.ensure(sizeof(int) * nn));
             KPL_HIP(h, hipMemset(h->skip.p, 0, h->skip.cap));             // kept zero by compact_kernel
+            KPL_HIP(h, hipDeviceSynchronize());
         }
         KPL_HIP(h, h->draw_list.ensure(sizeof(int) * (nn * (2 + kDrawAdj) + 8)));     // list, adjacency counts, adjacency (kernels.hip draw_adj_offset)
         KPL_HIP(h, h->draw_count.ensure(sizeof(int)));
@@ -719,7 +729,8 @@ int kpl_create(kpl_detector **out, int device) {
     }
     init_dev_state(h->h_state);
     if (const char *e = getenv("KPL_DEBUG_SCAN_POLL_LIMIT")) set_scan_poll_limit(atoi(e));      // tests: force the scan's failure path
-    if (hipMemcpy(h->dstate.p, h->h_state, sizeof(DevState), hipMemcpyHostToDevice) != hipSuccess) {
+    if (hipMemcpy(h->dstate.p, h->h_state, sizeof(DevState), hipMemcpyHostToDevice) != hipSuccess ||
+        hipDeviceSynchronize() != hipSuccess) {          // (the null stream is not ordered against the handle's stream)
         kpl_destroy(h);
         return KPL_ERR_DEVICE;
     }

@@ -150,6 +150,7 @@ int prepare(Worker &w, const Options &o) {
         CHECK_HIP(hipMalloc((void **)&v.d_xyz, nn * sizeof(PointInT)));
         CHECK_HIP(hipMalloc((void **)&v.d_nrm, nn * sizeof(PointNormalT)));
         if (v.n) CHECK_HIP(hipMemcpy(v.d_xyz, v.cloud.points.data(), (size_t)v.n * sizeof(PointInT), hipMemcpyHostToDevice));
+        CHECK_HIP(hipDeviceSynchronize());        // (the copy above ran on the null stream; w.st[] are non-blocking streams)
         CHECK_KPL(v.h, kpl_bind_cloud_device(v.h, v.d_xyz, sizeof(PointInT), v.d_nrm, sizeof(PointNormalT), v.n));
         if ((int)v.file_normals.size() == v.n && v.n) {
             CHECK_HIP(hipMemcpy(v.d_nrm, v.file_normals.points.data(), (size_t)v.n * sizeof(PointNormalT), hipMemcpyHostToDevice));
@@ -173,6 +174,9 @@ int prepare(Worker &w, const Options &o) {
     CHECK_HIP(hipMalloc((void **)&w.d_send, sizeof(int) * slot_ints(w.cap) * (size_t)w.slots));
     CHECK_HIP(hipMalloc((void **)&w.d_recv, sizeof(int) * slot_ints(w.cap) * (size_t)w.slots * (size_t)w.nranks));
     CHECK_HIP(hipMemset(w.d_send, 0, sizeof(int) * slot_ints(w.cap) * (size_t)w.slots));
+    // the null stream of the copies and the clear above is NOT ordered against the non-blocking streams the scoring runs
+    // on, and hipMemset returns before it is done (tests/csrc/memset_probe.cpp)
+    CHECK_HIP(hipDeviceSynchronize());
     return 0;
 }
 

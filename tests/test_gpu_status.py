@@ -144,3 +144,32 @@ def test_hammer_and_probe_run_clean(tmp_path):
         assert "mismatches 0" in out.stdout
     out = subprocess.run([os.path.join(ROOT, "tests", "csrc", "pageable_copy_probe"), "20"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "PROBE: clean" in out.stdout, out.stdout[-1500:] + out.stderr[-500:]
+
+
+def test_table_growth_is_ordered_before_the_kernels(kpl, cases):
+    """ROOT CAUSE of the round-3 / round-4 fuzz events (profiles/r04_notes.md section 1): hipMemset returns before the clear
+    is done and the null stream is not ordered against the handle's non-blocking stream, so a cell table that was just
+    grown and cleared could lose the writes of cell_sort_store_kernel -- every score NaN, no keypoint, status OK -- when the
+    table is ~1 GB (a view that needs ~2^28 grid cells) and nothing else of the call happens to synchronise (a handle
+    whose other tables are already large enough).  This sequence failed in 7 of 20 tries before the fix
+    (tools/repro_table_growth.py): the same view at a radius that needs 1.8e8 cells, then at one that needs 2.4e8."""
+    from tools import case_blob
+    c = case_blob.load_case(os.path.join(ROOT, "tests", "golden", "fuzz_r04_9004.npz"))
+    r_a, r_b = c["r"] * 1.137, c["r"] * 1.026
+    from oracle import kplo
+    forest = kplo.Forest(c["root"], c["var"], c["thrs"], c["left"], c["right"], c["value"], c["A"] * c["B"])
+    o_sc, o_kp = kplo.detect(c["xyz"], c["nrm"], c["A"], c["B"], r_b, c["rn"], c["thr"], forest, non_maxima=c["nms"], draws_remove=False)
+    assert len(o_kp) > 1000
+    for it in range(12):
+        det = kpl.KeypointLearningDetector()
+        det.setNAnnulus(c["A"]); det.setNBins(c["B"]); det.setNonMaxima(c["nms"]); det.setNonMaxRadius(c["rn"])
+        det.setNonMaximaDrawsRemove(False); det.setPredictionThreshold(c["thr"])
+        det.loadForestArrays(c["root"], c["var"], c["thrs"], c["left"], c["right"], c["value"], c["A"] * c["B"])
+        det.setInputCloud(c["xyz"]); det.setNormals(c["nrm"])
+        det.setRadiusSearch(r_a)
+        det.compute()
+        det.setRadiusSearch(r_b)
+        _, sc = det.compute()
+        assert cases.same_bits(sc, o_sc), "iteration %d: %d NaN scores of %d" % (it, int(np.isnan(sc).sum()), len(sc))
+        assert np.array_equal(det.getKeypointsIndices(), o_kp), it
+        det.close()
