@@ -72,6 +72,12 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+    msrc, mexe = os.path.join(tdir, "memset_probe.cpp"), os.path.join(tdir, "memset_probe")
+    if os.path.exists(msrc) and (force or _stale(mexe, [msrc])):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O2", "-o", mexe, msrc]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
     psrc, pexe = os.path.join(tdir, "pageable_copy_probe.cpp"), os.path.join(tdir, "pageable_copy_probe")
     if os.path.exists(psrc) and (force or _stale(pexe, [psrc])):
         cmd = [HIPCC, "-O2", "-o", pexe, psrc]
