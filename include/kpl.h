@@ -17,7 +17,9 @@
  * return when their results are in the caller's buffers; the *_device entry points only enqueue on the
  * stream they are given.  Both kinds use the handle's scratch: before mixing them on ONE handle, wait for
  * the stream of the earlier *_device call (kpl_sync_status or hipStreamSynchronize) -- nothing orders them
- * implicitly, not even the null stream.
+ * implicitly, not even the null stream (and a clear or copy the CALLER issues on the null stream -- hipMemset, hipMemcpy --
+ * is not ordered against a non-blocking stream either, nor complete when it returns: hipDeviceSynchronize() before handing
+ * such a buffer to a *_device entry point on another stream).
  * There is NO CPU fallback: without a usable HIP device every compute call fails with
  * KPL_ERR_DEVICE.
  */
