@@ -115,6 +115,7 @@ def main():
             send = packed[:, :cap + 1].contiguous().view(-1)
             gathered[0] = kd.gather_keypoints(send if args.backend == "nccl" else send.cpu())
 
+    torch.cuda.synchronize()            # (the buffers above were filled on the default stream; the batches run on others)
     job()
     while kpl.ERR_RETRY in [d.syncStatus(None) for d in dets]:
         job()

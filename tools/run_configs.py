@@ -212,6 +212,7 @@ def cfg3():
             kpl.compute_batch_device(dets[sl], [b[2].data_ptr() for b in bufs[sl]], [b[3][1:].data_ptr() for b in bufs[sl]],
                                      [len(b[2]) for b in bufs[sl]], [b[3][0:1].data_ptr() for b in bufs[sl]],
                                      streams[g].cuda_stream)
+    torch.cuda.synchronize()            # (the buffers above were filled on the default stream; the sweeps run on others)
     sweep()
     torch.cuda.synchronize()
     while kpl.ERR_RETRY in [det.syncStatus(None) for det in dets]:   # every detector, no short circuit
