@@ -173,6 +173,16 @@ def main():
         mr = kplo.cloud_resolution(xyz) if n > 1 else 1.0
         mr = mr if mr > 0 else 1.0
         r = float(np.float32(mr * rng.uniform(1.5, 9.0)))
+        # one case in 400: a radius so small against the extent of the cloud that the grid has 1e8 .. 2.7e8 cells (the limit is
+        # 2^28): a cell table of ~1 GB that the handle has to grow -- the class of view behind the fuzz events of rounds 3 and 4
+        # (an asynchronous clear of that table raced with the index build, profiles/r04_notes.md section 1)
+        if n > 50 and rng.random() < 0.0025:
+            fin = np.isfinite(xyz).all(axis=1)
+            if fin.sum() > 10:
+                ext = (xyz[fin].max(axis=0) - xyz[fin].min(axis=0)).astype(np.float64)
+                vol = float(np.prod(np.maximum(ext, 1e-9)))
+                if vol > 0:
+                    r = float(np.float32((vol / rng.uniform(1.0e8, 2.7e8)) ** (1.0 / 3.0)))
         rn = float(np.float32(mr * rng.uniform(0.0, 6.0)))
         thr = float(np.float32(rng.choice([0.0, 0.3, 0.5, 0.85, 1.0])))
         nms, draws = bool(rng.random() < 0.85), bool(rng.random() < 0.4)
