@@ -3749,8 +3749,6 @@ static int cu_count() {
 // Fewer words for the largest histograms so that a handful of waves still fit a CU (160 KB of LDS).
 constexpr int kLdsPerCu = 160 * 1024;
 static int accept_words(int F) {
-    static const int forced = getenv("KPL_EXP_ECAP") ? atoi(getenv("KPL_EXP_ECAP")) : 0;      // (experiments only)
-    if (forced > 0) return forced;
     int e = 24;
     while (e > 4 && feature_lds_bytes<kGroup>(F, e) * 6 > (size_t)kLdsPerCu) e -= 4;
     return e;
