@@ -57,6 +57,7 @@ class Stats(C.Structure):
 _vp, _ip, _fp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float)
 SYMBOLS = {
     "kpl_version": (C.c_int, []),
+    "kpl_source_hash": (C.c_char_p, []),
     "kpl_status_string": (C.c_char_p, [C.c_int]),
     "kpl_default_params": (None, [C.POINTER(Params)]),
     "kpl_create": (C.c_int, [C.POINTER(_vp), C.c_int]),

@@ -20,6 +20,17 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-fno-fast-math", "-Wall", "-Wno-unused-result", "-x", "hip"]
 
 
+def source_hash():
+    """sha256 over the sources and headers libkpl.so is built from: compiled into the library (kpl_source_hash) so that a
+    binary can be told apart from one built from other sources (tests/test_abi.py)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(SOURCES + HEADERS):
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read() + b"\0")
+    return h.hexdigest()
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -30,12 +41,17 @@ def _stale(target, deps):
 def build(force=False, verbose=False):
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     deps = srcs + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    sha = source_hash()
+    stamp = os.path.join(CSRC, ".build_hash")
+    built_from = open(stamp).read().strip() if os.path.exists(stamp) else ""
+    if built_from != sha:
+        force = True                       # (mtimes lie after a checkout; the hash does not)
     if force or _stale(LIB, deps):
         objs = []
         for s in srcs:
             o = os.path.splitext(s)[0] + ".o"
             if force or _stale(o, deps):
-                cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+                cmd = [HIPCC] + FLAGS + ['-DKPL_SOURCE_SHA="%s"' % sha, "-c", s, "-o", o]
                 if verbose:
                     print(" ".join(cmd))
                 subprocess.check_call(cmd)
@@ -45,6 +61,8 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+        with open(stamp, "w") as f:
+            f.write(sha + "\n")
     for name, tsrcs in TOOLS.items():
         tpaths = [os.path.join(CSRC, s) for s in tsrcs]
         if not all(os.path.exists(p) for p in tpaths):

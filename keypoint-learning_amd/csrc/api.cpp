@@ -677,6 +677,11 @@ extern "C" {
 
 int kpl_version(void) { return KPL_VERSION; }
 
+#ifndef KPL_SOURCE_SHA
+#define KPL_SOURCE_SHA "unknown"
+#endif
+const char *kpl_source_hash(void) { return KPL_SOURCE_SHA; }
+
 const char *kpl_status_string(int s) {
     switch (s) {
         case KPL_OK: return "ok";
