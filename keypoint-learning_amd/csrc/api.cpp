@@ -411,7 +411,7 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
     if (h->prm.neighbor_order == KPL_NEIGHBORS_SORTED) {
         // segments of sorted neighbor keys for the points with large neighborhoods: 64 keys per point to begin with; a
         // view that needs more fails its first call with KPL_ERR_RETRY and finds the array grown (sync_status)
-        KPL_HIP(h, h->large_list.ensure(sizeof(int) * nn));
+        KPL_HIP(h, h->large_list.ensure(sizeof(int) * 2 * nn));         // all large points + the ones for the workgroup kernel
         KPL_HIP(h, h->seg_start.ensure(sizeof(unsigned) * nn));
         KPL_HIP(h, h->seg_len.ensure(sizeof(int) * nn));
         if (h->sort_keys.cap < sizeof(unsigned long long) * 64 * nn) KPL_HIP(h, h->sort_keys.ensure(sizeof(unsigned long long) * 64 * nn));

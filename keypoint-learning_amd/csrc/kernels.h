@@ -111,7 +111,8 @@ struct ViewDev {
     StatsDev *stats;             // null unless counters are collected
     // sorted-search mode, large neighborhoods (kernels.hip "sorted mode, large neighborhoods"): scoreable points whose search
     // box holds more than kLargeCand candidates, their neighbor keys sorted by (d2, index) in one array, a segment per point
-    int *large_list;                 // [n] storage positions of those points (any order); their number: DevState::large_count
+    int *large_list;                 // [2 n] storage positions of those points (any order); their number: DevState::large_count.
+                                     // From [n] on: the ones with more keys than a wave sorts (DevState::huge_count)
     unsigned long long *sort_keys;   // [key_cap] the segments
     unsigned *seg_start;             // [n] by storage position: first key of the point's segment
     int *seg_len;                    // [n] its length (0: none, or the keys did not fit -> DevState::status)
@@ -144,7 +145,7 @@ struct DevState {
     // sorted-search mode, large neighborhoods: both counters are zero between calls (the compaction's last block re-arms them
     // after copying the cursor to keys_needed, which is what kpl_sync_status grows ViewDev::sort_keys to on kStatusKeyCapacity)
     int large_count;                   // points in ViewDev::large_list
-    int pad_;
+    int huge_count;                    // of them, points left to the workgroup kernel (second half of large_list)
     unsigned long long key_cursor;     // keys handed out of ViewDev::sort_keys so far (counts on past key_cap)
     unsigned long long keys_needed;    // key_cursor of the last call
 };

@@ -1966,6 +1966,27 @@ __device__ __forceinline__ WavePoint wave_point(const ViewDev &a, int chunk, int
     return w;
 }
 
+// Which view and which block of it a workgroup of a (blocks, views) grid takes.  Workgroups go to the 8 XCDs round robin by
+// their linear number; `by_xcd` deals the VIEWS the same way -- with 8 views every XCD works on one view and its 4 MB of L2
+// hold what that view reads at random (the sorted-search mode reads the caller's normals by original index: 2.4 MB per
+// 200 k-point view, 19 MB for 8 views that every XCD touches otherwise).  Only for views of about the same size
+// (launch_score): an XCD is not given work by how much it has left.
+struct ViewBlock {
+    unsigned view, bx;
+};
+__device__ __forceinline__ ViewBlock view_block(int by_xcd) {
+    ViewBlock r;
+    if (by_xcd) {
+        const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
+        r.view = lin % gridDim.y;
+        r.bx = lin / gridDim.y;
+    } else {
+        r.view = blockIdx.y;
+        r.bx = blockIdx.x;
+    }
+    return r;
+}
+
 // Sorted-search mode: which points take the path for LARGE neighborhoods (sorted_collect_kernel / sorted_add_kernel) without
 // being searched here first.  A cheap test on the index alone -- the population of the point's own cell (one pair of
 // cell_start[] entries): the box of a point holds about nine such cells on a surface, so more than kLargeCell points in the
@@ -2008,13 +2029,14 @@ __global__ __launch_bounds__(kLanes) void feature_kernel(Batch b, int maxF, int 
 // the same for the views in sorted-search mode: kSortGroup lanes per point, 64 / kSortGroup points per wave
 //   LDS: [H: maxF x 16 floats][accept words: ecap x 16 uint2][key lists: lcap x 16 keys of 8 bytes]
 template <bool STATS>
-__global__ __launch_bounds__(kLanes) void feature_sorted_kernel(Batch b, int maxF, int ecap, int lcap) {
+__global__ __launch_bounds__(kLanes) void feature_sorted_kernel(Batch b, int maxF, int ecap, int lcap, int by_xcd) {
     extern __shared__ float H[];
     constexpr int G = kSortGroup, kPts = kLanes / G;
-    const ViewDev &v = b.view[blockIdx.y];
+    const ViewBlock vb = view_block(by_xcd);
+    const ViewDev &v = b.view[vb.view];
     if (!v.f.sorted) return;
-    const int chunk = blockIdx.x / G, pi = threadIdx.x / G, gq = threadIdx.x % G;
-    const int col = (blockIdx.x % G) * kPts + pi;
+    const int chunk = vb.bx / G, pi = threadIdx.x / G, gq = threadIdx.x % G;
+    const int col = (vb.bx % G) * kPts + pi;
     if (chunk * kLanes + col - pi >= v.n) return;
     const WavePoint w = wave_point(v, chunk, col, true);
     // a point with a large neighborhood is scored by sorted_collect_kernel + sorted_add_kernel (below): no rows here, and
@@ -2022,13 +2044,26 @@ __global__ __launch_bounds__(kLanes) void feature_sorted_kernel(Batch b, int max
     const bool large = is_large_point(v.ds->grid, v.cell_start, w, v.f.rr);
     uint2 *ent = reinterpret_cast<uint2 *>(H + maxF * kPts);
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(ent + ecap * kPts);
-    bool deferred;
-    const int kf = point_features_sorted<G, true>(v.pts, v.nrmsrc, v.ns, v.cell_start, v.ds->grid, v.f, w.p, w.np, H, ent, ecap,
-                                                  keys, lcap, w.scoreable && !large, deferred);
-    if (deferred || large) {    // a large box, or more neighbors than the list holds: a point for sorted_collect_kernel / sorted_add_kernel
-        if (gq == 0) v.large_list[atomicAdd(&v.ds->large_count, 1)] = w.s;
-        return;
+    bool deferred = false;
+    int kf = 0;
+    if (__any(w.scoreable && !large))           // (a wave whose points are all large only lists them)
+        kf = point_features_sorted<G, true>(v.pts, v.nrmsrc, v.ns, v.cell_start, v.ds->grid, v.f, w.p, w.np, H, ent, ecap,
+                                            keys, lcap, w.scoreable && !large, deferred);
+    else
+        for (int c = gq; c < v.f.F; c += G) H[c * kPts + pi] = 0.0f;      // (what a point that is not scored leaves in its column)
+    // a large box, or more neighbors than the list holds: a point for the collect / add kernels.  ONE atomic per wave for its
+    // (up to 16) listed points: returning atomics on one address complete one after the other, ~18 ns each -- a view whose
+    // 200 k points all went to the list one by one spent 3.7 ms on nothing else (profiles/r04_notes.md)
+    const bool listed = deferred || large;
+    const unsigned long long lbal = __ballot(listed && gq == 0);
+    if (lbal != 0ull) {
+        const int lane = threadIdx.x;
+        int base = 0;
+        if (lane == __builtin_ctzll(lbal)) base = atomicAdd(&v.ds->large_count, __popcll(lbal));
+        base = __builtin_amdgcn_readlane(base, __builtin_ctzll(lbal));
+        if (listed && gq == 0) v.large_list[base + __popcll(lbal & ((1ull << lane) - 1ull))] = w.s;
     }
+    if (listed) return;
     if (STATS && w.scoreable && gq == 0) atomicAdd(&v.stats->sum_kf, (unsigned long long)kf);
     float *o = v.feat + (size_t)chunk * v.f.F * kLanes + col;
     for (int c = gq; c < v.f.F; c += G) o[c * kLanes] = H[c * kPts + pi];
@@ -2326,6 +2361,224 @@ __global__ __launch_bounds__(kLanes) void features_sorted_kernel(const float4 *_
 constexpr int kCollectThreads = 256, kCollectKeys = 4096, kCollectBuckets = 1024, kCollectAhead = 4;
 constexpr int kInsertionMax = 48;        // keys a thread orders by insertion; more in its buckets: the whole list by the network
 
+// ---- neighborhoods of up to kWaveKeys keys: ONE WAVE PER POINT (sorted_collect_wave_kernel) -------------------------------
+// Between what the register lists of feature_sorted_kernel hold (124 keys) and the neighborhoods the workgroup kernel below
+// is built for (thousands) a workgroup per point is mostly fixed cost: barriers per piece, a 1 024-bucket counting pass
+// for 200 keys (8 views of 200 k points at 10 mesh resolutions, K_f = 190: 14 ms of collect against 1.4 ms for the whole
+// canonical feature kernel).  Here every wave takes points of its own: the rows of the box 128 candidates at a time (the next
+// piece in flight), the accepted keys appended to the wave's list in LDS by ballot, the list then sorted IN REGISTERS -- E =
+// 1, 2, 4 or 8 keys per lane (blocked: lane l holds elements E l .. E l + E - 1), a bitonic network whose partners inside a
+// lane are registers and across lanes come through ds_bpermute -- and written to the point's segment of sort_keys.  A point
+// with more candidates in its box than kWaveCandidates, or more than kWaveKeys accepted, goes to the second half of
+// large_list (DevState::huge_count) for the workgroup kernel.
+constexpr int kWaveKeys = 512, kWaveCollectWaves = 4, kWaveAhead = 2;
+constexpr unsigned kWaveChunk = 2048;               // keys a wave takes from the key array at a time (16 KB)
+constexpr int kWaveCandidates = 6 * kWaveKeys;       // ~4.4 candidates per neighbor on a surface: beyond, the list would not hold them
+
+// the value of lane l ^ D: DPP moves inside a row of 16 lanes (no LDS crossbar, no wait), ds_bpermute across rows
+template <int D>
+__device__ __forceinline__ unsigned lane_xor32(unsigned x) {
+    if (D == 1) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, true);       // quad_perm [1,0,3,2]
+    if (D == 2) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, true);       // quad_perm [2,3,0,1]
+    if (D == 4) {       // banks 0 and 2 of a row (lanes 0-3, 8-11) read 4 lanes up (row_shl:4), banks 1 and 3 read 4 lanes down (row_shr:4)
+        const int t = __builtin_amdgcn_update_dpp(0, (int)x, 0x104, 0xf, 0x5, false);
+        return (unsigned)__builtin_amdgcn_update_dpp(t, (int)x, 0x114, 0xf, 0xa, false);
+    }
+    if (D == 8) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xf, 0xf, true);      // row_ror:8
+    return (unsigned)__shfl_xor((int)x, D);
+}
+template <int D>
+__device__ __forceinline__ unsigned long long lane_xor64(unsigned long long x) {
+    return ((unsigned long long)lane_xor32<D>((unsigned)(x >> 32)) << 32) | lane_xor32<D>((unsigned)x);
+}
+
+// (d is a constant wherever the network's loops are unrolled: the switch folds)
+__device__ __forceinline__ unsigned long long lane_xor64(unsigned long long x, int d) {
+    switch (d) {
+    case 1: return lane_xor64<1>(x);
+    case 2: return lane_xor64<2>(x);
+    case 4: return lane_xor64<4>(x);
+    case 8: return lane_xor64<8>(x);
+    case 16: return lane_xor64<16>(x);
+    default: return lane_xor64<32>(x);
+    }
+}
+
+template <int E>
+__device__ __forceinline__ void wave_sort_store(const unsigned long long *list, int n, int lane, unsigned long long *__restrict__ out) {
+    unsigned long long r[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = lane * E + e;
+        r[e] = i < n ? list[i] : ~0ull;
+    }
+#pragma unroll
+    for (int k = 2; k <= kWave * E; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j < E) {                        // partners inside the lane: elements e and e | j
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    if ((e & j) != 0) continue;
+                    const bool up = k < E ? (e & k) == 0 : (lane & (k / E)) == 0;
+                    const unsigned long long a = r[e], c = r[e | j];
+                    const bool sw = (a > c) == up;
+                    r[e] = sw ? c : a;
+                    r[e | j] = sw ? a : c;
+                }
+            } else {                            // partner lane l ^ (j / E), the same element; the lower lane keeps the minimum when ascending
+                const bool keep_min = ((lane & (j / E)) == 0) == ((lane & (k / E)) == 0);
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const unsigned long long o = lane_xor64(r[e], j / E);
+                    r[e] = ((o < r[e]) == keep_min) ? o : r[e];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = lane * E + e;
+        if (i < n) out[i] = r[e];
+    }
+}
+
+__global__ __launch_bounds__(kWaveCollectWaves *kWave) void sorted_collect_wave_kernel(Batch b, int by_xcd) {
+    __shared__ unsigned long long lists[kWaveCollectWaves][kWaveKeys];
+    const ViewBlock vb = view_block(by_xcd);
+    const ViewDev &v = b.view[vb.view];
+    if (!v.f.sorted) return;
+    DevState *ds = v.ds;
+    const int nlarge = ds->large_count;
+    const GridDesc g = ds->grid;
+    const float4 *__restrict__ pts = v.pts;
+    const int *__restrict__ cell_start = v.cell_start;
+    int *__restrict__ huge_list = v.large_list + v.n;
+    const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+    unsigned long long *list = lists[wid];
+    const float r2 = v.f.r2;
+    const int nwaves = gridDim.x * kWaveCollectWaves;
+    // first position and end of row r of the box of p in lane r < 16 (empty where the box has none)
+    auto box_rows = [&](const float4 &p, bool valid_point, int &row0, int &row1) {
+        row0 = row1 = 0;
+        CellBox bx = make_box(g, p.x, p.y, p.z, v.f.rr);
+        bx.hi[1] = min(bx.hi[1], bx.lo[1] + 3);
+        bx.hi[2] = min(bx.hi[2], bx.lo[2] + 3);
+        if (valid_point && lane < 16) {
+            const int z = bx.lo[2] + lane / 4, y = bx.lo[1] + lane % 4;
+            if (z <= bx.hi[2] && y <= bx.hi[1]) {
+                const int row = (z * g.dims[1] + y) * g.dims[0];
+                row0 = cell_start[row + bx.lo[0]];
+                row1 = cell_start[row + bx.hi[0] + 1];
+            }
+        }
+    };
+    // The chain list entry -> point -> row bounds of the NEXT point is requested while the current one is collected and sorted
+    // (three dependent round trips per point otherwise, with five waves per SIMD to hide them).
+    // Key segments come out of chunks of kWaveChunk keys that the wave takes from DevState::key_cursor with one atomic each
+    // (one atomic per POINT on that one address was 3.6 of the kernel's 5 ms at 200 keys per point); what is left of a chunk
+    // when the next list does not fit is not used (counted in key_cursor, like everything handed out).  With few points per
+    // wave a point takes exactly its keys: nothing to gain there, and small arrays are not wasted on.
+    const unsigned chunk_keys = nlarge >= 8 * nwaves ? kWaveChunk : 0u;
+    unsigned long long chunk_pos = 0ull, chunk_end = 0ull;
+    int li = vb.bx * kWaveCollectWaves + wid;
+    int s_cur = li < nlarge ? v.large_list[li] : -1;
+    int s_nxt = li + nwaves < nlarge ? v.large_list[li + nwaves] : -1;
+    float4 p = pts[max(s_cur, 0)];
+    int my_r0, my_r1;
+    box_rows(p, s_cur >= 0, my_r0, my_r1);
+    while (s_cur >= 0) {
+        const int s = s_cur;
+        const int li_nn = li + 2 * nwaves;
+        const int s_nn = li_nn < nlarge ? v.large_list[li_nn] : -1;
+        const float4 p_nxt = pts[max(s_nxt, 0)];
+        int cands = my_r1 - my_r0;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) cands += __shfl_xor(cands, off);
+        cands = __builtin_amdgcn_readfirstlane(cands);
+        int cnt = 0;
+        if (cands <= kWaveCandidates) {
+            wave_lds_fence();                   // (the list of the point before has been read into registers)
+            constexpr int kPiece = kWave * kWaveAhead;
+            int row = -1, t0 = 0, r1 = 0;       // (uniform) the piece [t0, min(t0 + kPiece, r1)) of row `row`
+            auto advance = [&]() -> bool {
+                t0 += kPiece;
+                while (t0 >= r1) {
+                    if (++row >= 16) return false;
+                    t0 = __builtin_amdgcn_readlane(my_r0, row);
+                    r1 = __builtin_amdgcn_readlane(my_r1, row);
+                }
+                return true;
+            };
+            auto load_piece = [&](float4 (&q)[kWaveAhead]) {
+#pragma unroll
+                for (int a = 0; a < kWaveAhead; ++a) q[a] = pts[min(t0 + a * kWave + lane, r1 - 1)];
+            };
+            float4 cur[kWaveAhead], nxt[kWaveAhead];
+            bool have = advance();
+            if (have) load_piece(cur);
+            while (have) {
+                const int c_t0 = t0, c_r1 = r1;
+                const bool have_next = advance();
+                if (have_next) load_piece(nxt);
+#pragma unroll
+                for (int a = 0; a < kWaveAhead; ++a) {
+                    const float d2 = dist2(p.x, p.y, p.z, cur[a]);
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)(unsigned)__float_as_int(cur[a].w);
+                    const bool take = c_t0 + a * kWave + lane < c_r1 && d2 < r2;                    // strict (KdTreeFLANN)
+                    const unsigned long long bal = __ballot(take);
+                    const int slot = cnt + __popcll(bal & ((1ull << lane) - 1ull));
+                    if (take && slot < kWaveKeys) list[slot] = key;
+                    cnt += __popcll(bal);
+                }
+#pragma unroll
+                for (int a = 0; a < kWaveAhead; ++a) cur[a] = nxt[a];
+                have = have_next;
+            }
+        }
+        int nr0, nr1;
+        box_rows(p_nxt, s_nxt >= 0, nr0, nr1);                      // (requested here, used by the next turn of the loop)
+        if (cands > kWaveCandidates || cnt > kWaveKeys) {          // (uniform) not a list for one wave
+            if (lane == 0) huge_list[atomicAdd(&ds->huge_count, 1)] = s;
+        } else {
+            if (chunk_end - chunk_pos < (unsigned long long)cnt) {           // (uniform) a new chunk
+                const unsigned long long take = (unsigned)cnt > chunk_keys ? (unsigned long long)cnt : (unsigned long long)chunk_keys;
+                unsigned off_lo = 0u, off_hi = 0u;
+                if (lane == 0) {
+                    const unsigned long long o = atomicAdd(&ds->key_cursor, take);
+                    off_lo = (unsigned)o;
+                    off_hi = (unsigned)(o >> 32);
+                }
+                chunk_pos = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)off_hi) << 32) |
+                            (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)off_lo);
+                chunk_end = chunk_pos + take;
+            }
+            const bool fits = chunk_pos + (unsigned long long)cnt <= v.key_cap;
+            const unsigned long long off = fits ? chunk_pos : ~0ull;
+            chunk_pos += (unsigned long long)cnt;
+            if (lane == 0) {
+                if (!fits) atomicCAS(&ds->status, kStatusOk, kStatusKeyCapacity);
+                v.seg_start[s] = (unsigned)off;
+                v.seg_len[s] = fits ? cnt : 0;
+            }
+            if (off != ~0ull) {                 // (no room: this call fails, the next one has it -- kpl_sync_status)
+                unsigned long long *out = v.sort_keys + off;
+                wave_lds_fence();               // the list is complete
+                if (cnt <= kWave) wave_sort_store<1>(list, cnt, lane, out);
+                else if (cnt <= 2 * kWave) wave_sort_store<2>(list, cnt, lane, out);
+                else if (cnt <= 4 * kWave) wave_sort_store<4>(list, cnt, lane, out);
+                else wave_sort_store<8>(list, cnt, lane, out);
+            }
+        }
+        li += nwaves;
+        s_cur = s_nxt;
+        s_nxt = s_nn;
+        p = p_nxt;
+        my_r0 = nr0;
+        my_r1 = nr1;
+    }
+}
+
 __global__ __launch_bounds__(kCollectThreads) void sorted_collect_kernel(Batch b) {
     __shared__ unsigned long long keys[kCollectKeys];
     __shared__ int hist[kCollectBuckets];
@@ -2335,7 +2588,8 @@ __global__ __launch_bounds__(kCollectThreads) void sorted_collect_kernel(Batch b
     const ViewDev &v = b.view[blockIdx.y];
     if (!v.f.sorted) return;
     DevState *ds = v.ds;
-    const int nlarge = ds->large_count;
+    const int nlarge = ds->huge_count;                      // what sorted_collect_wave_kernel left to this kernel
+    const int *__restrict__ huge_list = v.large_list + v.n;
     const GridDesc g = ds->grid;
     const float4 *__restrict__ pts = v.pts;
     const int *__restrict__ cell_start = v.cell_start;
@@ -2343,7 +2597,7 @@ __global__ __launch_bounds__(kCollectThreads) void sorted_collect_kernel(Batch b
     const float r2 = v.f.r2;
     const unsigned long long key_end = (unsigned long long)__float_as_uint(r2) << 32;     // every key is below it (d2 < r2)
     for (int li = blockIdx.x; li < nlarge; li += gridDim.x) {
-        const int s = v.large_list[li];
+        const int s = huge_list[li];
         const float4 p = pts[s];
         CellBox bx = make_box(g, p.x, p.y, p.z, v.f.rr);
         bx.hi[1] = min(bx.hi[1], bx.lo[1] + 3);
@@ -2570,7 +2824,7 @@ __global__ __launch_bounds__(kCollectThreads) void sorted_collect_kernel(Batch b
 constexpr int kAddWideBelow = 160 * 1024;       // large points of a view below which four lanes take a point
 
 template <bool STATS, int G>
-__device__ __forceinline__ void sorted_add_points(const ViewDev &v, float *H, int nlarge) {
+__device__ __forceinline__ void sorted_add_points(const ViewDev &v, float *H, int nlarge, int bx) {
     constexpr int kPts = kLanes / G;
     const int pi = threadIdx.x / G, gq = threadIdx.x % G;
     FeatDesc f;
@@ -2591,7 +2845,7 @@ __device__ __forceinline__ void sorted_add_points(const ViewDev &v, float *H, in
     const char *__restrict__ nrmsrc = v.nrmsrc;
     const unsigned ns = v.ns;
     const int col_address = lds_address(H + pi);
-    for (int first = blockIdx.x * kPts; first < nlarge; first += gridDim.x * kPts) {
+    for (int first = bx * kPts; first < nlarge; first += gridDim.x * kPts) {
         const bool has_point = first + pi < nlarge;
         const int s = has_point ? v.large_list[first + pi] : 0;
         wave_lds_fence();
@@ -2601,7 +2855,9 @@ __device__ __forceinline__ void sorted_add_points(const ViewDev &v, float *H, in
         const unsigned long long *seg = v.sort_keys + (has_point ? v.seg_start[s] : 0u);
         const float4 np = has_point ? v.nrm[s] : make_float4(0.f, 0.f, 0.f, 0.f);
         if (STATS && has_point && gq == 0) atomicAdd(&v.stats->sum_kf, (unsigned long long)len);
-        // element 0 of the order is dropped (hpp:336); keys two rounds ahead of their use, normals one
+        // element 0 of the order is dropped (hpp:336).  Keys are requested FOUR rounds ahead of their use and normals TWO: the
+        // address of a normal comes out of a key, and with the key one round ahead (until r04e) every round waited for a
+        // whole memory round trip -- 5.8 k cycles per round of 79 instructions at 200 keys per point.
         struct Slot {
             bool valid;
             float d2;
@@ -2617,35 +2873,41 @@ __device__ __forceinline__ void sorted_add_points(const ViewDev &v, float *H, in
             slot.orig = slot.valid ? (unsigned)key : 0u;
         };
         auto fetch_normal = [&](Slot &slot) { slot.n = *reinterpret_cast<const f32x3 *>(nrmsrc + (size_t)slot.orig * ns); };
-        Slot sa, sb, sc;
-        sa.valid = sb.valid = sc.valid = false;
-        sa.d2 = sb.d2 = sc.d2 = 0.f;
-        sa.orig = sb.orig = sc.orig = 0u;
-        sa.n = sb.n = sc.n = f32x3{0.f, 0.f, 0.f};
-        fetch_key(sa);
-        fetch_key(sb);
-        fetch_normal(sa);
-#define KPL_LARGE_ROUND(now, nxt, far)                                                             \
-    {                                                                                              \
-        fetch_key(far);                                                                            \
-        fetch_normal(nxt);                                                                         \
-        const bool has_ = now.valid & finite3(now.n.x, now.n.y, now.n.z);          /* hpp:338 */  \
-        Contribution c_;                                                                           \
-        if (has_) c_ = neighbor_contribution<kPts>(f, now.d2, np, now.n, col_address);             \
-        _Pragma("unroll") for (int sub_ = 0; sub_ < G; ++sub_) {                                   \
-            if (has_ & (gq == sub_)) apply_contribution(c_, request_cells(c_));                    \
-            wave_lds_fence();                                                                      \
-        }                                                                                          \
-    }
-        // (slots become invalid in key order: a group is done when its current slot is)
-        while (__any(sa.valid)) {
-            KPL_LARGE_ROUND(sa, sb, sc)
-            if (!__any(sb.valid)) break;
-            KPL_LARGE_ROUND(sb, sc, sa)
-            if (!__any(sc.valid)) break;
-            KPL_LARGE_ROUND(sc, sa, sb)
+        constexpr int kSlots = 6, kKeyAhead = 4, kNormalAhead = 2;
+        Slot sl[kSlots];
+#pragma unroll
+        for (int q = 0; q < kSlots; ++q) {
+            sl[q].valid = false;
+            sl[q].d2 = 0.f;
+            sl[q].orig = 0u;
+            sl[q].n = f32x3{0.f, 0.f, 0.f};
         }
-#undef KPL_LARGE_ROUND
+#pragma unroll
+        for (int q = 0; q < kKeyAhead; ++q) fetch_key(sl[q]);
+#pragma unroll
+        for (int q = 0; q < kNormalAhead; ++q) fetch_normal(sl[q]);
+        // (slots become invalid in key order: a group is done when its current slot is)
+        bool more = true;
+        while (more) {
+#pragma unroll
+            for (int q = 0; q < kSlots; ++q) {
+                Slot &now = sl[q];
+                if (!__any(now.valid)) {
+                    more = false;
+                    break;
+                }
+                fetch_key(sl[(q + kKeyAhead) % kSlots]);
+                fetch_normal(sl[(q + kNormalAhead) % kSlots]);
+                const bool has_ = now.valid & finite3(now.n.x, now.n.y, now.n.z);          /* hpp:338 */
+                Contribution c_;
+                if (has_) c_ = neighbor_contribution<kPts>(f, now.d2, np, now.n, col_address);
+#pragma unroll
+                for (int sub_ = 0; sub_ < G; ++sub_) {
+                    if (has_ & (gq == sub_)) apply_contribution(c_, request_cells(c_));
+                    wave_lds_fence();
+                }
+            }
+        }
         wave_lds_fence();
         for (int a = gq; a < f.A; a += G) {                                        // hpp:360-370, one row per lane
             float *h = H + (a * f.B) * kPts + pi;
@@ -2667,15 +2929,16 @@ __device__ __forceinline__ void sorted_add_points(const ViewDev &v, float *H, in
 }
 
 template <bool STATS>
-__global__ __launch_bounds__(kLanes) void sorted_add_kernel(Batch b, int maxF) {
+__global__ __launch_bounds__(kLanes) void sorted_add_kernel(Batch b, int maxF, int by_xcd) {
     extern __shared__ float H[];
-    const ViewDev &v = b.view[blockIdx.y];
+    const ViewBlock vb = view_block(by_xcd);
+    const ViewDev &v = b.view[vb.view];
     if (!v.f.sorted) return;
     const int nlarge = v.ds->large_count;
     if (nlarge == 0) return;
     if (v.ds->status != kStatusOk) return;                        // (segments incomplete: the call fails, kpl_sync_status)
-    if (nlarge < kAddWideBelow) sorted_add_points<STATS, 4>(v, H, nlarge);
-    else sorted_add_points<STATS, 2>(v, H, nlarge);
+    if (nlarge < kAddWideBelow) sorted_add_points<STATS, 4>(v, H, nlarge, (int)vb.bx);
+    else sorted_add_points<STATS, 2>(v, H, nlarge, (int)vb.bx);
 }
 
 // detectKeypoints, hpp:197-256 with draws_remove == false (order-independent predicate):
@@ -3589,6 +3852,7 @@ __global__ __launch_bounds__(kScanBlock) void compact_scan_kernel(Batch b, int p
                 v.ds->keys_needed = v.ds->key_cursor;        // sorted mode, large neighborhoods: re-armed for the next call
                 v.ds->key_cursor = 0ull;
                 v.ds->large_count = 0;
+                v.ds->huge_count = 0;
                 // every block of this launch has published, hence started, hence read the tag: the next call's may be set
                 __hip_atomic_store(&v.ds->scan_epoch, epoch + 1u == 0u ? 1u : epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -3808,8 +4072,23 @@ void launch_feature_stage(const Batch &b, hipStream_t st) {
         const int lcap = sorted_list_keys(maxF);
         const size_t lds = sorted_lds_bytes<kSortGroup>(maxF, kSortWords, lcap);
         const dim3 grid(div_up(n, kLanes) * kSortGroup, b.nviews);
-        if (stats) feature_sorted_kernel<true><<<grid, kLanes, lds, st>>>(b, maxF, kSortWords, lcap);
-        else feature_sorted_kernel<false><<<grid, kLanes, lds, st>>>(b, maxF, kSortWords, lcap);
+        // views of about the same size are dealt to the XCDs (view_block): what a view reads at random then stays in one L2
+        int min_n = n;
+        for (int k = 0; k < b.nviews; ++k) min_n = b.view[k].n < min_n ? b.view[k].n : min_n;
+        const int by_xcd = (b.nviews >= 2 && (long long)min_n * 10 >= (long long)n * 9) ? 1 : 0;
+        if (stats) feature_sorted_kernel<true><<<grid, kLanes, lds, st>>>(b, maxF, kSortWords, lcap, by_xcd);
+        else feature_sorted_kernel<false><<<grid, kLanes, lds, st>>>(b, maxF, kSortWords, lcap, by_xcd);
+        // persistent: as many workgroups of four waves as are resident at once (every wave takes the same share of the list:
+        // workgroups that start when others have finished would double the kernel's time)
+        static int wave_wgs_per_cu = 0;
+        if (wave_wgs_per_cu == 0) {
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sorted_collect_wave_kernel, kWaveCollectWaves * kWave, 0) != hipSuccess || nb < 1) nb = 4;
+            wave_wgs_per_cu = nb;
+        }
+        int wwgs = div_up(cu_count() * wave_wgs_per_cu, b.nviews);
+        if (wwgs > div_up(n, kWaveCollectWaves)) wwgs = div_up(n, kWaveCollectWaves);
+        sorted_collect_wave_kernel<<<dim3(wwgs, b.nviews), kWaveCollectWaves * kWave, 0, st>>>(b, by_xcd);
         int wgs = div_up(cu_count() * 4, b.nviews);             // persistent: four workgroups per CU (37 KB of LDS each)
         if (wgs > n) wgs = n;
         sorted_collect_kernel<<<dim3(wgs, b.nviews), kCollectThreads, 0, st>>>(b);
@@ -3817,8 +4096,8 @@ void launch_feature_stage(const Batch &b, hipStream_t st) {
         if (awgs > cu_count() * 16) awgs = cu_count() * 16;
         const dim3 agrid(awgs, b.nviews);
         const size_t alds = sizeof(float) * (size_t)maxF * (kLanes / 2);
-        if (stats) sorted_add_kernel<true><<<agrid, kLanes, alds, st>>>(b, maxF);
-        else sorted_add_kernel<false><<<agrid, kLanes, alds, st>>>(b, maxF);
+        if (stats) sorted_add_kernel<true><<<agrid, kLanes, alds, st>>>(b, maxF, by_xcd);
+        else sorted_add_kernel<false><<<agrid, kLanes, alds, st>>>(b, maxF, by_xcd);
     }
 }
 

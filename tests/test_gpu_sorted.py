@@ -255,3 +255,74 @@ def test_sorted_key_segments_grow_through_retry(kpl, oracle, cases):
     o_scores, _ = oracle.detect(xyz, nrm, 5, 6, 0.12, 0.0, 0.0, cases.oracle_forest(fa), non_maxima=False, order=oracle.ORDER_SORTED,
                                 threads=cases.usable_cores())
     assert cases.same_bits(ds.cpu().numpy(), o_scores)
+
+
+def test_sorted_mid_neighborhoods_take_a_wave_per_point(kpl, oracle, cases):
+    """K_f of 150-200 on every interior point of a 52 k-point view: more than the register lists hold, far less than the
+    workgroup kernel is built for -- sorted_collect_wave_kernel (a wave per point, the list sorted in registers, 4 keys per
+    lane), with more than 8 points per wave of the launch: key segments out of per-wave chunks"""
+    from tools import synth
+    xyz, nrm = synth.make_cloud(260, 200, seed=21)
+    xyz, nrm = synth.shuffle_cloud(xyz, nrm, 1021)
+    mr = oracle.cloud_resolution(xyz)
+    kf = _score_both_ways(kpl, oracle, cases, xyz, nrm, 5, 6, float(np.float32(9.5 * mr)), 13)
+    assert 140 < kf < 256, kf
+
+
+def test_sorted_neighborhoods_of_every_size_in_one_view(kpl, oracle, cases):
+    """a sheet whose density rises 40-fold along x: register lists (K_f < 124), the wave kernel with 1, 2, 4 and 8 keys per
+    lane (up to 512 keys) and the workgroup kernel (beyond) all in one launch; non-finite points and normals mixed in"""
+    rng = np.random.default_rng(17)
+    n = 60000
+    x = rng.uniform(0, 1, size=n) ** 3
+    xyz = np.stack([x, rng.uniform(0, 1, size=n), 0.01 * rng.normal(size=n)], axis=1).astype(np.float32)
+    nrm = rng.normal(size=(n, 3)).astype(np.float32) * np.float32([0.2, 0.2, 1.0])
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    xyz[::1013] = np.nan
+    nrm[7::907] = np.nan
+    r = 0.035
+    g = oracle.Grid(xyz, r)
+    ks = np.array([g.radius_search(int(i), r)[2] for i in range(0, n, 40) if np.isfinite(xyz[i]).all()])
+    assert (ks < 100).any() and ((ks > 128) & (ks <= 256)).any() and ((ks > 256) & (ks <= 512)).any() and (ks > 600).any(), np.percentile(ks, [1, 25, 50, 75, 99])
+    _score_both_ways(kpl, oracle, cases, xyz, nrm, 5, 6, r, 14)
+
+
+def test_sorted_batch_of_equal_views_dealt_to_the_xcds(kpl, oracle, cases):
+    """views of the same size in one launch: the sorted kernels deal them to the XCDs (view_block in kernels.hip), a
+    different block-to-view map than the (blocks, views) grid of every other launch; one of the views has mid-size
+    neighborhoods (wave kernel), one is in the canonical order"""
+    import torch
+    from tools import synth
+    fa = synth.random_forest(30, ntrees=6, max_depth=8, seed=5, target_nodes_per_tree=120)
+    of = cases.oracle_forest(fa)
+    dev = torch.device("cuda", 0)
+    dets, bufs, views = [], [], []
+    for k, (srt, rmul) in enumerate([(True, 6.0), (True, 9.5), (False, 6.0), (True, 7.5)]):
+        xyz, nrm = synth.make_cloud(150, 120, seed=30 + k)
+        xyz, nrm = synth.shuffle_cloud(xyz, nrm, 1030 + k)
+        mr = oracle.cloud_resolution(xyz)
+        r, rn, thr = float(np.float32(rmul * mr)), float(np.float32(4 * mr)), float(np.float32(0.6))
+        det = make_det(kpl, 5, 6, r, rn, thr, fa, sorted_search=srt)
+        n = len(xyz)
+        dx, dn = torch.from_numpy(xyz.copy()).to(dev), torch.from_numpy(nrm.copy()).to(dev)
+        ds = torch.empty(n, dtype=torch.float32, device=dev)
+        dk = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+        det.bindCloudDevice(dx.data_ptr(), 12, dn.data_ptr(), 12, n)
+        dets.append(det); bufs.append((dx, dn, ds, dk)); views.append((xyz, nrm, r, rn, thr, srt))
+    torch.cuda.synchronize()
+    ok = False
+    for rep in range(3):                    # (the first call may find the key array of the wave path too small: KPL_ERR_RETRY)
+        kpl.compute_batch_device(dets, [b[2].data_ptr() for b in bufs], [b[3][1:].data_ptr() for b in bufs],
+                                 [len(b[2]) for b in bufs], [b[3][0:1].data_ptr() for b in bufs], None)
+        torch.cuda.synchronize()
+        rcs = [det.syncStatus(None) for det in dets]
+        if all(rc == kpl.OK for rc in rcs):
+            ok = True
+            break
+        assert all(rc in (kpl.OK, kpl.ERR_RETRY) for rc in rcs), rcs
+    assert ok
+    for (xyz, nrm, r, rn, thr, srt), det, (dx, dn, ds, dk) in zip(views, dets, bufs):
+        o_sc, o_kp = oracle.detect(xyz, nrm, 5, 6, r, rn, thr, of, order=oracle.ORDER_SORTED if srt else oracle.ORDER_CANONICAL,
+                                   threads=cases.usable_cores())
+        assert cases.same_bits(ds.cpu().numpy(), o_sc)
+        assert np.array_equal(dk[1:1 + int(dk[0].item())].cpu().numpy(), o_kp)
