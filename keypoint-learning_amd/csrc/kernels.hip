@@ -1994,14 +1994,18 @@ __device__ __forceinline__ ViewBlock view_block(int by_xcd) {
 // roughly right: a point it lets through whose list runs full is deferred to the same kernels (DEFER below).  (Summing
 // the candidates of the whole box -- 32 dependent loads per lane in a kernel with two waves per SIMD -- cost 7 % of the
 // stage on views that have no large point at all.)
-constexpr int kLargeCell = 57;
-__device__ __forceinline__ bool is_large_point(const GridDesc &g, const int *__restrict__ cell_start, const WavePoint &w, float) {
-    if (!w.scoreable) return false;
+// A cell with more than kHugeCell points (~530 neighbors) is beyond what a wave sorts (kWaveKeys): such a point is listed for
+// the workgroup kernel at once (top bit of its large_list entry + the second half of the list), sorted_collect_wave_kernel
+// passes it over -- at the reference's own operating point (2 300 neighbors) every point is one of these.
+constexpr int kLargeCell = 57, kHugeCell = 170;
+constexpr unsigned kHugeBit = 0x80000000u;
+__device__ __forceinline__ int own_cell_population(const GridDesc &g, const int *__restrict__ cell_start, const WavePoint &w) {
+    if (!w.scoreable) return 0;
     const int cx = cell_coord(w.p.x, g.mn[0], g.h, g.dims[0]);
     const int cy = cell_coord(w.p.y, g.mn[1], g.h, g.dims[1]);
     const int cz = cell_coord(w.p.z, g.mn[2], g.h, g.dims[2]);
     const int c = (cz * g.dims[1] + cy) * g.dims[0] + cx;
-    return cell_start[c + 1] - cell_start[c] > kLargeCell;
+    return cell_start[c + 1] - cell_start[c];
 }
 
 // Several independent views per launch (blockIdx.y = view): one 200 k-point view is only a few waves per
@@ -2041,7 +2045,8 @@ __global__ __launch_bounds__(kLanes) void feature_sorted_kernel(Batch b, int max
     const WavePoint w = wave_point(v, chunk, col, true);
     // a point with a large neighborhood is scored by sorted_collect_kernel + sorted_add_kernel (below): no rows here, and
     // its column of the feature block is theirs
-    const bool large = is_large_point(v.ds->grid, v.cell_start, w, v.f.rr);
+    const int own_cell = own_cell_population(v.ds->grid, v.cell_start, w);
+    const bool large = own_cell > kLargeCell, huge = own_cell > kHugeCell;
     uint2 *ent = reinterpret_cast<uint2 *>(H + maxF * kPts);
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(ent + ecap * kPts);
     bool deferred = false;
@@ -2061,7 +2066,14 @@ __global__ __launch_bounds__(kLanes) void feature_sorted_kernel(Batch b, int max
         int base = 0;
         if (lane == __builtin_ctzll(lbal)) base = atomicAdd(&v.ds->large_count, __popcll(lbal));
         base = __builtin_amdgcn_readlane(base, __builtin_ctzll(lbal));
-        if (listed && gq == 0) v.large_list[base + __popcll(lbal & ((1ull << lane) - 1ull))] = w.s;
+        if (listed && gq == 0) v.large_list[base + __popcll(lbal & ((1ull << lane) - 1ull))] = (int)((unsigned)w.s | (huge ? kHugeBit : 0u));
+        const unsigned long long hbal = __ballot(huge && gq == 0);
+        if (hbal != 0ull) {
+            int hbase = 0;
+            if (lane == __builtin_ctzll(hbal)) hbase = atomicAdd(&v.ds->huge_count, __popcll(hbal));
+            hbase = __builtin_amdgcn_readlane(hbase, __builtin_ctzll(hbal));
+            if (huge && gq == 0) v.large_list[v.n + hbase + __popcll(hbal & ((1ull << lane) - 1ull))] = w.s;
+        }
     }
     if (listed) return;
     if (STATS && w.scoreable && gq == 0) atomicAdd(&v.stats->sum_kf, (unsigned long long)kf);
@@ -2340,7 +2352,7 @@ __global__ __launch_bounds__(kLanes) void features_sorted_kernel(const float4 *_
 // Sorted-search mode, LARGE neighborhoods (the reference's own default operating point: radiusFeatures 20 on the cheff
 // views = 30 mesh resolutions, K_f ~ 2 300 -- /root/reference/src/main_test_detector.cpp:65).  The register sort of
 // point_features_sorted holds 128 keys per point and pass and searches again for every pass: 20 passes over ~10 000 candidates
-// per point there (46 ms per 63 k-point view against 1.8 ms in the canonical order).  Points in crowded cells (is_large_point)
+// per point there (46 ms per 63 k-point view against 1.8 ms in the canonical order).  Points in crowded cells (own_cell_population > kLargeCell)
 // and points whose register list ran full take three kernels instead:
 //   feature_sorted_kernel  lists them instead of scoring them (DevState::large_count, ViewDev::large_list), and with them
 //                          the points whose register list ran full (DEFER)
@@ -2450,6 +2462,9 @@ __global__ __launch_bounds__(kWaveCollectWaves *kWave) void sorted_collect_wave_
     if (!v.f.sorted) return;
     DevState *ds = v.ds;
     const int nlarge = ds->large_count;
+    // every listed point is one for the workgroup kernel already (the count only grows in this kernel, by points that were not:
+    // equality means there are none)
+    if (__hip_atomic_load(&ds->huge_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nlarge) return;
     const GridDesc g = ds->grid;
     const float4 *__restrict__ pts = v.pts;
     const int *__restrict__ cell_start = v.cell_start;
@@ -2482,22 +2497,28 @@ __global__ __launch_bounds__(kWaveCollectWaves *kWave) void sorted_collect_wave_
     const unsigned chunk_keys = nlarge >= 8 * nwaves ? kWaveChunk : 0u;
     unsigned long long chunk_pos = 0ull, chunk_end = 0ull;
     int li = vb.bx * kWaveCollectWaves + wid;
-    int s_cur = li < nlarge ? v.large_list[li] : -1;
-    int s_nxt = li + nwaves < nlarge ? v.large_list[li + nwaves] : -1;
-    float4 p = pts[max(s_cur, 0)];
+    // (list entries: the storage position, top bit set = listed for the workgroup kernel already, passed over here; -1 past
+    // the end of the list)
+    constexpr int kEnd = -1;
+    auto is_mine = [](int e) { return e != kEnd && ((unsigned)e & kHugeBit) == 0u; };
+    auto position = [](int e) { return (int)((unsigned)e & ~kHugeBit); };
+    int s_cur = li < nlarge ? v.large_list[li] : kEnd;
+    int s_nxt = li + nwaves < nlarge ? v.large_list[li + nwaves] : kEnd;
+    float4 p = pts[s_cur == kEnd ? 0 : position(s_cur)];
     int my_r0, my_r1;
-    box_rows(p, s_cur >= 0, my_r0, my_r1);
-    while (s_cur >= 0) {
+    box_rows(p, is_mine(s_cur), my_r0, my_r1);
+    while (s_cur != kEnd) {
         const int s = s_cur;
         const int li_nn = li + 2 * nwaves;
-        const int s_nn = li_nn < nlarge ? v.large_list[li_nn] : -1;
-        const float4 p_nxt = pts[max(s_nxt, 0)];
+        const int s_nn = li_nn < nlarge ? v.large_list[li_nn] : kEnd;
+        const float4 p_nxt = pts[s_nxt == kEnd ? 0 : position(s_nxt)];
         int cands = my_r1 - my_r0;
 #pragma unroll
         for (int off = 1; off < 16; off <<= 1) cands += __shfl_xor(cands, off);
         cands = __builtin_amdgcn_readfirstlane(cands);
         int cnt = 0;
-        if (cands <= kWaveCandidates) {
+        const bool mine = is_mine(s);           // (uniform)
+        if (mine && cands <= kWaveCandidates) {
             wave_lds_fence();                   // (the list of the point before has been read into registers)
             constexpr int kPiece = kWave * kWaveAhead;
             int row = -1, t0 = 0, r1 = 0;       // (uniform) the piece [t0, min(t0 + kPiece, r1)) of row `row`
@@ -2533,12 +2554,13 @@ __global__ __launch_bounds__(kWaveCollectWaves *kWave) void sorted_collect_wave_
                 }
 #pragma unroll
                 for (int a = 0; a < kWaveAhead; ++a) cur[a] = nxt[a];
-                have = have_next;
+                have = have_next && cnt <= kWaveKeys;               // (more keys than a wave sorts: the walk is over)
             }
         }
         int nr0, nr1;
-        box_rows(p_nxt, s_nxt >= 0, nr0, nr1);                      // (requested here, used by the next turn of the loop)
-        if (cands > kWaveCandidates || cnt > kWaveKeys) {          // (uniform) not a list for one wave
+        box_rows(p_nxt, is_mine(s_nxt), nr0, nr1);                  // (requested here, used by the next turn of the loop)
+        if (!mine) {
+        } else if (cands > kWaveCandidates || cnt > kWaveKeys) {   // (uniform) not a list for one wave
             if (lane == 0) huge_list[atomicAdd(&ds->huge_count, 1)] = s;
         } else {
             if (chunk_end - chunk_pos < (unsigned long long)cnt) {           // (uniform) a new chunk
@@ -2847,7 +2869,7 @@ __device__ __forceinline__ void sorted_add_points(const ViewDev &v, float *H, in
     const int col_address = lds_address(H + pi);
     for (int first = bx * kPts; first < nlarge; first += gridDim.x * kPts) {
         const bool has_point = first + pi < nlarge;
-        const int s = has_point ? v.large_list[first + pi] : 0;
+        const int s = has_point ? (int)((unsigned)v.large_list[first + pi] & ~kHugeBit) : 0;
         wave_lds_fence();
         for (int c = gq; c < f.F; c += G) H[c * kPts + pi] = 0.0f;                 // hpp:325
         wave_lds_fence();
