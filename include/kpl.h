@@ -109,7 +109,7 @@ void kpl_destroy(kpl_detector *h);
 const char *kpl_last_error(const kpl_detector *h);
 const char *kpl_status_string(int status);
 int kpl_version(void);
-/* sha256 (hex) of the sources this library was built from (csrc/*.hip, *.cpp, their headers and this file), as
+/* sha256 (hex) of the sources this library was built from (the .hip and .cpp files of csrc, their headers and this file), as
  * keypoint-learning_amd/build.py computes it: ties a shipped binary to a source tree (tests/test_abi.py). */
 const char *kpl_source_hash(void);
 
