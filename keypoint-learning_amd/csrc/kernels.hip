@@ -2380,7 +2380,8 @@ constexpr int kInsertionMax = 48;        // keys a thread orders by insertion; m
 // canonical feature kernel).  Here every wave takes points of its own: the rows of the box 128 candidates at a time (the next
 // piece in flight), the accepted keys appended to the wave's list in LDS by ballot, the list then sorted IN REGISTERS -- E =
 // 1, 2, 4 or 8 keys per lane (blocked: lane l holds elements E l .. E l + E - 1), a bitonic network whose partners inside a
-// lane are registers and across lanes come through ds_bpermute -- and written to the point's segment of sort_keys.  A point
+// lane are registers, inside a row of 16 lanes come through DPP moves and across rows through ds_bpermute -- and written to
+// the point's segment of sort_keys.  A point
 // with more candidates in its box than kWaveCandidates, or more than kWaveKeys accepted, goes to the second half of
 // large_list (DevState::huge_count) for the workgroup kernel.
 constexpr int kWaveKeys = 512, kWaveCollectWaves = 4, kWaveAhead = 2;
@@ -2559,10 +2560,9 @@ __global__ __launch_bounds__(kWaveCollectWaves *kWave) void sorted_collect_wave_
         }
         int nr0, nr1;
         box_rows(p_nxt, is_mine(s_nxt), nr0, nr1);                  // (requested here, used by the next turn of the loop)
-        if (!mine) {
-        } else if (cands > kWaveCandidates || cnt > kWaveKeys) {   // (uniform) not a list for one wave
+        if (mine && (cands > kWaveCandidates || cnt > kWaveKeys)) {   // (uniform) not a list for one wave
             if (lane == 0) huge_list[atomicAdd(&ds->huge_count, 1)] = s;
-        } else {
+        } else if (mine) {
             if (chunk_end - chunk_pos < (unsigned long long)cnt) {           // (uniform) a new chunk
                 const unsigned long long take = (unsigned)cnt > chunk_keys ? (unsigned long long)cnt : (unsigned long long)chunk_keys;
                 unsigned off_lo = 0u, off_hi = 0u;
@@ -4102,7 +4102,7 @@ void launch_feature_stage(const Batch &b, hipStream_t st) {
         else feature_sorted_kernel<false><<<grid, kLanes, lds, st>>>(b, maxF, kSortWords, lcap, by_xcd);
         // persistent: as many workgroups of four waves as are resident at once (every wave takes the same share of the list:
         // workgroups that start when others have finished would double the kernel's time)
-        static int wave_wgs_per_cu = 0;
+        static int wave_wgs_per_cu = 0;         // (every thread that gets here computes the same value)
         if (wave_wgs_per_cu == 0) {
             int nb = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sorted_collect_wave_kernel, kWaveCollectWaves * kWave, 0) != hipSuccess || nb < 1) nb = 4;
