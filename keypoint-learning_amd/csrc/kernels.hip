@@ -2844,6 +2844,9 @@ __global__ __launch_bounds__(kCollectThreads) void sorted_collect_kernel(Batch b
 // they are few (a 63 k-point view with 2 300 neighbors per point is 2 000 waves of two lanes per point -- two per SIMD,
 // each alive for the whole kernel; four lanes per point are twice the waves and half the rounds per wave).
 constexpr int kAddWideBelow = 160 * 1024;       // large points of a view below which four lanes take a point
+constexpr unsigned long long kAddWideKeys = 1024;       // ... or mean keys per point below which they do: lists of a few hundred
+                                                        // keys are over in ~50 rounds of four lanes (8 x 200 k points at 200 / 290
+                                                        // keys: 8.2 -> 7.6, 11.6 -> 10.7 ms for the stage)
 
 template <bool STATS, int G>
 __device__ __forceinline__ void sorted_add_points(const ViewDev &v, float *H, int nlarge, int bx) {
@@ -2959,7 +2962,9 @@ __global__ __launch_bounds__(kLanes) void sorted_add_kernel(Batch b, int maxF, i
     const int nlarge = v.ds->large_count;
     if (nlarge == 0) return;
     if (v.ds->status != kStatusOk) return;                        // (segments incomplete: the call fails, kpl_sync_status)
-    if (nlarge < kAddWideBelow) sorted_add_points<STATS, 4>(v, H, nlarge, (int)vb.bx);
+    // (all segments have been handed out: the cursor is the number of keys of the view, chunk tails included)
+    const bool wide = nlarge < kAddWideBelow || v.ds->key_cursor < (unsigned long long)nlarge * kAddWideKeys;
+    if (wide) sorted_add_points<STATS, 4>(v, H, nlarge, (int)vb.bx);
     else sorted_add_points<STATS, 2>(v, H, nlarge, (int)vb.bx);
 }
 
