@@ -101,6 +101,32 @@ def iso_ms_val(t):
     return t["feature_ms"] / max(t["calls"], 1)
 
 
+def visible_devices():
+    """GPUs this process would see, WITHOUT initialising HIP (torch.cuda.device_count() only counts)."""
+    import torch
+    return torch.cuda.device_count()
+
+
+def self_launch(args):
+    """`bench.py --gpus N` outside a torch.distributed job: start N ranks (one process per GPU) with the launcher the
+    driver uses, as a child process; its stdout (rank 0's JSON line) and exit code are this process's."""
+    import socket
+    import subprocess
+    ndev = visible_devices()
+    if ndev < args.gpus and not args.share_devices:
+        sys.stderr.write("bench.py: --gpus %d but only %d device(s) are visible; refusing to wrap ranks onto shared "
+                         "devices (--share-devices allows it for tests)\n" % (args.gpus, ndev))
+        return 2
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:      # a free rendezvous port on the loopback
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs between processes on this driver
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     # the oracle's OpenMP workers must sleep, not spin, once the parity gate is done: spinning
     # workers would compete with the thread that enqueues the timed steps
@@ -126,12 +152,23 @@ def main():
                          "of the keypoint lists (RCCL with --backend nccl) exactly as it does with N > 1")
     ap.add_argument("--repeats", type=int, default=REPEATS,
                     help="timed repetitions of the K-step loop (the median one is reported); profiling runs use 1")
+    ap.add_argument("--share-devices", action="store_true",
+                    help="tests on a box with fewer GPUs than ranks: ranks wrap onto the visible devices (local_rank %% "
+                         "device_count) instead of the run being refused; the line then says devices_shared")
     args = ap.parse_args()
     repeats = max(1, args.repeats)
+
+    # `python bench.py --gpus N` launched bare: this process only starts the N rank processes (one per GPU, the launcher
+    # the driver itself uses) as a CHILD and passes its exit code on.  Nothing here has touched the GPU: counting devices
+    # does not initialise HIP, and a process that has is never replaced by another program.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(1, args.gpus):
+        raise SystemExit("bench.py --gpus %d inside a job of %d rank(s): the two must agree" % (args.gpus, world))
     # N > 1: every rank process onto the CPUs next to ITS GPU, before the first HIP call of the process (sysfs only)
     affinity = None
     if world > 1:
@@ -146,7 +183,14 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    local_rank %= torch.cuda.device_count()      # (only matters for the 1-GPU gloo smoke run)
+    ndev = torch.cuda.device_count()
+    devices_shared = False
+    if local_rank >= ndev:
+        if not args.share_devices:
+            raise SystemExit("bench.py: rank %d has no GPU of its own (%d visible device(s), %d rank(s)); "
+                             "--share-devices lets ranks share a device (tests only)" % (local_rank, ndev, world))
+        local_rank %= ndev
+    devices_shared = args.share_devices and world > ndev
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -318,6 +362,12 @@ def main():
         rep_enq.append(t_enq - t0)
     timing = dets[0].getTiming()
     dets[0].enableTiming(False)
+    # a status raised DURING the timed loop (a table that had to grow, a failed scan) would otherwise go unseen: every
+    # detector must report OK now (the barrier above has drained every stream), else the numbers are not those of the path
+    rcs = [d.syncStatus(None) for d in dets]
+    if any(rc != kpl.OK for rc in rcs):
+        raise SystemExit("bench.py: a timed step failed on the device: statuses %s (%s)" %
+                         (rcs, "; ".join(d.lastError() for d, rc in zip(dets, rcs) if rc != kpl.OK)))
     per_rank = None
     if use_dist:        # every repetition: the slowest rank counts; every rank's own times travel too
         tt = torch.tensor(rep_s, dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
@@ -330,6 +380,8 @@ def main():
     med = order[repeats // 2]
     elapsed, enq_s = rep_s[med], rep_enq[med]
     if use_dist:
+        assert dist.get_world_size() == world == max(1, args.gpus), "the collective does not span --gpus ranks"
+        assert per_rank is not None and len(per_rank) == world, "one timing row per rank"
         lists = kd.unpack_keypoints(gathered[0].view(world * nb, gather_cap + 1))
         assert len(lists) == world * nb and all(len(x) > 0 for x in lists)
         g_last = (step_no[0] - 1) % ng
@@ -516,9 +568,11 @@ def main():
     prof, why_not = load_profile(nb)
     traffic = valu_busy = ta_busy = hbm_counter_frac = waves_per_simd = valu_issue_frac = valu_model = lane_frac = None
     forest_prof = None
+    rocprof_avg_ns = rocprof_tag = None
     if prof:
         pk = prof["kernels"].get("feature_kernel", {})
         traffic = pk.get("hbm_bytes")
+        rocprof_avg_ns, rocprof_tag = pk.get("rocprof_avg_ns"), prof.get("tag")
         valu_busy = pk.get("valu_busy")
         ta_busy = pk.get("ta_busy")
         waves_per_simd = pk.get("waves_per_simd")
@@ -596,6 +650,7 @@ def main():
             "per_rank_ms_per_step": [round(r[med] * 1e3 / args.steps, 5) for r in per_rank] if per_rank else None,
             "collective": {"backend": "RCCL" if args.backend == "nccl" else args.backend, "world_size": dist.get_world_size()}
             if use_dist else None,
+            "devices_shared": devices_shared,       # true only in tests that run more ranks than the box has GPUs
             "cpu_affinity": affinity,
             # SURVEY 8(d) contract figure: gather-model bytes of the dominant kernel / its launch time / 8 TB/s (most of
             # those bytes are L1 / L2 hits: the HBM traffic by counters is hbm_counter_frac of peak).  `bound` is set from
@@ -607,6 +662,15 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 5), "traffic": traffic,
                          "kernel": "feature_kernel (histogram features, %d view(s) per launch)" % nb,
                          "kernel_ms": round(feat_ms, 5), "alg_bytes_per_launch": int(b_alg_feat),
+                         # measured IN THIS RUN: achieved / frac / kernel_ms (HIP events on the launching stream) and
+                         # alg_bytes_per_launch (the engine's own counters).  NOT measured in this run: everything that needs
+                         # rocprofv3 -- traffic, valu_*, ta_busy, waves_per_simd, hbm_counter_frac's numerator and the forest
+                         # kernel's counters -- replayed from profiles/counters.json, quoted only while its source hash matches.
+                         # frac_rocprof = the same algorithmic bytes / the kernel's AVERAGE duration in the committed
+                         # rocprofv3 --kernel-trace --stats summary (profiles/<tag>_kernel_stats.csv) / peak
+                         "frac_rocprof": round(b_alg_feat / (rocprof_avg_ns * 1e-9) / HBM_PEAK, 5) if rocprof_avg_ns else None,
+                         "rocprof_avg_ms": round(rocprof_avg_ns * 1e-6, 5) if rocprof_avg_ns else None,
+                         "rocprof_summary": ("profiles/%s_kernel_stats.csv" % rocprof_tag) if rocprof_avg_ns else None,
                          "valu_issue_frac": valu_issue_frac,
                          "valu_issue_model": {k: valu_model[k] for k in ("valu_issue_frac_bounds", "class_cycles_per_instruction",
                                                                          "avg_cycles_per_instruction_at_ceiling", "static_fast_share")}
@@ -614,7 +678,8 @@ def main():
                          "valu_busy": valu_busy, "valu_active_lane_frac": lane_frac, "ta_busy": ta_busy, "hbm_counter_frac": hbm_counter_frac,
                          "waves_per_simd": waves_per_simd,
                          "counters": {"file": "profiles/counters.json", "source_sha256": kernel_source_sha256()[:16],
-                                      "matches_these_kernels": prof is not None, "note": why_not},
+                                      "matches_these_kernels": prof is not None, "note": why_not,
+                                      "measured_in_this_run": False},
                          "alone_on_gpu": {"kernel_ms": round(iso_ms, 5),
                                           "frac": round(b_alg_feat / (iso_ms * 1e-3) / HBM_PEAK, 5)} if iso_ms else None,
                          # the forest kernel walks nodes that it has staged in LDS: its node bytes never come from HBM, so

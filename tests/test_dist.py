@@ -113,3 +113,20 @@ def test_pin_to_gpu_numa_is_best_effort():
     if "skipped" in out:
         assert os.sched_getaffinity(0) == before
     os.sched_setaffinity(0, before)
+
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """Without --share-devices a run with more ranks than visible GPUs is refused with a non-zero exit code and a message,
+    not silently wrapped onto one device (which would report n_gpus = N for one GPU's work)."""
+    import subprocess
+    import sys
+    import torch
+    want = max(2, torch.cuda.device_count() + 1)
+    env_clean = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", str(want), "--steps", "2", "--warmup", "1"], cwd=_ROOT,
+                         env=env_clean, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert "visible" in out.stderr and not [l for l in out.stdout.splitlines() if l.startswith("{")]

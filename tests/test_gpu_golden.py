@@ -361,10 +361,31 @@ def test_bench_two_ranks_on_one_device_in_fresh_processes():
     j = _child(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                 "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "3",
                 "--warmup", "1", "--repeats", "2", "--batch", "2", "--nx", "80", "--ny", "60", "--lean",
-                "--no-cpu-baseline"])
+                "--no-cpu-baseline", "--share-devices"])
     assert j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == "weak"
     assert j["parity"]["scores_bit_exact"] and j["parity"]["keypoints_identical"]
     assert j["value"] > 0 and j["config"]["views_per_step_per_gpu"] == 2
+
+
+def test_bench_gpus_2_launched_bare_starts_its_own_ranks():
+    """`python bench.py --gpus 2 ...` with NO launcher around it (how the driver starts N = 1, and what a user types): the
+    script starts its two ranks itself -- torch.distributed.run as a child process, before anything touches the GPU -- and
+    the line that comes back is the two-rank job's: n_gpus 2, a collective of world size 2, one timing row per rank."""
+    env_clean = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1",
+                          "--repeats", "2", "--batch", "2", "--nx", "80", "--ny", "60", "--lean", "--no-cpu-baseline",
+                          "--share-devices"], cwd=ROOT, env=dict(env_clean, HSA_ENABLE_IPC_MODE_LEGACY="0"),
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["collective"]["world_size"] == 2 and len(j["per_rank_ms_per_step"]) == 2
+    assert j["devices_shared"] is True          # (this box has one GPU; on an 8-GPU node the flag is not passed)
+    assert j["parity"]["scores_bit_exact"] and j["parity"]["keypoints_identical"]
+    assert j["roofline"]["counters"]["measured_in_this_run"] is False
 
 
 def test_config3_recipe_two_ranks_gloo():
