@@ -39,7 +39,7 @@ sys.path.insert(0, ROOT)
 FOREST = os.path.join(ROOT, "data", "forests", "synth200k_a5b6_t10.yaml.gz")
 REPEATS = 5         # timed repetitions of the K-step loop; the median one is reported
 KERNEL_SOURCES = ("keypoint-learning_amd/csrc/kernels.hip", "keypoint-learning_amd/csrc/kernels.h",
-                  "keypoint-learning_amd/csrc/exact_math.h")
+                  "keypoint-learning_amd/csrc/exact_math.h", "keypoint-learning_amd/csrc/soft_pair.h")
 A, B = 5, 6
 HBM_PEAK = 8.0e12   # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
 LDS_PEAK = 75.0e12  # B/s, MI355X_MICROARCH.md "LDS": ~75 TB/s aggregate for ds_read_b32 with every CU streaming (b64: ~150)

@@ -89,6 +89,21 @@ typedef struct kpl_params {
  *              ~2 300 of the reference's default radius (a workgroup per point). */
 enum { KPL_NEIGHBORS_CANONICAL = 0, KPL_NEIGHBORS_SORTED = 1 };
 
+/* How the feature kernels WALK the canonical order (never what they compute: every choice gives the same bits --
+ * tests/test_gpu_walks.py).  AUTO (default): picked per launch from the mean number of neighbors per point that the
+ * handle's own earlier calls measured (read back by kpl_sync_status; until then, and whenever the feature radius or
+ * the size of the view changes, LANES with two lanes per point).
+ *   LANES     search and drain alternate in one kernel, the accept words of a point in LDS (neighborhoods of up to a few
+ *             hundred points)
+ *   TWO_PASS  the accept words of a point's whole walk go through global memory, a second kernel drains every list in one
+ *             go (the reference's default radius: ~2 300 neighbors per point).  Needs ~0.3 x 8 bytes per neighbor of
+ *             scratch; a first call whose scratch is too small returns KPL_ERR_RETRY like a view whose grid has grown
+ * lanes_per_point: 2 or 4. */
+enum { KPL_WALK_AUTO = -1, KPL_WALK_LANES = 0, KPL_WALK_TWO_PASS = 1 };
+int kpl_set_feature_walk(kpl_detector *h, int walk, int lanes_per_point);
+/* what the next launch would use, and the mean neighbors per point it is based on (< 0: not measured yet) */
+int kpl_get_feature_walk(const kpl_detector *h, int *walk, int *lanes_per_point, double *mean_neighbors);
+
 /* Counters for the algorithmic-bytes model of SURVEY.md 8(d), filled by kpl_collect_stats. */
 typedef struct kpl_stats {
     int64_t n_points;        /* points handed in                                              */

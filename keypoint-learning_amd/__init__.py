@@ -19,6 +19,7 @@ OK, ERR_INVALID_ARG, ERR_NO_FOREST, ERR_FOREST_PARSE, ERR_VAR_COUNT, ERR_GRID_TO
     ERR_CAPACITY, ERR_DEVICE, ERR_UNSUPPORTED, ERR_IO, ERR_NO_CLOUD, ERR_RETRY, ERR_INTERNAL = range(13)
 
 
+WALK_AUTO, WALK_LANES, WALK_TWO_PASS = -1, 0, 1
 NEIGHBORS_CANONICAL, NEIGHBORS_SORTED = 0, 1      # kpl_params.neighbor_order
 
 
@@ -87,6 +88,8 @@ SYMBOLS = {
     "kpl_compute_batch_device": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "kpl_compute_batch_keypoints_device": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "kpl_sync_status": (C.c_int, [_vp, _vp]),
+    "kpl_set_feature_walk": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "kpl_get_feature_walk": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "kpl_enable_timing": (C.c_int, [_vp, C.c_int]),
     "kpl_get_timing": (C.c_int, [_vp, C.POINTER(Timing)]),
     "kpl_collect_stats": (C.c_int, [_vp, C.POINTER(Stats), _vp]),
@@ -263,6 +266,18 @@ class KeypointLearningDetector:
         """pcl::Keypoint::setSearchMethod with a pcl::search::KdTree(sorted = on): the feature loop meets the
         neighbors in ascending (squared distance, index) order instead of the engine's canonical order."""
         self._p.neighbor_order = NEIGHBORS_SORTED if on else NEIGHBORS_CANONICAL
+
+    def setFeatureWalk(self, walk=WALK_AUTO, lanes_per_point=2):
+        """kpl_set_feature_walk: how the feature kernels walk the canonical order (WALK_AUTO / WALK_LANES / WALK_TWO_PASS, 2 or
+        4 lanes per point) -- a choice of speed only, the results are the same bits."""
+        self._check(self._lib.kpl_set_feature_walk(self._h, int(walk), int(lanes_per_point)))
+
+    def getFeatureWalk(self):
+        """(walk, lanes per point, mean neighbors per point measured by the handle's earlier calls or -1) of the next launch."""
+        self._push()
+        w, l, k = C.c_int(), C.c_int(), C.c_double()
+        self._check(self._lib.kpl_get_feature_walk(self._h, C.byref(w), C.byref(l), C.byref(k)))
+        return w.value, l.value, k.value
 
     def loadForest(self, path):
         rc = self._lib.kpl_load_forest_file(self._h, os.fsencode(path))

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libkpl.so")
 SOURCES = ["kernels.hip", "organized_normals.hip", "api.cpp", "forest.cpp"]
-HEADERS = ["kernels.h", "exact_math.h", "organized_normals.h", "forest.h", os.path.join("..", "..", "include", "kpl.h")]
+HEADERS = ["kernels.h", "exact_math.h", "soft_pair.h", "organized_normals.h", "forest.h", os.path.join("..", "..", "include", "kpl.h")]
 TOOLS = {"TestDetector": ["test_detector_main.cpp"], "DetectViews": ["batch_views_main.cpp"]}
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -116,6 +116,15 @@ def build(force=False, verbose=False):
     cexe = os.path.join(HERE, "..", "tools", "check_exact_math")
     if os.path.exists(csrc_) and (force or _stale(cexe, [csrc_, os.path.join(CSRC, "exact_math.h")])):
         cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-I", CSRC, "-o", cexe, csrc_]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    # the soft assignment of the kernels (csrc/soft_pair.h) on the device over the reference-generated table
+    # (tests/test_gpu_soft_pair.py)
+    ssrc = os.path.join(HERE, "..", "tools", "check_soft_pair.hip")
+    sexe = os.path.join(HERE, "..", "tools", "check_soft_pair")
+    if os.path.exists(ssrc) and (force or _stale(sexe, [ssrc, os.path.join(CSRC, "exact_math.h"), os.path.join(CSRC, "soft_pair.h")])):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math", "-I", CSRC, "-o", sexe, ssrc]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -21,6 +21,7 @@
 #include "forest.h"
 #include "kernels.h"
 #include "organized_normals.h"
+#include "soft_pair.h"
 
 using namespace kpl;
 
@@ -69,6 +70,15 @@ struct kpl_detector {
     bool pos_of_valid = false;    // the index was built with pos_of[]
     double index_radius = 0.0;
     bool has_origin = false;      // kpl_set_grid_origin
+    // how the feature kernels walk the neighborhoods (never WHAT they compute): kpl_set_feature_walk, or -- automatic -- the
+    // mean K_f the handle's previous calls measured (DevState::kf_sum / kf_points, read back in sync_status)
+    int walk_forced = KPL_WALK_AUTO, lanes_forced = 0;
+    double kf_hint = -1.0;        // mean neighbors per point of the calls before the last status read; < 0: not known
+    double kf_hint_radius = 0.0;  // ... measured at this feature radius
+    int kf_hint_n = 0;            // ... on a view of this many points
+    unsigned long long kf_seen_sum = 0, kf_seen_points = 0;     // DevState::kf_sum / kf_points at that read
+    double launched_radius = 0.0; // feature radius / points of the last scoring launch (what the next read-back describes)
+    int launched_n = 0;
     float origin[3] = {0.0f, 0.0f, 0.0f};
 
     DevBuf stage_xyz, stage_nrm, stage_idx, stage_feat;
@@ -151,19 +161,47 @@ FeatDesc make_feat(const kpl_params &p) {
     f.A = p.n_annulus;
     f.B = p.n_bins;
     f.F = p.n_annulus * p.n_bins;
-    f.A1f = (float)(f.A - 1);
-    f.B1f = (float)(f.B - 1);
     f.support = (float)p.radius_search;       // double search_radius_ -> float `support`
-    f.ann_dim = f.support / (float)f.A;       // cpp:43
-    f.ann_half = f.ann_dim / 2;               // cpp:52
-    f.bin_dim = 2 / (float)f.B;               // cpp:75
-    f.bin_half = f.bin_dim / 2;               // cpp:83
-    f.ann_rdim = 1.0f / f.ann_dim;            // correctly rounded reciprocals (float division)
-    f.bin_rdim = 1.0f / f.bin_dim;
+    const PairConsts ca = annulus_consts(f.A, f.support), cb = bin_consts(f.B);      // soft_pair.h (cpp:43,52 / :75,83)
+    f.A1f = ca.nm1;
+    f.B1f = cb.nm1;
+    f.ann_dim = ca.dim;
+    f.ann_half = ca.half;
+    f.ann_rdim = ca.rdim;                     // correctly rounded reciprocals (float division)
+    f.bin_dim = cb.dim;
+    f.bin_half = cb.half;
+    f.bin_rdim = cb.rdim;
     f.r2 = (float)(p.radius_search * p.radius_search);
     f.rr = (float)(p.radius_search * (1.0 + 1.0 / 1024.0));
     f.sorted = p.neighbor_order == KPL_NEIGHBORS_SORTED ? 1 : 0;
+    f.walk = 0;
+    f.lanes = 2;
     return f;
+}
+
+// How the canonical order is walked for this launch.  Both walks and both lane counts give the same bits; this only picks
+// the fastest for the neighborhood size, which the host learns from the handle's own earlier calls: the feature kernels
+// add up K_f over a sample of their waves, sync_status reads the sums back.  Measured on MI355X (tools/walk_sweep.py,
+// profiles/r05_walk_sweep.jsonl): search and drain alternating in one kernel, two lanes per point, is fastest up to ~300
+// neighbors per point (63 k points: 0.127 against 0.162 ms at K_f = 194; 500 k points: 0.51 against 0.70); from ~400 on the
+// two-pass walk with four lanes per point is (63 k points: 0.256 against 0.305 ms at K_f = 388, 0.889 against 1.348 at
+// 1 900; 500 k points: 1.11 against 1.12 at 376, 4.96 against 5.51 at 1 690; cheff001 at the reference's default radius,
+// K_f = 2 293: 1.09 against 1.78 ms) -- one drain per point instead of one per 24 accept words of the fullest list of the wave.
+constexpr double kTwoPassFromKf = 400.0;
+void choose_walk(const kpl_detector *h, FeatDesc &f) {
+    f.walk = 0;
+    f.lanes = 2;
+    if (h->walk_forced != KPL_WALK_AUTO) {
+        f.walk = h->walk_forced == KPL_WALK_TWO_PASS ? 1 : 0;
+        f.lanes = h->lanes_forced == 4 ? 4 : 2;
+        return;
+    }
+    const bool hint_fits = h->kf_hint >= 0.0 && h->kf_hint_radius == h->prm.radius_search && h->kf_hint_n > 0 &&
+                           (long long)h->n * 4 >= (long long)h->kf_hint_n * 3 && (long long)h->n * 3 <= (long long)h->kf_hint_n * 4;
+    if (hint_fits && h->kf_hint >= kTwoPassFromKf) {
+        f.walk = 1;
+        f.lanes = 4;
+    }
 }
 
 NmsDesc make_nms(const kpl_params &p) {
@@ -331,6 +369,13 @@ int ensure_index(kpl_detector *h, hipStream_t st) {
 int sync_status(kpl_detector *h, hipStream_t st) {
     KPL_HIP(h, hipMemcpyAsync(h->h_state, h->dstate.p, sizeof(DevState), hipMemcpyDeviceToHost, st));
     KPL_HIP(h, hipStreamSynchronize(st));
+    if (h->h_state->kf_points > h->kf_seen_points) {        // what the scoring launches since the last read measured
+        h->kf_hint = (double)(h->h_state->kf_sum - h->kf_seen_sum) / (double)(h->h_state->kf_points - h->kf_seen_points);
+        h->kf_hint_radius = h->launched_radius;
+        h->kf_hint_n = h->launched_n;
+        h->kf_seen_sum = h->h_state->kf_sum;
+        h->kf_seen_points = h->h_state->kf_points;
+    }
     if (h->h_state->status == kStatusGridTooLarge)
         return fail(h, KPL_ERR_GRID_TOO_LARGE, "bounding box / radius needs more than 2^28 grid cells");
     if (h->h_state->status == kStatusBadOrigin)
@@ -343,14 +388,15 @@ int sync_status(kpl_detector *h, hipStream_t st) {
         return fail(h, KPL_ERR_INTERNAL, "keypoint compaction: the look-back of the single-pass scan timed out (call again)");
     }
     if (h->h_state->status == kStatusKeyCapacity) {
-        // sorted-search mode: the neighbor keys of the points with large neighborhoods did not fit (kernels.hip)
+        // sorted-search mode: the neighbor keys of the points with large neighborhoods did not fit; two-pass walk: the accept
+        // words of the view did not (kernels.hip) -- the same array, grown to what the failed call counted
         const unsigned long long need = h->h_state->keys_needed;
         if (need > 0xfffffff0ull)
-            return fail(h, KPL_ERR_CAPACITY, "sorted search: %llu neighbor keys in one view (limit 2^32)", need);
+            return fail(h, KPL_ERR_CAPACITY, "%llu neighbor keys / accept words in one view (limit 2^32)", need);
         h->index_valid = false;
         KPL_HIP(h, hipDeviceSynchronize());
         KPL_HIP(h, h->sort_keys.ensure(sizeof(unsigned long long) * (size_t)(need + need / 16 + 4096)));
-        return fail(h, KPL_ERR_RETRY, "sorted search needs room for %llu neighbor keys: array grown, call again", need);
+        return fail(h, KPL_ERR_RETRY, "the view needs room for %llu neighbor keys / accept words: array grown, call again", need);
     }
     if (h->h_state->status == kStatusCellCapacity) {
         const int64_t need = h->h_state->ncells_needed;
@@ -408,6 +454,24 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
     v.seg_start = nullptr;
     v.seg_len = nullptr;
     v.key_cap = 0;
+    FeatDesc feat = make_feat(h->prm);
+    choose_walk(h, feat);
+    if (!feat.sorted && feat.walk == 1) {
+        // two-pass walk: the accept words of every point's whole walk (8-byte entries in the array the sorted mode keeps its
+        // keys in -- a view is in one mode or the other).  About one word per five neighbors on a surface (32 candidates
+        // a word, 4.6 candidates per neighbor) and a third more for the lock step of a wave; a view that needs more fails
+        // its first call with KPL_ERR_RETRY and finds the array grown (sync_status)
+        const double per_point = (h->kf_hint > 0.0 ? h->kf_hint : 1000.0) * 0.3 + 96.0;
+        const size_t want = sizeof(unsigned long long) * (size_t)((double)nn * per_point);
+        KPL_HIP(h, h->seg_start.ensure(sizeof(unsigned) * nn));
+        KPL_HIP(h, h->seg_len.ensure(sizeof(int) * nn));
+        if (h->sort_keys.cap < want) KPL_HIP(h, h->sort_keys.ensure(want));
+        v.sort_keys = h->sort_keys.as<unsigned long long>();
+        v.seg_start = h->seg_start.as<unsigned>();
+        v.seg_len = h->seg_len.as<int>();
+        v.key_cap = h->sort_keys.cap / sizeof(unsigned long long);
+        if (v.key_cap > 0xfffffff0ull) v.key_cap = 0xfffffff0ull;         // entry numbers are 32-bit
+    }
     if (h->prm.neighbor_order == KPL_NEIGHBORS_SORTED) {
         // segments of sorted neighbor keys for the points with large neighborhoods: 64 keys per point to begin with; a
         // view that needs more fails its first call with KPL_ERR_RETRY and finds the array grown (sync_status)
@@ -422,7 +486,9 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
         v.key_cap = h->sort_keys.cap / sizeof(unsigned long long);
         if (v.key_cap > 0xfffffffeull) v.key_cap = 0xfffffffeull;         // segment starts are 32-bit
     }
-    v.f = make_feat(h->prm);
+    v.f = feat;
+    h->launched_radius = h->prm.radius_search;
+    h->launched_n = n;
     v.forest = ForestDev{h->d_nodes.as<uint2>(), h->flat.ntrees, (int)h->flat.nodes.size(), (int)h->flat.ntop,
                          h->flat.order_free ? 1 : 0, h->flat.chain};
     v.nd = nd;
@@ -773,6 +839,27 @@ int kpl_set_params(kpl_detector *h, const kpl_params *p) {
     if (!h || !p) return KPL_ERR_INVALID_ARG;
     if (p->n_annulus < 1 || p->n_bins < 1) return fail(h, KPL_ERR_INVALID_ARG, "n_annulus and n_bins must be >= 1");
     h->prm = *p;
+    return KPL_OK;
+}
+
+int kpl_set_feature_walk(kpl_detector *h, int walk, int lanes_per_point) {
+    if (!h) return KPL_ERR_INVALID_ARG;
+    if (walk != KPL_WALK_AUTO && walk != KPL_WALK_LANES && walk != KPL_WALK_TWO_PASS)
+        return fail(h, KPL_ERR_INVALID_ARG, "walk must be KPL_WALK_AUTO, KPL_WALK_LANES or KPL_WALK_TWO_PASS");
+    if (walk != KPL_WALK_AUTO && lanes_per_point != 2 && lanes_per_point != 4)
+        return fail(h, KPL_ERR_INVALID_ARG, "lanes_per_point must be 2 or 4");
+    h->walk_forced = walk;
+    h->lanes_forced = walk == KPL_WALK_AUTO ? 0 : lanes_per_point;
+    return KPL_OK;
+}
+
+int kpl_get_feature_walk(const kpl_detector *h, int *walk, int *lanes_per_point, double *mean_neighbors) {
+    if (!h) return KPL_ERR_INVALID_ARG;
+    FeatDesc f = make_feat(h->prm);
+    choose_walk(h, f);
+    if (walk) *walk = f.walk ? KPL_WALK_TWO_PASS : KPL_WALK_LANES;
+    if (lanes_per_point) *lanes_per_point = f.lanes;
+    if (mean_neighbors) *mean_neighbors = h->kf_hint;
     return KPL_OK;
 }
 

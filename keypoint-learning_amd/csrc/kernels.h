@@ -39,6 +39,9 @@ struct FeatDesc {
     float r2;        // (float)(r*r), product in double -- KdTreeFLANN::radiusSearch
     float rr;        // (float)(r*(1+2^-10)): half width of the cell box that is searched
     int sorted;      // neighbor order of the feature loop: 0 = canonical (cell id, index), 1 = ascending (d2, index)
+    // how the canonical order is walked -- never WHAT is computed: every combination gives the same bits (kernels.hip)
+    int walk;        // 0: search and drain alternate, accept words in LDS (point_features); 1: two passes, the accept words of the whole walk through global memory (large neighborhoods)
+    int lanes;       // lanes per point: 2 or 4
 };
 
 struct NmsDesc {
@@ -148,6 +151,14 @@ struct DevState {
     int huge_count;                    // of them, points left to the workgroup kernel (second half of large_list)
     unsigned long long key_cursor;     // keys handed out of ViewDev::sort_keys so far (counts on past key_cap)
     unsigned long long keys_needed;    // key_cursor of the last call
+    // neighborhood size of the view, for the handle's NEXT call: sum of K_f and number of points over a sample of the waves of
+    // the feature kernels (one in 64); cumulative, the host takes differences (api.cpp).  On a cache line of their own:
+    // every wave of every kernel reads the grid descriptor at the top of this struct, and atomics on its line queue those
+    // reads behind them (the bench lost 3 % with the counters next to it)
+    alignas(128) unsigned long long kf_sum;
+    unsigned long long kf_points;
+    // two-pass walk (kernels.hip): entries handed out of each 32nd of the word list (ViewDev::sort_keys); zero between calls
+    alignas(128) unsigned long long word_cursor[32];
 };
 void init_dev_state(DevState *host_copy);
 // look-back polls of the compaction's single-pass scan before the call is failed (default 2^22; < 0: every block but the

@@ -8,6 +8,7 @@
 // /root/reference/src/KeypointLearning.cpp:41-92; per-kernel citations below.
 #include "kernels.h"
 #include "exact_math.h"
+#include "soft_pair.h"
 
 #ifdef KPL_ABLATE
 #error "KPL_ABLATE timing experiments are not part of libkpl: build them from a scratch copy of this file"
@@ -696,30 +697,12 @@ __global__ __launch_bounds__(256) void pos_of_kernel(Batch b) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Soft assignment, /root/reference/src/KeypointLearning.cpp:41-65 and :68-92.  dim, dim/2 and
-// RN(1/dim) are per-launch constants computed on the host with float operations.  The
-// reference's assert on the index range is replaced by a clamp (no effect on in-range values).
-//
+// Soft assignment, /root/reference/src/KeypointLearning.cpp:41-65 and :68-92: soft_pair.h (soft_pair, clamp_cosine
+// and the per-launch constants dim, dim/2, RN(1/dim)) -- one definition shared with tools/check_soft_pair.hip, which
+// runs it on the device over the table generated by the reference's own functions (tests/golden/pair_kat.json).
 // div_rn(a, b, rb) = the correctly rounded quotient a / b in 3 instructions, sqrt_rn(x) = the correctly rounded
 // square root in 9: exact_math.h.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void soft_pair(int n, float nm1, float v, float dim, float half_dim, float rdim,
-                                          int &k, int &p, float &w) {
-    // k = (int)floor(v / dim) and "if (k == n) k--" (cpp:45-48, :76-79).  v >= 0 here (a square root; a cosine
-    // clamped to [0, 2]), so k >= 0, and the floor -- an integer-valued float far below 2^24 -- clamped to
-    // nm1 = (float)(n - 1) IS the (float)k of cpp:52 / :83: no round trip through the integer
-    // (the minimum as an INTEGER minimum of the bit patterns -- both floats are >= +0 --: fminf would first canonicalise the
-    // launch constant nm1 with a v_max_f32 of its own, every time)
-    const float kf = __int_as_float(min(__float_as_int(floorf(div_rn(v, dim, rdim))), __float_as_int(nm1)));
-    k = (int)kf;
-    float center = (kf * dim) + half_dim;
-    float wt = v - center;
-    wt = div_rn(wt, dim, rdim);
-    p = (wt > 0) ? k + 1 : k - 1;
-    p = min(max(p, 0), n - 1);            // p == -1 -> 0; p == n (only from k == n - 1) -> k (cpp:59-60, :88-89)
-    w = fabsf(wt);
-}
-
 struct CellBox {
     int lo[3], hi[3];
 };
@@ -773,7 +756,7 @@ __device__ __forceinline__ Contribution neighbor_contribution(const FeatDesc &f,
     int a, ap, bi, bp;
     float aw, bw;
     soft_pair(f.A, f.A1f, sqrt_rn(d2), f.ann_dim, f.ann_half, f.ann_rdim, a, ap, aw);   // hpp:345
-    cosine = fminf(fmaxf(cosine, 0.0f), 2.0f);                                     // cpp:70-73
+    cosine = clamp_cosine(cosine);                                                 // cpp:70-73
     soft_pair(f.B, f.B1f, cosine, f.bin_dim, f.bin_half, f.bin_rdim, bi, bp, bw);          // hpp:348
     Contribution c;
     c.w00 = (1 - bw) * (1 - aw);
@@ -919,11 +902,13 @@ __host__ __device__ inline size_t feature_lds_bytes(int F, int ecap) {
     return (sizeof(float) * (size_t)F + sizeof(uint2) * (size_t)ecap) * (size_t)(kLanes / G);
 }
 
-// OR over the G lanes of a group (DPP quad_perm [1,0,3,2], then [2,3,0,1])
+// OR over the G lanes of a group (DPP quad_perm [1,0,3,2], then [2,3,0,1], then row_half_mirror: lane i <-> 7 - i of
+// every 8 lanes, which pairs the two quads of the group)
 template <int G>
 __device__ __forceinline__ unsigned group_or(unsigned v) {
     v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);
-    if (G == 4) v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);
+    if (G >= 4) v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);
+    if (G == 8) v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true);
     return v;
 }
 
@@ -941,7 +926,7 @@ template <int G>
 __device__ __forceinline__ int point_features(const float4 *__restrict__ pts, const float4 *__restrict__ nrm,
                                                     const int *__restrict__ cell_start, const GridDesc &g,
                                                     const FeatDesc &fin, float4 p, float4 np, float *H, uint2 *ent,
-                                                    int ecap, bool active) {
+                                                    int ecap, bool active, float *raw_mass = nullptr) {
     static_assert(G == 2 || G == 4, "lanes per point");
     constexpr int kPts = kLanes / G, kStepBits = kStepW * G, kSteps = 32 / kStepBits;    // 16 / 8 candidates per step
     const int tid = threadIdx.x, pi = tid / G, gq = tid % G;
@@ -1094,6 +1079,16 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts, co
         if (!slots_left && !__any(t < t1)) break;
     }
     wave_lds_fence();
+    // the sum of the lane's cells BEFORE the rows are normalised: every neighbor with a finite normal added weights that sum
+    // to one, so the histogram's mass is the size of the neighborhood (minus the dropped first neighbor) -- the caller's
+    // sample of K_f for the handle's next launch (note_kf), taken by the sampled waves only and at no cost to the loops above
+    // (kept live through them, the count of accepted neighbors took the kernel from 96 to 98 registers = from 5 waves per
+    // SIMD to 4: -2.5 % on the bench)
+    if (raw_mass) {
+        float m = 0.0f;
+        for (int c = gq; c < f.F; c += G) m += H[c * kPts + pi];
+        *raw_mass = m;
+    }
     for (int a = gq; a < f.A; a += G) {                                            // hpp:360-370, one row per lane
         float *h = H + (a * f.B) * kPts + pi;
         float s = 0.0f;
@@ -1107,6 +1102,441 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts, co
     }
     wave_lds_fence();
     return kf;
+}
+
+// ---------------------------------------------------------------------------------------------
+// computePointFeatures for LARGE neighborhoods in TWO PASSES (FeatDesc::walk == kWalkTwoPass; the reference's own default
+// operating point: radiusFeatures 20 on the cheff views = 30 mesh resolutions, ~730 points per cell, K_f ~ 2 300, ~10 000
+// candidates in the 27 cells around a point -- /root/reference/src/main_test_detector.cpp:65).  Same neighbor set, same
+// canonical order, same arithmetic as point_features: the results are the same bits.
+//
+// point_features alternates search and drain whenever ONE point of the wave has filled its 24 accept words in LDS.  With
+// thousands of neighbors per point that is a drain every few hundred candidates, and every drain lasts as long as the
+// point with the most accepted neighbors SINCE THE LAST ONE: on cheff001 a wave runs 1 700 drain rounds of two neighbors
+// per point where its longest neighborhood needs 1 260, and the waves of the densest cells -- 2.7 x the candidates, 1.5 x
+// the neighbors of the average wave -- run 3 600, alone on their SIMDs for the second half of the launch (measured with
+// in-kernel stamps: profiles/r05_notes.md).  Here the accept words of a point's WHOLE walk go to a list in global
+// memory first (search_point_words: nothing but the search, no LDS, deep prefetch), and a second kernel drains every list
+// in one go (drain_point_words): its rounds are those of the wave's longest neighborhood, once.
+//   word list of a wave   ViewDev::sort_keys (an array of 8-byte records that the sorted-search mode uses for its keys; a
+//                         view is in one mode or the other), one contiguous block per wave of the search kernel:
+//                         entry e of the wave's point pi at block + e * (64 / G) + pi -- x = storage position of the
+//                         word's first candidate, y = accept bits (first candidate = bit 0), the first accepted neighbor
+//                         of the point already dropped (hpp:336).  seg_start[s] = block + pi, seg_len[s] = entries.
+//   blocks                bump allocation, one returning atomic per wave on one of 32 cursors (DevState::word_cursor: returning
+//                         atomics on one address complete one after the other, ~11 ns each -- 8 000 waves on one cursor
+//                         would queue for 90 us), each over a 32nd of the array.  The size of a block is known before the walk: the wave steps
+//                         through its rows in lock step, one word per step.  A block that does not fit sets
+//                         kStatusKeyCapacity: the call fails with KPL_ERR_RETRY and finds the array grown (kpl_sync_status).
+// ---------------------------------------------------------------------------------------------
+constexpr int kWalkLanes = 0, kWalkTwoPass = 1;      // FeatDesc::walk
+constexpr int kWordShards = 32;
+
+// maximum over the lanes of the wave (every lane returns it)
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d));
+    return v;
+}
+
+// Pass 1: the accept words of the point's whole walk -> list[e * kPts] (the caller has added the point's column).
+// Returns K_f; entries = the number of words stored.  `block` is called once, with the number of word steps of the wave
+// (an upper bound of every point's entries), and returns the wave's block of the list or nullptr.
+template <int G, class Block>
+__device__ __forceinline__ int search_point_words(const float4 *__restrict__ pts, const int *__restrict__ cell_start,
+                                                  const GridDesc &g, const FeatDesc &fin, float4 p, bool active,
+                                                  Block block, int &entries) {
+    static_assert(G == 2 || G == 4, "lanes per point");
+    constexpr int kPts = kLanes / G, kStepBits = kStepW * G, kSteps = 32 / kStepBits;
+    const int tid = threadIdx.x, pi = tid / G, gq = tid % G;
+    const float r2 = pin_f(fin.r2);
+    CellBox b = make_box(g, p.x, p.y, p.z, fin.rr);
+    b.hi[1] = min(b.hi[1], b.lo[1] + 3);
+    b.hi[2] = min(b.hi[2], b.lo[2] + 3);
+    const int ny = active ? b.hi[1] - b.lo[1] + 1 : 0, nz = active ? b.hi[2] - b.lo[2] + 1 : 0;
+    const int wny = __any(ny > 3) ? 4 : __any(ny > 2) ? 3 : __any(ny > 1) ? 2 : __any(ny > 0) ? 1 : 0;
+    const int wnz = __any(nz > 3) ? 4 : __any(nz > 2) ? 3 : __any(nz > 1) ? 2 : __any(nz > 0) ? 1 : 0;
+    const int t_max = max(cell_start[g.ncells] - 1, 0);
+    auto row_range = [&](int ky, int kz, int &r0, int &r1) {
+        const bool valid = (ky < ny) & (kz < nz);
+        const int row = valid ? ((b.lo[2] + kz) * g.dims[1] + b.lo[1] + ky) * g.dims[0] : 0;
+        const int x = ld4(cell_start, row + (valid ? b.lo[0] : 0));
+        const int y = ld4(cell_start, row + (valid ? b.hi[0] + 1 : 0));
+        r0 = valid ? x : 0;
+        r1 = valid ? y : 0;
+    };
+    // the word steps of the wave: every row slot costs it the words of its longest instance
+    int steps = 0;
+    for (int kz = 0; kz < wnz; ++kz)
+        for (int ky = 0; ky < wny; ++ky) {
+            int r0, r1;
+            row_range(ky, kz, r0, r1);
+            steps += wave_max_i((r1 - r0 + 31) >> 5);
+        }
+    entries = 0;
+    uint2 *list = block(steps);
+    if (list == nullptr) return 0;
+    list += pi;
+    int ky = 0, kz = 0;
+    bool slots_left = wny > 0 && wnz > 0;
+    int n0 = 0, n1 = 0;
+    if (slots_left) row_range(0, 0, n0, n1);
+    int t = 0, t1 = 0;                            // current row of the group: next candidate of lane 0, end
+    const int mine = kStepW * gq;                 // this lane's 4 candidates of a step start here
+    const int nib_shift = 4 * (G - 1 - gq);
+    // the candidates of a whole word are in flight while the word before is tested
+    Cand cur[kSteps], nxt[kSteps];
+#pragma unroll
+    for (int st = 0; st < kSteps; ++st) cur[st] = load_cand(pts, 0);
+    bool first_pending = true;
+    int kf = 0, ecnt = 0;
+    for (;;) {
+        if (!__any(t < t1)) {
+            if (!slots_left) break;
+            t = n0;
+            t1 = n1;
+#pragma unroll
+            for (int st = 0; st < kSteps; ++st) cur[st] = load_cand(pts, min(t + st * kStepBits + mine, t_max));
+            if (++ky == wny) {
+                ky = 0;
+                ++kz;
+            }
+            slots_left = kz < wnz;
+            if (slots_left) row_range(ky, kz, n0, n1);
+            continue;
+        }
+        const int wbase = t;
+#pragma unroll
+        for (int st = 0; st < kSteps; ++st) nxt[st] = load_cand(pts, min(t + 32 + st * kStepBits + mine, t_max));
+        unsigned w = 0u;
+#pragma unroll
+        for (int st = 0; st < kSteps; ++st) w = (w << kStepBits) | group_or<G>(search_step(0u, p, cur[st], r2) << nib_shift);
+#pragma unroll
+        for (int st = 0; st < kSteps; ++st) cur[st] = nxt[st];
+        t += 32;
+        const int nv = min(max(t1 - wbase, 0), 32);                  // candidates of this word inside the row
+        w = nv > 0 ? (w & (0xffffffffu << ((32 - nv) & 31))) : 0u;
+        kf += __popc(w);
+        if (first_pending & (w != 0u)) {                             // hpp:336
+            w = drop_first_bit(w);
+            first_pending = false;
+        }
+        if (w != 0u) {
+            if (gq == 0) list[ecnt * kPts] = make_uint2((unsigned)wbase, __brev(w));     // first candidate = bit 0
+            ++ecnt;
+        }
+    }
+    entries = ecnt;
+    return kf;
+}
+
+// Pass 1 for the cells that hold MANY points (what the two-pass walk exists for): with hundreds of points per cell the
+// 64 / G points of a wave -- consecutive storage positions -- nearly always share ONE cell, hence one search box, and walk
+// the same rows.  search_point_words lets every lane fetch its candidates itself: 8 twelve-byte loads per word and lane,
+// every lane at an address of its own -- the texture addresser of the CU takes them a lane at a time, and a kernel that
+// does nothing but search is bound by it (cheff001: 0.53 ms).  Here the wave fetches the candidates ONCE, for all its
+// points:
+//   group    the points of the wave that lie in the same grid cell (usually all of them; a wave that straddles cells
+//            takes its groups one after the other).  Their boxes differ by a cell at most: the wave walks the UNION of
+//            them -- rows (cz, cy) ascending, every row the run of cells lo_x .. hi_x --, a superset of every point's
+//            own box in the same order; what lies outside a point's own box is farther than rr > r from it in one
+//            coordinate and fails the distance test like any other candidate.
+//   stage    the row in windows of W consecutive storage positions, copied to LDS by the whole wave
+//            (global_load_lds_dwordx4: 1 KiB per instruction, no registers, all of a window in flight together)
+//   search   as in search_point_words -- 4 G candidates per step, accept words of 32 candidates, the first accepted
+//            neighbor of a point dropped (hpp:336) -- but every group reads the SAME candidates, from LDS
+// The words of a point are cut at other positions than in search_point_words (rows start at the union's first cell);
+// the neighbors they stand for, and their order, are the same.
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void global_cvoid;
+
+// minimum / maximum over the lanes of the wave that take part (every lane returns the result)
+__device__ __forceinline__ int wave_min_of(int v, bool in) {
+    v = in ? v : 0x7fffffff;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d));
+    return v;
+}
+__device__ __forceinline__ int wave_max_of(int v, bool in) {
+    v = in ? v : (int)0x80000000;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d));
+    return v;
+}
+
+template <int G, class Block>
+__device__ __forceinline__ int search_point_words_staged(const float4 *__restrict__ pts, const int *__restrict__ cell_start,
+                                                         const GridDesc &g, const FeatDesc &fin, float4 p, bool active,
+                                                         float4 *sp, int W, Block block, int &entries) {
+    static_assert(G == 2 || G == 4 || G == 8, "lanes per point");
+    constexpr int kPts = kLanes / G, kStepBits = kStepW * G, kSteps = 32 / kStepBits;
+    const int tid = threadIdx.x, pi = tid / G, gq = tid % G;
+    const float r2 = pin_f(fin.r2);
+    const CellBox b = make_box(g, p.x, p.y, p.z, fin.rr);
+    const int cx = cell_coord(p.x, g.mn[0], g.h, g.dims[0]), cy = cell_coord(p.y, g.mn[1], g.h, g.dims[1]),
+              cz = cell_coord(p.z, g.mn[2], g.h, g.dims[2]);
+    const int own = (cz * g.dims[1] + cy) * g.dims[0] + cx;
+    // the union of the boxes of a group.  Its points share their cell c, and a box reaches two cells beyond the point's own at
+    // most (rr < 1.001 cell edges): the bounds come out of a few wave votes -- a reduction over the lanes is a chain of six
+    // cross-lane moves per bound, and a wave of this kernel lives for a few hundred word steps only
+    struct Union {
+        int lx, hx, ly, hy, lz, hz;
+    };
+    auto vote_min = [&](int v, int c, bool in) -> int {
+        if (__any(in && v < c - 2)) return pin_i(wave_min_of(v, in));
+        return __any(in && v <= c - 2) ? c - 2 : __any(in && v <= c - 1) ? c - 1 : c;
+    };
+    auto vote_max = [&](int v, int c, bool in) -> int {
+        if (__any(in && v > c + 2)) return pin_i(wave_max_of(v, in));
+        return __any(in && v >= c + 2) ? c + 2 : __any(in && v >= c + 1) ? c + 1 : c;
+    };
+    auto group_union = [&](bool in_group, int leader) {
+        const int lcx = __builtin_amdgcn_readlane(cx, leader), lcy = __builtin_amdgcn_readlane(cy, leader),
+                  lcz = __builtin_amdgcn_readlane(cz, leader);
+        Union u;
+        u.lx = vote_min(b.lo[0], lcx, in_group);
+        u.hx = vote_max(b.hi[0], lcx, in_group);
+        u.ly = vote_min(b.lo[1], lcy, in_group);
+        u.hy = vote_max(b.hi[1], lcy, in_group);
+        u.lz = vote_min(b.lo[2], lcz, in_group);
+        u.hz = vote_max(b.hi[2], lcz, in_group);
+        return u;
+    };
+    // the bounds of the rows rb .. rb + 63 of a union (row k = (lz + k / nyr, ly + k % nyr)), one row per lane: ONE round trip
+    // for all of them (fetched one after the other as the walk got to them, the 9 - 25 rows of a box cost a wave more than
+    // its word steps: 190 k of its 300 k cycles on cheff001)
+    auto row_bounds = [&](const Union &u, int rb, int &br0, int &br1) {
+        const int nyr = u.hy - u.ly + 1, nrows = nyr * (u.hz - u.lz + 1), k = rb + tid;
+        const bool rv = k < nrows;
+        const int rowbase = rv ? ((u.lz + k / nyr) * g.dims[1] + u.ly + k % nyr) * g.dims[0] : 0;
+        const int x = ld4(cell_start, rowbase + (rv ? u.lx : 0)), y = ld4(cell_start, rowbase + (rv ? u.hx + 1 : 0));
+        br0 = rv ? x : 0;
+        br1 = rv ? y : 0;
+        return nrows;
+    };
+    // word steps of the wave = those of its longest group (a point stores the words of its own group only)
+    int steps = 0;
+    {
+        unsigned long long todo = __ballot(active);
+        while (todo != 0ull) {
+            const int leader = pin_i(__builtin_ctzll(todo));
+            const bool in_group = active && own == __builtin_amdgcn_readlane(own, leader);
+            todo &= ~__ballot(in_group);
+            const Union u = group_union(in_group, leader);
+            int words = 0;
+            for (int rb = 0;; rb += kLanes) {
+                int br0, br1;
+                const int nrows = row_bounds(u, rb, br0, br1);
+                words += (br1 - br0 + 31) >> 5;
+                if (rb + kLanes >= nrows) break;
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) words += __shfl_xor(words, d);
+            steps = max(steps, pin_i(words));
+        }
+    }
+    entries = 0;
+    uint2 *list = block(steps);
+    if (list == nullptr) return 0;
+    list += pi;
+    const int mine = kStepW * gq;                 // this lane's 4 candidates of a step start here
+    const int nib_shift = 4 * (G - 1 - gq);
+    bool first_pending = true;
+    int kf = 0, ecnt = 0;
+    unsigned long long todo = __ballot(active);
+    while (todo != 0ull) {
+        const int leader = pin_i(__builtin_ctzll(todo));
+        const bool in_group = active && own == __builtin_amdgcn_readlane(own, leader);
+        todo &= ~__ballot(in_group);
+        const Union u = group_union(in_group, leader);
+      for (int rb = 0;; rb += kLanes) {              // (one pass: a union has 25 rows at most)
+        int br0, br1;
+        const int nrows = row_bounds(u, rb, br0, br1);
+        const int nb = min(kLanes, nrows - rb);
+        // the windows of the group's walk, one after the other: rows in order, a row in pieces of W candidates.
+        // Two buffers: the NEXT window is on its way to LDS while the current one is searched (a wave that waited for
+        // every window spent more time waiting than searching: 81 windows of a crowded cell at 2-3 us each)
+        int jrow = -1, w0 = 0, r1 = 0;                // the row jrow of the batch is cut from w0 on; r1 = its end
+        auto next_window = [&](int &o_w0, int &o_nw) -> bool {      // wave-uniform; false: no window left
+            for (;;) {
+                if (jrow >= 0 && w0 < r1) {
+                    o_w0 = w0;
+                    o_nw = min(W, r1 - w0);
+                    w0 += W;
+                    return true;
+                }
+                if (++jrow >= nb) return false;
+                w0 = __builtin_amdgcn_readlane(br0, jrow);
+                r1 = __builtin_amdgcn_readlane(br1, jrow);
+            }
+        };
+        auto issue = [&](int a_w0, int a_nw, float4 *buf) {
+            for (int j = 0; j < a_nw; j += kLanes) {
+                const int src = min(a_w0 + j + tid, a_w0 + a_nw - 1);              // (the last piece: lanes past the end re-read its last record)
+                __builtin_amdgcn_global_load_lds((global_cvoid *)(pts + src), (lds_void *)(buf + j), 16, 0, 0);
+            }
+        };
+        int c_w0 = 0, c_nw = 0, n_w0 = 0, n_nw = 0, cur = 0;
+        bool have = next_window(c_w0, c_nw);
+        if (have) issue(c_w0, c_nw, sp);
+        while (have) {
+            const bool more = next_window(n_w0, n_nw);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the current window has landed ...
+            wave_lds_fence();
+            if (more) issue(n_w0, n_nw, sp + (cur ^ 1) * W);          // ... the next one is under way while this one is searched
+            const float4 *win = sp + cur * W;
+            for (int wb = 0; wb < c_nw; wb += 32) {
+                unsigned w = 0u;
+                if (G == 8) {
+                    // lane gq of the group tests the candidates gq, gq + 8, gq + 16, gq + 24 of the word: every read
+                    // instruction of the wave then covers 8 CONSECUTIVE records (128 bytes, every bank once; the 4
+                    // consecutive candidates per lane of the other walks put lanes 0 and 4 of a group on the same banks).
+                    // All 16 bytes of a record: ds_read_b128 moves 256 bytes per clock, the ds_read_b96 the compiler would
+                    // pick 96 -- and this kernel is bound by what the LDS delivers (0.55 -> 0.35 ms on cheff001).
+                    Cand c;
+                    float4 q[kStepW];
+#pragma unroll
+                    for (int j = 0; j < kStepW; ++j) q[j] = win[wb + 8 * j + gq];
+                    static_assert(kStepW == 4, "the four reads of a word are requested together");
+                    asm volatile("" : "+v"(q[0].w), "+v"(q[1].w), "+v"(q[2].w), "+v"(q[3].w));      // (one wait for the four of them)
+#pragma unroll
+                    for (int j = 0; j < kStepW; ++j) c.q[j] = f32x3{q[j].x, q[j].y, q[j].z};
+                    // the lane's 4 accept bits (candidate gq + 8 j in bit 3 - j) -> bits 24, 16, 8, 0, then to the places of
+                    // its candidates: candidate c of the word in bit 31 - c
+                    const unsigned nib = search_step(0u, p, c, r2);
+                    w = group_or<G>(((nib * 0x00204081u) & 0x01010101u) << (7 - gq));
+                } else {
+#pragma unroll
+                    for (int st = 0; st < kSteps; ++st) {
+                        Cand c;
+                        float4 q[kStepW];
+#pragma unroll
+                        for (int j = 0; j < kStepW; ++j) q[j] = win[wb + st * kStepBits + mine + j];
+                        asm volatile("" : "+v"(q[0].w), "+v"(q[1].w), "+v"(q[2].w), "+v"(q[3].w));
+#pragma unroll
+                        for (int j = 0; j < kStepW; ++j) c.q[j] = f32x3{q[j].x, q[j].y, q[j].z};
+                        const unsigned part = group_or<G>(search_step(0u, p, c, r2) << nib_shift);
+                        w = (w << (kStepBits & 31)) | part;
+                    }
+                }
+                const int nv = min(c_nw - wb, 32);                               // candidates of this word inside the window
+                w &= 0xffffffffu << ((32 - nv) & 31);
+                w = in_group ? w : 0u;
+                kf += __popc(w);
+                if (first_pending & (w != 0u)) {                                 // hpp:336
+                    w = drop_first_bit(w);
+                    first_pending = false;
+                }
+                if (w != 0u) {
+                    if (gq == 0) list[ecnt * kPts] = make_uint2((unsigned)(c_w0 + wb), __brev(w));     // first candidate = bit 0
+                    ++ecnt;
+                }
+            }
+            wave_lds_fence();                                         // (this window has been read: its buffer is the one after the next)
+            have = more;
+            c_w0 = n_w0;
+            c_nw = n_nw;
+            cur ^= 1;
+        }
+        if (rb + kLanes >= nrows) break;
+      }
+    }
+    entries = ecnt;
+    return kf;
+}
+
+// Pass 2: the feature loop proper (hpp:334-359) over the point's word list, G neighbors per round as in point_features;
+// entry e of the point at list[e * stride].  H as in point_features (zeroed here, normalised here).
+template <int G>
+__device__ __forceinline__ void drain_point_words(const float4 *__restrict__ pts, const float4 *__restrict__ nrm,
+                                                  const FeatDesc &fin, float4 p, float4 np, float *H,
+                                                  const uint2 *__restrict__ list, int stride, int ecnt) {
+    static_assert(G == 2 || G == 4, "lanes per point");
+    constexpr int kPts = kLanes / G;
+    const int tid = threadIdx.x, pi = tid / G, gq = tid % G;
+    FeatDesc f;                                    // (pinned in scalar registers: see point_features)
+    f.A = pin_i(fin.A);
+    f.B = pin_i(fin.B);
+    f.F = pin_i(fin.F);
+    f.A1f = pin_f(fin.A1f);
+    f.B1f = pin_f(fin.B1f);
+    f.support = fin.support;
+    f.ann_dim = pin_f(fin.ann_dim);
+    f.ann_half = pin_f(fin.ann_half);
+    f.ann_rdim = pin_f(fin.ann_rdim);
+    f.bin_dim = pin_f(fin.bin_dim);
+    f.bin_half = pin_f(fin.bin_half);
+    f.bin_rdim = pin_f(fin.bin_rdim);
+    f.r2 = pin_f(fin.r2);
+    f.rr = fin.rr;
+    for (int c = gq; c < f.F; c += G) H[c * kPts + pi] = 0.0f;                     // hpp:325
+    const int col_address = lds_address(H + pi);
+    wave_lds_fence();
+    if (__any(ecnt > 0)) {
+        struct Taken {
+            bool valid;
+            f32x3 q, n;      // n.x is NaN for a normal that is not finite
+        };
+        const int last = max(ecnt - 1, 0);
+        int e = 0;                             // words of the point's list consumed
+        unsigned w = 0u;
+        int wbase = 0;
+        uint2 nw = ecnt > 0 ? list[0] : make_uint2(0u, 0u);                   // next word, requested ahead of its use
+        auto take = [&](Taken &slot) {
+            const bool refill = (w == 0u) & (e < ecnt);
+            w = refill ? nw.y : w;
+            wbase = refill ? (int)nw.x : wbase;
+            e += refill ? 1 : 0;
+            if (refill) nw = list[min(e, last) * stride];
+            unsigned m;
+            if (G == 2) {
+                const unsigned c1 = drop_lowest_bit(w);
+                m = gq == 0 ? w : c1;
+                w = drop_lowest_bit(c1);
+            } else {
+                const unsigned c1 = drop_lowest_bit(w), c2 = drop_lowest_bit(c1), c3 = drop_lowest_bit(c2);
+                m = gq == 0 ? w : gq == 1 ? c1 : gq == 2 ? c2 : c3;
+                w = drop_lowest_bit(c3);
+            }
+            slot.valid = m != 0u;
+            const int tt = slot.valid ? wbase + lowest_bit_index(m) : 0;
+            slot.q = ld12(pts, tt);
+            slot.n = ld12(nrm, tt);
+        };
+        Taken pa, pb;
+        pa.valid = pb.valid = false;
+        pa.q = pa.n = pb.q = pb.n = f32x3{0.f, 0.f, 0.f};
+#define KPL_LIST_ROUND(now, nxt)                                                                   \
+    {                                                                                              \
+        take(nxt);                                                                                 \
+        const bool has_ = now.valid & (now.n.x == now.n.x);                         /* hpp:338 */  \
+        Contribution c_;                                                                           \
+        if (has_) c_ = neighbor_contribution<kPts>(f, dist2(p.x, p.y, p.z, now.q), np, now.n, col_address); \
+        _Pragma("unroll") for (int sub_ = 0; sub_ < G; ++sub_) {                                   \
+            if (has_ & (gq == sub_)) apply_contribution(c_, request_cells(c_));                    \
+            wave_lds_fence();                                                                      \
+        }                                                                                          \
+        now.valid = false;                                                                         \
+    }
+        do {
+            KPL_LIST_ROUND(pa, pb)
+            KPL_LIST_ROUND(pb, pa)
+        } while (__any((w != 0u) | (e < ecnt) | pa.valid | pb.valid));
+#undef KPL_LIST_ROUND
+    }
+    wave_lds_fence();
+    for (int a = gq; a < f.A; a += G) {                                            // hpp:360-370, one row per lane
+        float *h = H + (a * f.B) * kPts + pi;
+        float s = 0.0f;
+        for (int k = 0; k < f.B; ++k) {
+            float v = h[k * kPts];
+            s += v * v;
+        }
+        const float nr = sqrtf(s);
+        if (nr > 0)
+            for (int k = 0; k < f.B; ++k) h[k * kPts] = h[k * kPts] / nr;
+    }
+    wave_lds_fence();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2011,23 +2441,106 @@ __device__ __forceinline__ int own_cell_population(const GridDesc &g, const int 
 // Several independent views per launch (blockIdx.y = view): one 200 k-point view is only a few waves per
 // SIMD; a batch of views fills the chip.  Workgroup (= wave) x handles the 64 / kGroup storage positions
 // x * 64 / kGroup ..; it writes its columns of the F x 64 feature block of its chunk of 64 positions.
-template <bool STATS>
+// K_f of the view for the handle's NEXT call (DevState::kf_sum / kf_points, cumulative; the host takes differences in
+// kpl_sync_status and picks the walk and the lanes per point of the next launch from them -- api.cpp choose_walk): one wave
+// in 64 adds the K_f of its points, a sample of every part of the view for two atomics per 64 waves
+__device__ __forceinline__ bool kf_sampled(int bx) { return (bx & 63) == 0; }
+// sum = what the lane adds (an exact count, or its share of a histogram's mass), points = 1 in the lanes that stand for a point
+__device__ __forceinline__ void note_kf(const ViewDev &v, float sum, int points) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        sum += __shfl_xor(sum, d);
+        points += __shfl_xor(points, d);
+    }
+    if (threadIdx.x == 0 && points > 0) {
+        atomicAdd(&v.ds->kf_sum, (unsigned long long)(sum + 0.5f));
+        atomicAdd(&v.ds->kf_points, (unsigned long long)points);
+    }
+}
+
+template <bool STATS, int G>
 __global__ __launch_bounds__(kLanes) void feature_kernel(Batch b, int maxF, int ecap) {
     extern __shared__ float H[];
-    constexpr int kPts = kLanes / kGroup;
+    constexpr int kPts = kLanes / G;
     const ViewDev &v = b.view[blockIdx.y];
-    if (v.f.sorted) return;                                           // scored by feature_sorted_kernel
-    const int chunk = blockIdx.x / kGroup, pi = threadIdx.x / kGroup, gq = threadIdx.x % kGroup;
-    const int col = (blockIdx.x % kGroup) * kPts + pi;                // the point's column of the chunk's F x 64 block
+    if (v.f.sorted || v.f.walk != kWalkLanes || v.f.lanes != G) return;       // scored by another kernel of the stage
+    const int chunk = blockIdx.x / G, pi = threadIdx.x / G, gq = threadIdx.x % G;
+    const int col = (blockIdx.x % G) * kPts + pi;                     // the point's column of the chunk's F x 64 block
     if (chunk * kLanes + col - pi >= v.n) return;
     const WavePoint w = wave_point(v, chunk, col, true);
     // every lane of the wave runs the feature code (wave-level votes inside); a group without a scoreable
     // point simply has no rows
-    const int kf = point_features<kGroup>(v.pts, v.nrm, v.cell_start, v.ds->grid, v.f, w.p, w.np, H,
-                                          reinterpret_cast<uint2 *>(H + maxF * kPts), ecap, w.scoreable);
+    const bool sampled = kf_sampled(blockIdx.x);
+    float mass = 0.0f;
+    const int kf = point_features<G>(v.pts, v.nrm, v.cell_start, v.ds->grid, v.f, w.p, w.np, H,
+                                     reinterpret_cast<uint2 *>(H + maxF * kPts), ecap, w.scoreable, sampled ? &mass : nullptr);
     if (STATS && w.scoreable && gq == 0) atomicAdd(&v.stats->sum_kf, (unsigned long long)kf);
+    if (sampled) note_kf(v, w.scoreable ? mass + (gq == 0 ? 1.0f : 0.0f) : 0.0f, w.scoreable && gq == 0 ? 1 : 0);
     float *o = v.feat + (size_t)chunk * v.f.F * kLanes + col;
-    for (int c = gq; c < v.f.F; c += kGroup) o[c * kLanes] = H[c * kPts + pi];
+    for (int c = gq; c < v.f.F; c += G) o[c * kLanes] = H[c * kPts + pi];
+}
+
+// the same for the views whose neighborhoods are LARGE (FeatDesc::walk == kWalkTwoPass), first pass: the accept words of
+// every point's whole walk -> its wave's block of the word list (search_point_words); no LDS
+constexpr int kSearchGroup = 8;        // lanes per point of the search pass: a word of 32 candidates is ONE step of the 8 lanes; 8 points per wave --
+                                       // the waves of the densest cells walk 2.7 x the words of the average wave, the launch lasts as long as they do
+constexpr int kSearchWindow = 128;     // candidates per staged window (two windows of 2 KB of LDS per wave: the ~31 waves per CU of a 63 k-point view are resident together)
+template <bool STATS>
+__global__ __launch_bounds__(kLanes) void feature_search_kernel(Batch b) {
+    __shared__ float4 sp[2 * kSearchWindow];        // two windows: one searched, the next on its way
+    constexpr int G = kSearchGroup, kPts = kLanes / G;
+    const ViewDev &v = b.view[blockIdx.y];
+    if (v.f.sorted || v.f.walk != kWalkTwoPass) return;
+    const int chunk = blockIdx.x / G, pi = threadIdx.x / G, gq = threadIdx.x % G;
+    const int col = (blockIdx.x % G) * kPts + pi;
+    if (chunk * kLanes + col - pi >= v.n) return;
+    const WavePoint w = wave_point(v, chunk, col, true);
+    unsigned first = 0u;                           // the wave's block: first entry of its point 0
+    bool fits = true;
+    auto block = [&](int steps) -> uint2 * {
+        // a 32nd of the array per cursor; the cursor of a wave = its number mod 32 (waves go to the XCDs round robin: four cursors per XCD)
+        const unsigned long long share = v.key_cap / kWordShards, need = (unsigned long long)steps * kPts;
+        const int shard = blockIdx.x % kWordShards;
+        unsigned long long off = 0ull;
+        if (threadIdx.x == 0 && need > 0) off = atomicAdd(&v.ds->word_cursor[shard], need);
+        off = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(off >> 32)) << 32) |
+              (unsigned)__builtin_amdgcn_readfirstlane((int)off);
+        fits = off + need <= share;
+        if (!fits) {
+            if (threadIdx.x == 0) atomicCAS(&v.ds->status, kStatusOk, kStatusKeyCapacity);
+            return nullptr;
+        }
+        first = (unsigned)(share * shard + off);
+        return reinterpret_cast<uint2 *>(v.sort_keys) + first;
+    };
+    int entries = 0;
+    const int kf = search_point_words_staged<G>(v.pts, v.cell_start, v.ds->grid, v.f, w.p, w.scoreable, sp, kSearchWindow, block, entries);
+    if (w.in_range && gq == 0) {
+        v.seg_start[w.s] = first + (unsigned)pi;
+        v.seg_len[w.s] = fits ? entries : 0;
+    }
+    if (STATS && w.scoreable && gq == 0) atomicAdd(&v.stats->sum_kf, (unsigned long long)kf);
+    if (kf_sampled(blockIdx.x)) note_kf(v, w.scoreable && gq == 0 ? (float)kf : 0.0f, w.scoreable && gq == 0 ? 1 : 0);
+}
+
+// ... second pass: every point's list drained in one go (drain_point_words).  `stride` = points per wave of the search
+// kernel (the lists of a wave's points are interleaved)
+//   LDS: [H: maxF x 64 / G floats]
+template <int G>
+__global__ __launch_bounds__(kLanes) void feature_drain_kernel(Batch b, int maxF, int stride) {
+    extern __shared__ float H[];
+    constexpr int kPts = kLanes / G;
+    const ViewDev &v = b.view[blockIdx.y];
+    if (v.f.sorted || v.f.walk != kWalkTwoPass || v.f.lanes != G) return;
+    const int chunk = blockIdx.x / G, pi = threadIdx.x / G, gq = threadIdx.x % G;
+    const int col = (blockIdx.x % G) * kPts + pi;
+    if (chunk * kLanes + col - pi >= v.n) return;
+    const WavePoint w = wave_point(v, chunk, col, true);
+    const int ecnt = w.scoreable ? v.seg_len[w.s] : 0;
+    const uint2 *list = reinterpret_cast<const uint2 *>(v.sort_keys) + (w.scoreable ? v.seg_start[w.s] : 0u);
+    drain_point_words<G>(v.pts, v.nrm, v.f, w.p, w.np, H, list, stride, ecnt);
+    float *o = v.feat + (size_t)chunk * v.f.F * kLanes + col;
+    for (int c = gq; c < v.f.F; c += G) o[c * kLanes] = H[c * kPts + pi];
 }
 
 // the same for the views in sorted-search mode: kSortGroup lanes per point, 64 / kSortGroup points per wave
@@ -3876,7 +4389,14 @@ __global__ __launch_bounds__(kScanBlock) void compact_scan_kernel(Batch b, int p
                                     __hip_atomic_load(&v.ds->scan_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
                 *v.kp_count = failed ? -1 : before + total;     // -1: see kpl_sync_status
                 *v.cand.count = 0;
-                v.ds->keys_needed = v.ds->key_cursor;        // sorted mode, large neighborhoods: re-armed for the next call
+                // sorted mode, large neighborhoods, and the word lists of the two-pass walk (32 cursors, each over a 32nd
+                // of the array: the fullest one counts): what the call needed, re-armed for the next call
+                unsigned long long wmax = 0ull;
+                for (int k = 0; k < kWordShards; ++k) {
+                    wmax = v.ds->word_cursor[k] > wmax ? v.ds->word_cursor[k] : wmax;
+                    v.ds->word_cursor[k] = 0ull;
+                }
+                v.ds->keys_needed = v.ds->key_cursor + wmax * kWordShards;
                 v.ds->key_cursor = 0ull;
                 v.ds->large_count = 0;
                 v.ds->huge_count = 0;
@@ -4039,9 +4559,10 @@ static int cu_count() {
 // and every launch with larger neighborhoods 10-25 % slower; the host cannot know the neighborhood size.
 // Fewer words for the largest histograms so that a handful of waves still fit a CU (160 KB of LDS).
 constexpr int kLdsPerCu = 160 * 1024;
+template <int G>
 static int accept_words(int F) {
     int e = 24;
-    while (e > 4 && feature_lds_bytes<kGroup>(F, e) * 6 > (size_t)kLdsPerCu) e -= 4;
+    while (e > 4 && feature_lds_bytes<G>(F, e) * 6 > (size_t)kLdsPerCu) e -= 4;
     return e;
 }
 
@@ -4084,14 +4605,39 @@ void launch_feature_stage(const Batch &b, hipStream_t st) {
         maxF = b.view[v].f.F > maxF ? b.view[v].f.F : maxF;
         stats |= b.view[v].stats != nullptr;
     }
-    bool canonical = false, sorted = false;
-    for (int v = 0; v < b.nviews; ++v) (b.view[v].f.sorted ? sorted : canonical) = true;
-    if (canonical) {
-        const int ecap = accept_words(maxF);
-        const size_t lds = feature_lds_bytes<kGroup>(maxF, ecap);
-        const dim3 grid(div_up(n, kLanes) * kGroup, b.nviews);
-        if (stats) feature_kernel<true><<<grid, kLanes, lds, st>>>(b, maxF, ecap);
-        else feature_kernel<false><<<grid, kLanes, lds, st>>>(b, maxF, ecap);
+    // the views of the batch by how their features are computed: every kernel of the stage skips the views of the others
+    bool sorted = false, lanes2 = false, lanes4 = false, two2 = false, two4 = false;
+    for (int v = 0; v < b.nviews; ++v) {
+        const FeatDesc &f = b.view[v].f;
+        if (f.sorted) sorted = true;
+        else if (f.walk == kWalkTwoPass) (f.lanes == 4 ? two4 : two2) = true;
+        else (f.lanes == 4 ? lanes4 : lanes2) = true;
+    }
+    if (lanes2) {
+        const int ecap = accept_words<2>(maxF);
+        const size_t lds = feature_lds_bytes<2>(maxF, ecap);
+        const dim3 grid(div_up(n, kLanes) * 2, b.nviews);
+        if (stats) feature_kernel<true, 2><<<grid, kLanes, lds, st>>>(b, maxF, ecap);
+        else feature_kernel<false, 2><<<grid, kLanes, lds, st>>>(b, maxF, ecap);
+    }
+    if (lanes4) {
+        const int ecap = accept_words<4>(maxF);
+        const size_t lds = feature_lds_bytes<4>(maxF, ecap);
+        const dim3 grid(div_up(n, kLanes) * 4, b.nviews);
+        if (stats) feature_kernel<true, 4><<<grid, kLanes, lds, st>>>(b, maxF, ecap);
+        else feature_kernel<false, 4><<<grid, kLanes, lds, st>>>(b, maxF, ecap);
+    }
+    // two passes (large neighborhoods): the search for every such view (eight lanes per point: the lists of a wave's 8
+    // points are interleaved), then the drain with the lanes per point of the view
+    if (two2 || two4) {
+        const dim3 sgrid(div_up(n, kLanes) * kSearchGroup, b.nviews);
+        if (stats) feature_search_kernel<true><<<sgrid, kLanes, 0, st>>>(b);
+        else feature_search_kernel<false><<<sgrid, kLanes, 0, st>>>(b);
+        const int stride = kLanes / kSearchGroup;
+        if (two2)
+            feature_drain_kernel<2><<<dim3(div_up(n, kLanes) * 2, b.nviews), kLanes, sizeof(float) * (size_t)maxF * (kLanes / 2), st>>>(b, maxF, stride);
+        if (two4)
+            feature_drain_kernel<4><<<dim3(div_up(n, kLanes) * 4, b.nviews), kLanes, sizeof(float) * (size_t)maxF * (kLanes / 4), st>>>(b, maxF, stride);
     }
     if (sorted) {       // the views in sorted-search mode (each kernel skips the views of the other mode)
         // the register-sort kernel lists the points with large neighborhoods instead of scoring them, the collect / add pair
@@ -4214,7 +4760,7 @@ void launch_features(const float4 *pts, const float4 *nrm, const char *nrmsrc, u
             pts, nrm, nrmsrc, ns, cell_start, pos_of, ds, f, query, m, n, kSortWords, lcap, out);
         return;
     }
-    const int ecap = accept_words(f.F);
+    const int ecap = accept_words<kGroup>(f.F);
     features_kernel<<<div_up(m, kLanes / kGroup), kLanes, feature_lds_bytes<kGroup>(f.F, ecap), st>>>(pts, nrm, cell_start, pos_of, ds,
                                                                                                       f, query, m, n, ecap, out);
 }

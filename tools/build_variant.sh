@@ -10,7 +10,7 @@ V=$R/build/variants/$name
 C=$R/keypoint-learning_amd/csrc
 mkdir -p $V
 [ -f $V/kernels.hip ] || cp $C/kernels.hip $V/kernels.hip
-cp $C/kernels.h $C/forest.h $C/organized_normals.h $C/exact_math.h $V/ 2>/dev/null || true
+cp $C/kernels.h $C/forest.h $C/organized_normals.h $C/exact_math.h $C/soft_pair.h $V/ 2>/dev/null || true
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-result -x hip -I$C -I$R/include"
 /opt/rocm/bin/hipcc $FLAGS "$@" -c $V/kernels.hip -o $V/kernels.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/build/variants/libkpl_$name.so $V/kernels.o $C/organized_normals.o $C/api.o $C/forest.o -lz -Wl,-rpath,/opt/rocm/lib

@@ -145,26 +145,34 @@ def cfg0():
     r, rn, thr = float(z["r_feat"]), float(z["r_nms"]), float(z["thr"])
     rows = {}
     cores = helpers.usable_cores()
-    for order in ("canonical", "sorted"):
+    walks = [a for a in sys.argv[1:] if a.startswith("walk=")]          # e.g. walk=lanes2 walk=twopass4: forced walks beside the automatic one
+    variants = [("canonical", None), ("sorted", None)] + [("canonical", w[5:]) for w in walks]
+    for order, forced in variants:
         t0 = time.perf_counter()
         kplo.detect(xyz, nrm, 5, 10, r, rn, thr, helpers.oracle_forest(fa), threads=cores,
                     order=kplo.ORDER_SORTED if order == "sorted" else kplo.ORDER_CANONICAL)
         cpu_all = len(xyz) / (time.perf_counter() - t0) / 1e6
         det = make_detector(5, 10, r, rn, thr, forest, sorted_search=order == "sorted")
+        if forced:
+            det.setFeatureWalk(kpl.WALK_TWO_PASS if forced.startswith("twopass") else kpl.WALK_LANES, int(forced[-1]))
         mr = det.cloudResolution(xyz)
         t, sc, kp, phases, st = time_gpu(det, xyz, nrm, reps=10, batch=3)
         ok = bool(helpers.same_bits(sc, z["scores_" + order]) and np.array_equal(kp, z["kp_" + order]))
         n = len(xyz)
         b_feat = 24 * (st["n_scored"] + st["sum_kf"])
-        rows[order] = {"config": "cfg0 TestDetector defaults: cheff001, 5x10, r_feat 20 (%.1f mr), r_nms 4, %s order" % (r / mr, order),
+        wk = det.getFeatureWalk()
+        key = order if not forced else forced
+        order_name = order if not forced else "canonical order, walk forced to " + forced
+        rows[key] = {"config": "cfg0 TestDetector defaults: cheff001, 5x10, r_feat 20 (%.1f mr), r_nms 4, %s order" % (r / mr, order_name),
+                       "walk": {"walk": "two-pass" if wk[0] == kpl.WALK_TWO_PASS else "lanes", "lanes_per_point": wk[1], "mean_neighbors_measured": round(wk[2], 1)},
                        "N": n, "T": fa.ntrees, "nodes": int(fa.nnodes), "mr": round(mr, 5), "gpu_Mpts": round(n / t / 1e6, 2),
                        "gpu_ms": round(t * 1e3, 4), "phases_ms": {k: round(v, 4) for k, v in phases.items()},
                        "K_f": round(st["sum_kf"] / max(st["n_scored"], 1), 1), "keypoints": int(len(kp)),
                        "feature_kernel_alg_GBps": round(b_feat / (phases["feature_ms"] * 1e-3) / 1e9, 1),
                        "feature_kernel_frac_of_8TBps": round(b_feat / (phases["feature_ms"] * 1e-3) / 8e12, 4),
                        "cpu_all_Mpts": round(cpu_all, 4), "cores": cores, "parity": ok}
-        print(json.dumps(rows[order]), flush=True)
-        assert ok, "PARITY FAILURE in cfg0 " + order
+        print(json.dumps(rows[key]), flush=True)
+        assert ok, "PARITY FAILURE in cfg0 " + key
     print(json.dumps({"config": "cfg0 sorted / canonical", "compute_ratio": round(rows["sorted"]["gpu_ms"] / rows["canonical"]["gpu_ms"], 3),
                       "feature_kernel_ratio": round(rows["sorted"]["phases_ms"]["feature_ms"] / rows["canonical"]["phases_ms"]["feature_ms"], 3)}),
           flush=True)
@@ -264,7 +272,70 @@ def cfg5():
            {"forest_build_s": round(time.perf_counter() - t0, 1)})
 
 
+def cfg0b():
+    """The reference's default operating point as a BATCH: 8 cheff views (cheff000 / 001 / 002, the three clouds of
+    data/point_cloud_test, cycled) through kpl_compute_batch_device at radiusFeatures 20 / radiusNMS 4, 5 x 10 -- what
+    DetectViews does with the views of a dataset.  Views checked against the oracle's scores of the same view."""
+    forest = os.path.join(ROOT, "data", "forests", "cheff_a5b10_t10.yaml.gz")
+    fa = forest_yaml.load_forest(forest)
+    z1 = np.load(os.path.join(ROOT, "tests", "golden", "cheff001.npz"))
+    r, rn, thr = float(z1["r_feat"]), float(z1["r_nms"]), float(z1["thr"])
+    clouds = [np.load(os.path.join(ROOT, "tests", "golden", "cheff00%d.npz" % k)) for k in (1, 0, 2)]
+    of = helpers.oracle_forest(fa)
+    expect = [kplo.detect(c["xyz"], c["nrm"], 5, 10, r, rn, thr, of, threads=helpers.usable_cores()) for c in clouds]
+    for order in ("canonical", "sorted"):
+        if order == "sorted":
+            expect = [kplo.detect(c["xyz"], c["nrm"], 5, 10, r, rn, thr, of, threads=helpers.usable_cores(), order=kplo.ORDER_SORTED)
+                      for c in clouds]
+        dets, bufs = [], []
+        for k in range(8):
+            c = clouds[k % 3]
+            det = make_detector(5, 10, r, rn, thr, forest, sorted_search=order == "sorted")
+            n = len(c["xyz"])
+            dx, dn = torch.from_numpy(np.array(c["xyz"])).to(DEV), torch.from_numpy(np.array(c["nrm"])).to(DEV)
+            ds = torch.empty(n, dtype=torch.float32, device=DEV)
+            dk = torch.zeros(n + 1, dtype=torch.int32, device=DEV)
+            det.bindCloudDevice(dx.data_ptr(), 12, dn.data_ptr(), 12, n)
+            dets.append(det); bufs.append((dx, dn, ds, dk))
+        stream = torch.cuda.Stream()
+
+        def sweep():
+            kpl.compute_batch_device(dets, [b[2].data_ptr() for b in bufs], [b[3][1:].data_ptr() for b in bufs],
+                                     [len(b[2]) for b in bufs], [b[3][0:1].data_ptr() for b in bufs], stream.cuda_stream)
+        torch.cuda.synchronize()
+        for _ in range(6):          # tables grow, then the handles learn their neighborhood size
+            sweep()
+            torch.cuda.synchronize()
+            if kpl.ERR_RETRY not in [det.syncStatus(None) for det in dets]:
+                pass
+        sweep(); torch.cuda.synchronize()
+        assert all(det.syncStatus(None) == kpl.OK for det in dets)
+        ok = True
+        for k, (det, (dx, dn, ds, dk)) in enumerate(zip(dets, bufs)):
+            o_sc, o_kp = expect[k % 3]
+            cnt = int(dk[0].item())
+            ok &= bool(helpers.same_bits(ds.cpu().numpy(), o_sc) and np.array_equal(dk[1:1 + cnt].cpu().numpy(), o_kp))
+        dets[0].enableTiming(True)
+        times = []
+        for _ in range(12):
+            t0 = time.perf_counter()
+            sweep(); sweep()
+            torch.cuda.synchronize()
+            times.append((time.perf_counter() - t0) / 2)
+        tm = dets[0].getTiming()
+        dets[0].enableTiming(False)
+        t = float(np.median(times))
+        npts = sum(len(b[2]) for b in bufs)
+        wk = dets[0].getFeatureWalk()
+        print(json.dumps({"config": "cfg0b 8 cheff views in one batch at the reference's defaults (5x10, r_feat 20, r_nms 4), %s order" % order,
+                          "points": npts, "ms_per_batch": round(t * 1e3, 4), "gpu_Mpts": round(npts / t / 1e6, 2),
+                          "walk": {"walk": "two-pass" if wk[0] == kpl.WALK_TWO_PASS else "lanes", "lanes_per_point": wk[1], "mean_neighbors_measured": round(wk[2], 1)},
+                          "phases_ms": {k: round(tm[k] / max(tm["calls"], 1), 4) for k in ("index_ms", "feature_ms", "forest_ms", "nms_ms")},
+                          "parity": ok}), flush=True)
+        assert ok, "PARITY FAILURE in cfg0b " + order
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["cfg0", "cfg1", "cfg2", "cfg3", "cfg4", "cfg5"]
+    which = [a for a in sys.argv[1:] if not a.startswith("walk=")] or ["cfg0", "cfg1", "cfg2", "cfg3", "cfg4", "cfg5"]
     for name in which:
         globals()[name]()
