@@ -104,6 +104,11 @@ int kpl_set_feature_walk(kpl_detector *h, int walk, int lanes_per_point);
 /* what the next launch would use, and the mean neighbors per point it is based on (< 0: not measured yet) */
 int kpl_get_feature_walk(const kpl_detector *h, int *walk, int *lanes_per_point, double *mean_neighbors);
 
+/* Test hook, per handle: look-back polls of the keypoint compaction's single-pass scan before the call is failed with
+ * KPL_ERR_INTERNAL (default 2^22, never reached in practice); polls < 0 makes every block but the first give up at once, which
+ * is how tests/test_gpu_status.py drives the failure path.  No environment variable, no process-wide state. */
+int kpl_debug_set_scan_poll_limit(kpl_detector *h, int polls);
+
 /* Counters for the algorithmic-bytes model of SURVEY.md 8(d), filled by kpl_collect_stats. */
 typedef struct kpl_stats {
     int64_t n_points;        /* points handed in                                              */

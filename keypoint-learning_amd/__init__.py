@@ -89,6 +89,7 @@ SYMBOLS = {
     "kpl_compute_batch_keypoints_device": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "kpl_sync_status": (C.c_int, [_vp, _vp]),
     "kpl_set_feature_walk": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "kpl_debug_set_scan_poll_limit": (C.c_int, [_vp, C.c_int]),
     "kpl_get_feature_walk": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "kpl_enable_timing": (C.c_int, [_vp, C.c_int]),
     "kpl_get_timing": (C.c_int, [_vp, C.POINTER(Timing)]),

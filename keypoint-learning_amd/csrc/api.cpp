@@ -73,6 +73,7 @@ struct kpl_detector {
     // how the feature kernels walk the neighborhoods (never WHAT they compute): kpl_set_feature_walk, or -- automatic -- the
     // mean K_f the handle's previous calls measured (DevState::kf_sum / kf_points, read back in sync_status)
     int walk_forced = KPL_WALK_AUTO, lanes_forced = 0;
+    int scan_poll_limit = 1 << 22;   // kpl_debug_set_scan_poll_limit (per handle)
     double kf_hint = -1.0;        // mean neighbors per point of the calls before the last status read; < 0: not known
     double kf_hint_radius = 0.0;  // ... measured at this feature radius
     int kf_hint_n = 0;            // ... on a view of this many points
@@ -212,6 +213,7 @@ NmsDesc make_nms(const kpl_params &p) {
     d.non_maxima = p.non_maxima;
     d.draws_remove = p.non_maxima && p.non_maxima_draws_remove;
     d.draws_thr = p.non_maxima_draws_threshold;
+    d.scan_poll_limit = 1 << 22;
     return d;
 }
 
@@ -376,15 +378,21 @@ int sync_status(kpl_detector *h, hipStream_t st) {
         h->kf_seen_sum = h->h_state->kf_sum;
         h->kf_seen_points = h->h_state->kf_points;
     }
+    const bool scan_failed = h->h_state->scan_fail != 0;
+    if (scan_failed) {
+        // a workgroup of the compaction's single-pass scan never saw its predecessors publish (kernels.hip,
+        // compact_scan_kernel): the keypoint list of that call is invalid.  The flag is cleared HERE, before any return of
+        // this function -- whichever status the call ends with, the next call starts clean
+        KPL_HIP(h, hipMemsetAsync((char *)h->dstate.p + offsetof(DevState, scan_fail), 0, sizeof(int), st));
+        KPL_HIP(h, hipStreamSynchronize(st));
+    }
     if (h->h_state->status == kStatusGridTooLarge)
         return fail(h, KPL_ERR_GRID_TOO_LARGE, "bounding box / radius needs more than 2^28 grid cells");
     if (h->h_state->status == kStatusBadOrigin)
         return fail(h, KPL_ERR_INVALID_ARG, "the grid origin (kpl_set_grid_origin) exceeds the minimum of the view");
-    if (h->h_state->scan_fail != 0) {
-        // a workgroup of the compaction's single-pass scan never saw its predecessors publish (kernels.hip,
-        // compact_scan_kernel): the keypoint list of that call is invalid.  Cleared here so that the next call starts clean
-        KPL_HIP(h, hipMemsetAsync((char *)h->dstate.p + offsetof(DevState, scan_fail), 0, sizeof(int), st));
-        KPL_HIP(h, hipStreamSynchronize(st));
+    if (scan_failed && h->h_state->status == kStatusOk) {
+        h->index_valid = false;              // (like every other deferred failure: nothing of that call is trusted)
+        h->pos_of_valid = false;
         return fail(h, KPL_ERR_INTERNAL, "keypoint compaction: the look-back of the single-pass scan timed out (call again)");
     }
     if (h->h_state->status == kStatusKeyCapacity) {
@@ -438,7 +446,8 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
         KPL_HIP(h, hipMemset(h->scan_state.p, 0, h->scan_state.cap));     // tag 0 = "never written"
         KPL_HIP(h, hipDeviceSynchronize());
     }
-    const NmsDesc nd = make_nms(h->prm);
+    NmsDesc nd = make_nms(h->prm);
+    nd.scan_poll_limit = h->scan_poll_limit;
     if (nd.draws_remove) {
         if (h->skip.cap < sizeof(int) * nn) {
             KPL_HIP(h, hipDeviceSynchronize());
@@ -701,7 +710,7 @@ int detect_staged(kpl_detector *h, int n, float *scores_out, int *kp_idx_out, fl
         if (scores_out && n > 0)
             KPL_HIP(h, hipMemcpyAsync(scores_out, h->out_scores.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, st));
         rc = sync_status(h, st);
-        if (rc == KPL_ERR_RETRY && attempt < 3) continue;    // cell tables / key segments were grown: run again
+        if (rc == KPL_ERR_RETRY && attempt < 6) continue;    // cell tables / key segments / word lists were grown: run again
         if (rc) return rc;
         break;
     }
@@ -799,7 +808,6 @@ int kpl_create(kpl_detector **out, int device) {
         return KPL_ERR_DEVICE;
     }
     init_dev_state(h->h_state);
-    if (const char *e = getenv("KPL_DEBUG_SCAN_POLL_LIMIT")) set_scan_poll_limit(atoi(e));      // tests: force the scan's failure path
     if (hipMemcpy(h->dstate.p, h->h_state, sizeof(DevState), hipMemcpyHostToDevice) != hipSuccess ||
         hipDeviceSynchronize() != hipSuccess) {          // (the null stream is not ordered against the handle's stream)
         kpl_destroy(h);
@@ -850,6 +858,12 @@ int kpl_set_feature_walk(kpl_detector *h, int walk, int lanes_per_point) {
         return fail(h, KPL_ERR_INVALID_ARG, "lanes_per_point must be 2 or 4");
     h->walk_forced = walk;
     h->lanes_forced = walk == KPL_WALK_AUTO ? 0 : lanes_per_point;
+    return KPL_OK;
+}
+
+int kpl_debug_set_scan_poll_limit(kpl_detector *h, int polls) {
+    if (!h) return KPL_ERR_INVALID_ARG;
+    h->scan_poll_limit = polls;
     return KPL_OK;
 }
 

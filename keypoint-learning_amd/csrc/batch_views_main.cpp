@@ -185,7 +185,13 @@ int prepare(Worker &w, const Options &o) {
 int score(Worker &w, bool first) {
     CHECK_HIP(hipSetDevice(w.device));
     const int nv = (int)w.views.size();
-    for (int attempt = 0; attempt < 3; ++attempt) {          // (first round: the cell tables and, in sorted-search mode, the key array may each grow once)
+    // first round: checked until TWO rounds in a row came back clean.  A handle grows what a view needs when it first sees
+    // it -- the cell tables, in sorted-search mode the key array (its need can rise once more: the chunk tails of the wave
+    // kernel are counted like keys and depend on the order the waves ran in) -- and after its first clean round it knows the
+    // neighborhood size of the view and may switch to the two-pass walk, whose word list then grows once too: none of this
+    // may happen in the timed rounds, which are not read back
+    int clean = 0;
+    for (int attempt = 0; attempt < 10 && clean < (first ? 2 : 1); ++attempt) {
         for (int b0 = 0, bi = 0; b0 < nv; b0 += 8, ++bi) {
             const int cnt = std::min(8, nv - b0);
             kpl_detector *hs[8];
@@ -202,14 +208,15 @@ int score(Worker &w, bool first) {
             CHECK_KPL(hs[0], kpl_compute_batch_keypoints_device(hs, cnt, kps, kscores, caps, counts, w.st[bi & 1]));
         }
         if (!first) break;
-        bool retry = false;                                            // first round only: cell tables may have to grow once
+        bool retry = false;
         for (int k = 0; k < nv; ++k) {
             const int rc = kpl_sync_status(w.views[(size_t)k]->h, w.st[(k / 8) & 1]);
-            if (rc == KPL_ERR_RETRY && attempt < 2) retry = true;
+            if (rc == KPL_ERR_RETRY) retry = true;
             else if (rc != KPL_OK) { fprintf(stderr, "%s: %s\n", w.views[(size_t)k]->path.c_str(), kpl_last_error(w.views[(size_t)k]->h)); return 1; }
         }
-        if (!retry) break;
+        clean = retry ? 0 : clean + 1;
     }
+    if (first && clean < 2) { fprintf(stderr, "device %d: the views keep asking for larger tables (10 rounds)\n", w.device); return 1; }
     CHECK_HIP(hipStreamSynchronize(w.st[1]));                          // the gather is enqueued behind stream 0: wait for the other one
     return 0;
 }
@@ -218,8 +225,16 @@ int score(Worker &w, bool first) {
 int score_and_gather(Worker &w, bool first, Rendezvous &rv) {
     const int rc = score(w, first);
     if (!rv.agree(rc == 0)) return rc ? rc : 1;                        // some device failed: nobody enters the collective
-    CHECK_NCCL(ncclAllGather(w.d_send, w.d_recv, slot_ints(w.cap) * (size_t)w.slots, ncclInt32, w.comm, w.st[0]));
-    CHECK_HIP(hipStreamSynchronize(w.st[0]));
+    // ... and every thread learns how the collective went on EVERY device before anyone goes on to the next round: a thread
+    // whose ncclAllGather or stream wait failed would leave the loop, and the others would wait forever in the next
+    // round's agree() for a party that never arrives
+    bool ok = ncclAllGather(w.d_send, w.d_recv, slot_ints(w.cap) * (size_t)w.slots, ncclInt32, w.comm, w.st[0]) == ncclSuccess;
+    if (!ok) fprintf(stderr, "device %d: ncclAllGather failed\n", w.device);
+    if (ok && hipStreamSynchronize(w.st[0]) != hipSuccess) {
+        fprintf(stderr, "device %d: the gather's stream failed\n", w.device);
+        ok = false;
+    }
+    if (!rv.agree(ok)) return 1;
     return 0;
 }
 
@@ -299,7 +314,8 @@ int main(int argc, char **argv) {
     if (o.rounds > 1) {
         auto timed = [&](Worker &w) {
             const auto t0 = std::chrono::steady_clock::now();
-            // (a failed round fails on every device -- score_and_gather agrees first --, so all threads leave the loop together)
+            // (a failed round fails on every device -- score_and_gather agrees before AND after the collective --, so all
+            // threads leave the loop together)
             for (int r = 0; r < o.rounds && !w.rc; ++r) w.rc = score_and_gather(w, false, rv);
             w.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         };

@@ -50,6 +50,8 @@ struct NmsDesc {
     int non_maxima;
     int draws_remove;     // non_maxima_draws_remove_
     float draws_thr;      // non_maxima_draws_threshold_
+    int scan_poll_limit;  // look-back polls of the compaction's single-pass scan before the call is failed (2^22; < 0: every block
+                          // but the first gives up at once -- the failure path, forced by tests through kpl_debug_set_scan_poll_limit)
 };
 
 // candidates of the NMS stage: storage positions of the points whose score passed the threshold,
@@ -161,9 +163,6 @@ struct DevState {
     alignas(128) unsigned long long word_cursor[32];
 };
 void init_dev_state(DevState *host_copy);
-// look-back polls of the compaction's single-pass scan before the call is failed (default 2^22; < 0: every block but the
-// first gives up at once -- the failure path, forced by tests through KPL_DEBUG_SCAN_POLL_LIMIT)
-void set_scan_poll_limit(int polls);
 
 // ---- the three stages of compute(), each over every view of the batch ------------------------
 // index build ("initCompute"): needs the input + index fields of ViewDev

@@ -4302,8 +4302,9 @@ __device__ __forceinline__ void scan_publish(unsigned long long *word, unsigned 
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ __launch_bounds__(kScanBlock) void compact_scan_kernel(Batch b, int poll_limit) {
+__global__ __launch_bounds__(kScanBlock) void compact_scan_kernel(Batch b) {
     const ViewDev &v = b.view[blockIdx.y];
+    const int poll_limit = v.nd.scan_poll_limit;       // (of the view's handle: kpl_debug_set_scan_poll_limit)
     const int n = v.n, kp_cap = v.kp_cap;
     const int nb = n > 0 ? (n + kScanChunk - 1) / kScanChunk : 1;      // blocks of this view (block 0 exists for an empty view too)
     if ((int)blockIdx.x >= nb) return;
@@ -4441,11 +4442,7 @@ __global__ __launch_bounds__(256) void list_match_kernel(Batch b, int match) {
 
 inline int div_up(int a, int b) { return (a + b - 1) / b; }
 
-int g_scan_poll_limit = 1 << 22;       // look-back polls of compact_scan_kernel before the call is failed (set_scan_poll_limit)
-
 }  // namespace
-
-void set_scan_poll_limit(int polls) { g_scan_poll_limit = polls; }
 
 // =============================================================================================
 // launch wrappers
@@ -4810,7 +4807,7 @@ void launch_post(const Batch &b, hipStream_t st) {
                                 sizeof(uint32_t) * (size_t)lds_words + sizeof(int) * (size_t)kRestWaves * kWave * kDrawAdj, st>>>(b, lds_words);
         }
     }
-    compact_scan_kernel<<<dim3(n > 0 ? div_up(n, kScanChunk) : 1, nv), kScanBlock, 0, st>>>(b, g_scan_poll_limit);
+    compact_scan_kernel<<<dim3(n > 0 ? div_up(n, kScanChunk) : 1, nv), kScanBlock, 0, st>>>(b);
 }
 
 size_t scan_state_bytes(int n) { return sizeof(unsigned long long) * ((size_t)(n > 0 ? n : 1) / kScanChunk + 2); }

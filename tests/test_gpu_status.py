@@ -28,17 +28,17 @@ def make():
     helpers.load_arrays(det, fa)
     det.setInputCloud(xyz); det.setNormals(nrm)
     return det
-os.environ["KPL_DEBUG_SCAN_POLL_LIMIT"] = "-1"          # read by kpl_create: every block but the first gives up at once
 bad = make()
+bad._lib.kpl_debug_set_scan_poll_limit(bad._h, -1)      # this handle only: every block of the scan but the first gives up at once
 try:
     bad.compute()
     print("NO ERROR")
 except kpl.KplError as e:
     print("status", e.status, "internal" if e.status == kpl.ERR_INTERNAL else "other", "|", e)
-os.environ["KPL_DEBUG_SCAN_POLL_LIMIT"] = str(1 << 22)  # the next kpl_create restores the limit (it is per process)
-good = make()
+good = make()                                           # (another handle of the same process is not affected)
 _, s1 = good.compute()
 k1 = good.getKeypointsIndices().copy()
+bad._lib.kpl_debug_set_scan_poll_limit(bad._h, 1 << 22)
 _, s2 = bad.compute()                                   # the handle that failed works again: the flag was cleared
 k2 = bad.getKeypointsIndices().copy()
 print("recovered", bool(np.array_equal(k1, k2) and helpers.same_bits(s1, s2)), len(k1))
@@ -47,7 +47,7 @@ print("recovered", bool(np.array_equal(k1, k2) and helpers.same_bits(s1, s2)), l
 
 def test_scan_look_back_timeout_is_an_error_not_a_count():
     """compact_scan_kernel's look-back gives up -> KPL_ERR_INTERNAL from the host entry point (kernels.hip; forced through
-    KPL_DEBUG_SCAN_POLL_LIMIT in a child process, the limit is per process), and the handle recovers."""
+    kpl_debug_set_scan_poll_limit on that handle, in a child process), and the handle recovers."""
     out = subprocess.run([sys.executable, "-c", _FORCED_TIMEOUT % {"root": ROOT}], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = out.stdout.strip().splitlines()
@@ -62,6 +62,7 @@ def test_device_entry_point_reports_the_timeout_through_sync_status(kpl):
     code = _FORCED_TIMEOUT.split("bad = make()")[0] + r"""
 import torch
 det = make()
+det._lib.kpl_debug_set_scan_poll_limit(det._h, -1)
 dev = torch.device("cuda", 0)
 dx, dn = torch.from_numpy(np.ascontiguousarray(xyz)).to(dev), torch.from_numpy(np.ascontiguousarray(nrm)).to(dev)
 dk = torch.zeros(len(xyz) + 1, dtype=torch.int32, device=dev)
@@ -77,7 +78,7 @@ try:
     det.syncStatus(None)
     print("again ok")
 except kpl.KplError as e:
-    print("again", e.status)          # the limit is still -1 in this process: fails again, never hangs
+    print("again", e.status)          # the limit of this handle is still -1: fails again, never hangs
 """
     out = subprocess.run([sys.executable, "-c", code % {"root": ROOT}], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]

@@ -96,3 +96,84 @@ def test_the_automatic_walk_follows_what_the_handle_measured(kpl, cases, gold):
     det.compute()
     walk, lanes, kf = det.getFeatureWalk()
     assert walk == kpl.WALK_LANES and lanes == 2 and 20 < kf < 400, (walk, lanes, kf)
+
+
+def test_two_pass_word_list_grows_through_retry(kpl, oracle, cases):
+    """a random volume, ~7 500 neighbors and ~30 000 candidates per point -- about 1 000 accept words per point where a
+    fresh handle reserves ~500: the device entry point cannot grow the list itself, the first call reports KPL_ERR_RETRY
+    through kpl_sync_status (count -1), the second one has room; non-finite points and normals mixed in; then the same view
+    through the host entry point on a fresh handle, which retries by itself"""
+    import torch
+    from tools import synth
+    rng = np.random.default_rng(5)
+    xyz = rng.uniform(0, 1, size=(60000, 3)).astype(np.float32)
+    nrm = rng.normal(size=(60000, 3)).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    xyz[::997] = np.nan
+    nrm[5::811] = np.nan
+    A, B, r = 3, 4, 0.36
+    fa = synth.random_forest(A * B, ntrees=6, max_depth=8, seed=12, target_nodes_per_tree=120)
+    o_scores, _ = oracle.detect(xyz, nrm, A, B, r, 0.0, 0.0, cases.oracle_forest(fa), non_maxima=False, threads=cases.usable_cores())
+
+    def make():
+        det = kpl.KeypointLearningDetector()
+        det.setNAnnulus(A); det.setNBins(B); det.setNonMaxima(False); det.setNonMaxRadius(0.0)
+        det.setPredictionThreshold(0.0); det.setRadiusSearch(r)
+        cases.load_arrays(det, fa)
+        det.setFeatureWalk(kpl.WALK_TWO_PASS, 4)
+        return det
+    det = make()
+    dev = torch.device("cuda", 0)
+    dx, dn = torch.from_numpy(xyz).to(dev), torch.from_numpy(nrm).to(dev)
+    ds = torch.empty(len(xyz), dtype=torch.float32, device=dev)
+    dk = torch.zeros(len(xyz) + 1, dtype=torch.int32, device=dev)
+    det.bindCloudDevice(dx.data_ptr(), 12, dn.data_ptr(), 12, len(xyz))
+    det.computeDevice(ds.data_ptr(), dk[1:].data_ptr(), len(xyz), dk[0:1].data_ptr())
+    assert det.syncStatus(None) == kpl.ERR_RETRY and int(dk[0].item()) == -1
+    assert "accept words" in det.lastError()
+    det.computeDevice(ds.data_ptr(), dk[1:].data_ptr(), len(xyz), dk[0:1].data_ptr())
+    assert det.syncStatus(None) == kpl.OK
+    assert cases.same_bits(ds.cpu().numpy(), o_scores)
+    det2 = make()
+    det2.setInputCloud(xyz)
+    det2.setNormals(nrm)
+    _, scores = det2.compute()
+    assert cases.same_bits(scores, o_scores)
+
+
+def test_batch_mixes_the_walks(kpl, oracle, cases):
+    """one kpl_compute_batch_device call over views that take different walks (forced): every kernel of the stage skips the
+    views of the others; each view's scores and keypoints are the oracle's"""
+    import torch
+    A, B = 5, 6
+    xyz, nrm = cases.cloud()
+    mr = cases.resolution()
+    fa = cases.trained_forest(A, B)
+    of = cases.oracle_forest(fa)
+    dev = torch.device("cuda", 0)
+    modes = [(kpl.WALK_LANES, 2, 6.0), (kpl.WALK_TWO_PASS, 4, 12.0), (kpl.WALK_LANES, 4, 8.0), (kpl.WALK_TWO_PASS, 2, 6.0)]
+    dets, bufs, want = [], [], []
+    for walk, lanes, rmul in modes:
+        r, rn, thr = float(np.float32(rmul * mr)), float(np.float32(4 * mr)), float(np.float32(0.6))
+        det = kpl.KeypointLearningDetector()
+        det.setNAnnulus(A); det.setNBins(B); det.setNonMaxima(True); det.setNonMaxRadius(rn)
+        det.setNonMaximaDrawsRemove(False); det.setPredictionThreshold(thr); det.setRadiusSearch(r)
+        cases.load_arrays(det, fa)
+        det.setFeatureWalk(walk, lanes)
+        dx, dn = torch.from_numpy(np.array(xyz)).to(dev), torch.from_numpy(np.array(nrm)).to(dev)
+        ds = torch.empty(len(xyz), dtype=torch.float32, device=dev)
+        dk = torch.zeros(len(xyz) + 1, dtype=torch.int32, device=dev)
+        det.bindCloudDevice(dx.data_ptr(), 12, dn.data_ptr(), 12, len(xyz))
+        dets.append(det); bufs.append((dx, dn, ds, dk))
+        want.append(oracle.detect(xyz, nrm, A, B, r, rn, thr, of))
+    for attempt in range(3):
+        kpl.compute_batch_device(dets, [b[2].data_ptr() for b in bufs], [b[3][1:].data_ptr() for b in bufs],
+                                 [len(xyz)] * len(dets), [b[3][0:1].data_ptr() for b in bufs], None)
+        torch.cuda.synchronize()
+        rcs = [d.syncStatus(None) for d in dets]
+        if kpl.ERR_RETRY not in rcs:
+            break
+    assert all(rc == kpl.OK for rc in rcs), rcs
+    for (dx, dn, ds, dk), (o_sc, o_kp) in zip(bufs, want):
+        assert cases.same_bits(ds.cpu().numpy(), o_sc)
+        assert np.array_equal(dk[1:1 + int(dk[0].item())].cpu().numpy(), o_kp)

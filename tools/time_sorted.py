@@ -43,20 +43,27 @@ def main():
     torch.cuda.synchronize()
     st = torch.cuda.Stream()
     run = lambda: kpl.compute_batch_device(dets, ps, pk, [n] * nb, pc, st.cuda_stream)
-    for _ in range(3):
+    # the cell tables and the key array of the large path grow on the first calls (KPL_ERR_RETRY): EVERY detector is synced
+    # after every run (no short circuit) until all of them report OK -- a timed run of a handle that is still growing would
+    # measure failing calls
+    for attempt in range(8):
         run()
         torch.cuda.synchronize()
-        try:
-            for d in dets:
-                d.syncStatus(None)
-        except kpl.KplError as e:              # (the key array of the large path grows on the first call: KPL_ERR_RETRY)
-            if e.status != kpl.ERR_RETRY:
-                raise
+        rcs = [d.syncStatus(None) for d in dets]      # (raises on anything but OK / RETRY)
+        if kpl.ERR_RETRY not in rcs:
+            break
+    else:
+        raise SystemExit("still growing after 8 attempts: %s" % rcs)
+    run()
+    torch.cuda.synchronize()
+    assert all(d.syncStatus(None) == kpl.OK for d in dets)
     dets[0].enableTiming(True)
     for _ in range(20):
         run()
     torch.cuda.synchronize()
     t = dets[0].getTiming()
+    assert all(d.syncStatus(None) == kpl.OK for d in dets), "a timed run failed on the device"
+    assert all(int(k[4].item()) >= 0 for k in keep)
     calls = max(t["calls"], 1)
     print(json.dumps({"lib": os.environ.get("KPL_LIB_PATH", "libkpl.so"), "sorted": srt, "rmul": rmul, "feature_ms": round(t["feature_ms"] / calls, 4),
                       "forest_ms": round(t["forest_ms"] / calls, 4), "keypoints": int(sum(int(k[4].item()) for k in keep))}))
