@@ -31,20 +31,51 @@ namespace {
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    bool pooled = false;          // allocated by hipMallocAsync (freed in stream order), else by hipMalloc
+    // Grow-only scratch; the content is not kept.  Without a stream: hipFree + hipMalloc -- hipFree waits for EVERY stream of
+    // the device (entry points that block anyway: host-buffer calls, set-up).
     hipError_t ensure(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
+        release();
         size_t want = bytes + bytes / 4 + 256;
         hipError_t e = hipMalloc(&p, want);
         if (e == hipSuccess) cap = want;
         return e;
     }
+    // With the stream the next kernels are launched on: the new array is allocated -- and cleared, if asked -- IN THE ORDER OF
+    // THAT STREAM (hipMallocAsync, hipMemsetAsync), the old one is freed in that order too (hipFreeAsync: after the kernels of
+    // earlier calls that still use it).  Nothing waits on the host, no other stream or handle of the process is held up; an
+    // array that came from hipMalloc is parked and freed with the handle.
+    hipError_t ensure(size_t bytes, hipStream_t st, std::vector<void *> &parked, bool zero = false) {
+        if (bytes <= cap) return hipSuccess;
+        const size_t want = bytes + bytes / 4 + 256;
+        void *np = nullptr;
+        hipError_t e = hipMallocAsync(&np, want, st);
+        if (e != hipSuccess) return e;
+        if (zero) {
+            e = hipMemsetAsync(np, 0, want, st);
+            if (e != hipSuccess) {
+                (void)hipFreeAsync(np, st);
+                return e;
+            }
+        }
+        if (p) {
+            if (pooled) (void)hipFreeAsync(p, st);
+            else parked.push_back(p);
+        }
+        p = np;
+        cap = want;
+        pooled = true;
+        return hipSuccess;
+    }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) {
+            if (pooled) (void)hipFreeAsync(p, nullptr);
+            else (void)hipFree(p);
+        }
         p = nullptr;
         cap = 0;
+        pooled = false;
     }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
@@ -101,6 +132,7 @@ struct kpl_detector {
     size_t pending_nrm_bytes = 0;
     hipEvent_t ev_xyz = nullptr, ev_nrm = nullptr;
     DevBuf out_kp_score;
+    std::vector<void *> parked;   // hipMalloc'ed arrays that stream-ordered growth replaced: freed with the handle
     void *h_res = nullptr;        // pinned landing zone of the keypoint lists (host-buffer entry points)
     size_t h_res_cap = 0;
 
@@ -254,7 +286,10 @@ int install_forest(kpl_detector *h, ForestModel &&m) {
         nodes.release();
         return fail(h, KPL_ERR_DEVICE, "forest upload failed: %s", hipGetErrorString(e));
     }
-    KPL_HIP(h, hipDeviceSynchronize());     // no kernel of an earlier call still walks the old nodes
+    // REPLACING a forest is the one place left that waits for the whole device: no kernel of an earlier call may still walk
+    // the old nodes, and the loaders have no stream to order the release in (a set-up call; the first forest of a handle
+    // replaces nothing and waits for nothing)
+    if (h->d_nodes.p) KPL_HIP(h, hipDeviceSynchronize());
     h->d_nodes.release();
     h->d_nodes = nodes;
     h->model = std::move(m);
@@ -263,20 +298,16 @@ int install_forest(kpl_detector *h, ForestModel &&m) {
     return KPL_OK;
 }
 
-// (re)allocates the cell table for `cap` cells
-int ensure_cells(kpl_detector *h, int64_t cap) {
+// (re)allocates the cell table for `cap` cells, cleared, in the order of `st` (the stream the index kernels that read it are
+// launched on next).  Rounds 3 and 4 cleared it with hipMemset on the null stream, which returns BEFORE the clear is done and
+// is not ordered against a non-blocking stream: cell_sort_store_kernel wrote cell_start[] while the clear was still passing
+// over it and lost its writes (every score NaN, status OK: tools/repro_table_growth.py, profiles/r04_notes.md section 1).
+// Round 4 fenced that with hipDeviceSynchronize on both sides -- correct, but a barrier for every stream of the process.  A
+// clear ON the launch stream is ordered by the stream itself, and so is the release of the old table (DevBuf::ensure).
+int ensure_cells(kpl_detector *h, int64_t cap, hipStream_t st) {
     if (cap <= h->cells_cap) return KPL_OK;
     if (cap > kMaxGridCells) cap = kMaxGridCells;
-    KPL_HIP(h, hipDeviceSynchronize());
-    KPL_HIP(h, h->cell_start.ensure(sizeof(int) * ((size_t)cap + 2)));
-    KPL_HIP(h, hipMemset(h->cell_start.p, 0, sizeof(int) * ((size_t)cap + 2)));
-    // hipMemset returns BEFORE the clear is done (tests/csrc/memset_probe.cpp: 285 us whatever the size) and the null stream it
-    // runs on is not ordered against the handle's non-blocking stream: without this wait cell_sort_store_kernel of the call
-    // that follows wrote cell_start[] while the clear was still passing over it and lost its writes -- every point "outside
-    // the grid", every score NaN, no keypoint, status OK.  It took a 1 GB table (a view that needs ~2^28 cells) that no other
-    // reallocation of the same call happened to synchronise: the one fuzz event of round 3 and two of round 4
-    // (tools/repro_table_growth.py reproduces it in 7 of 20 tries on the old code; profiles/r04_notes.md section 1).
-    KPL_HIP(h, hipDeviceSynchronize());
+    KPL_HIP(h, h->cell_start.ensure(sizeof(int) * ((size_t)cap + 2), st, h->parked, true));
     h->cells_cap = (int)cap;
     return KPL_OK;
 }
@@ -285,7 +316,7 @@ int ensure_cells(kpl_detector *h, int64_t cap) {
 // -> cell ids + counts -> scan -> scatter -> rank/store.  The host does not learn the grid size;
 // a view whose grid does not fit the current cell tables sets DevState::status (kpl_sync_status).
 // prepare_index checks, allocates and fills the index half of the view descriptor.
-int prepare_index(kpl_detector *h, bool auto_cell, ViewDev &v, double cell = 0.0) {
+int prepare_index(kpl_detector *h, bool auto_cell, ViewDev &v, hipStream_t st, double cell = 0.0) {
     int rc = (auto_cell || cell > 0.0) ? KPL_OK : check_params_for_compute(h, false);
     if (rc) return rc;
     if (!h->bound) return fail(h, KPL_ERR_NO_CLOUD, "no cloud bound");
@@ -295,17 +326,17 @@ int prepare_index(kpl_detector *h, bool auto_cell, ViewDev &v, double cell = 0.0
     const int n = h->n;
     const size_t nn = (size_t)(n > 0 ? n : 1);
     if (h->cells_cap == 0) {
-        rc = ensure_cells(h, (int64_t)8 * n + 65536);
+        rc = ensure_cells(h, (int64_t)8 * n + 65536, st);
         if (rc) return rc;
     }
-    KPL_HIP(h, h->cid.ensure(sizeof(int) * nn));
-    KPL_HIP(h, h->tmp_idx.ensure(2 * sizeof(float4) * nn));
-    KPL_HIP(h, h->btable.ensure(sizeof(int) * btable_ints(n)));
+    KPL_HIP(h, h->cid.ensure(sizeof(int) * nn, st, h->parked));
+    KPL_HIP(h, h->tmp_idx.ensure(2 * sizeof(float4) * nn, st, h->parked));
+    KPL_HIP(h, h->btable.ensure(sizeof(int) * btable_ints(n), st, h->parked));
     const size_t scan_len = (size_t)(h->cells_cap > n ? h->cells_cap : n) + 1;
-    KPL_HIP(h, h->scan_tmp.ensure(sizeof(int) * (scan_len / 4096 + 4)));
-    KPL_HIP(h, h->pts.ensure(pts_bytes(n)));            // incl. the tail the search steps read past the last point
-    KPL_HIP(h, h->nrm.ensure(sizeof(float4) * nn));
-    KPL_HIP(h, h->pos_of.ensure(sizeof(int) * nn));
+    KPL_HIP(h, h->scan_tmp.ensure(sizeof(int) * (scan_len / 4096 + 4), st, h->parked));
+    KPL_HIP(h, h->pts.ensure(pts_bytes(n), st, h->parked));            // incl. the tail the search steps read past the last point
+    KPL_HIP(h, h->nrm.ensure(sizeof(float4) * nn, st, h->parked));
+    KPL_HIP(h, h->pos_of.ensure(sizeof(int) * nn, st, h->parked));
     v.xyz = h->d_xyz;
     v.nrmsrc = h->d_nrm;
     v.xs = (unsigned)h->xs;
@@ -341,7 +372,7 @@ void index_was_built(kpl_detector *h, bool auto_cell, bool with_pos_of = true) {
 int build_index(kpl_detector *h, hipStream_t st, bool auto_cell = false) {
     Batch b{};
     b.nviews = 1;
-    int rc = prepare_index(h, auto_cell, b.view[0]);
+    int rc = prepare_index(h, auto_cell, b.view[0], st);
     if (rc) return rc;
     const size_t ev0 = mark(h, st);
     launch_index(b, st);
@@ -357,7 +388,7 @@ int ensure_index(kpl_detector *h, hipStream_t st) {
     if (!h->pos_of_valid) {
         Batch b{};
         b.nviews = 1;
-        int rc = prepare_index(h, false, b.view[0]);
+        int rc = prepare_index(h, false, b.view[0], st);
         if (rc) return rc;
         launch_pos_of(b, st);
         KPL_HIP(h, hipGetLastError());
@@ -402,14 +433,13 @@ int sync_status(kpl_detector *h, hipStream_t st) {
         if (need > 0xfffffff0ull)
             return fail(h, KPL_ERR_CAPACITY, "%llu neighbor keys / accept words in one view (limit 2^32)", need);
         h->index_valid = false;
-        KPL_HIP(h, hipDeviceSynchronize());
-        KPL_HIP(h, h->sort_keys.ensure(sizeof(unsigned long long) * (size_t)(need + need / 16 + 4096)));
+        KPL_HIP(h, h->sort_keys.ensure(sizeof(unsigned long long) * (size_t)(need + need / 16 + 4096), st, h->parked));
         return fail(h, KPL_ERR_RETRY, "the view needs room for %llu neighbor keys / accept words: array grown, call again", need);
     }
     if (h->h_state->status == kStatusCellCapacity) {
         const int64_t need = h->h_state->ncells_needed;
         h->index_valid = false;
-        int rc = ensure_cells(h, need + need / 4 + 1024);
+        int rc = ensure_cells(h, need + need / 4 + 1024, st);
         if (rc) return rc;
         return fail(h, KPL_ERR_RETRY, "grid needs %lld cells: tables grown, call again", (long long)need);
     }
@@ -418,7 +448,7 @@ int sync_status(kpl_detector *h, hipStream_t st) {
 
 // checks, scratch and the scoring / NMS half of the view descriptor (detectKeypoints)
 int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, int *d_kp_count,
-                   StatsDev *d_stats, ViewDev &v) {
+                   StatsDev *d_stats, ViewDev &v, hipStream_t st) {
     int rc = check_params_for_compute(h, true);
     if (rc) return rc;
     if (!h->bound) return fail(h, KPL_ERR_NO_CLOUD, "no cloud bound");
@@ -428,35 +458,21 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
     if (rc) return rc;
     const int n = h->n;
     const size_t nn = (size_t)(n > 0 ? n : 1);
-    KPL_HIP(h, h->score_sorted.ensure(sizeof(float) * nn));
-    KPL_HIP(h, h->feat.ensure(feat_bytes(n, h->prm.n_annulus * h->prm.n_bins)));
-    if (h->flags.cap < sizeof(int) * (nn + 1) || !h->cand_count.p) {
-        KPL_HIP(h, hipDeviceSynchronize());
-        KPL_HIP(h, h->flags.ensure(sizeof(int) * (nn + 1)));
-        KPL_HIP(h, h->cand_count.ensure(sizeof(int)));
-        KPL_HIP(h, hipMemset(h->flags.p, 0, h->flags.cap));       // kept zero by compact_kernel from here on
-        KPL_HIP(h, hipMemset(h->cand_count.p, 0, sizeof(int)));
-        KPL_HIP(h, hipDeviceSynchronize());                      // (a null-stream clear is not ordered against the kernels' stream: ensure_cells)
-    }
-    KPL_HIP(h, h->cand_list.ensure(sizeof(int) * nn));
-    KPL_HIP(h, h->prefix.ensure(sizeof(int) * (nn + 2)));
-    if (h->scan_state.cap < scan_state_bytes(n)) {
-        KPL_HIP(h, hipDeviceSynchronize());
-        KPL_HIP(h, h->scan_state.ensure(scan_state_bytes(n)));
-        KPL_HIP(h, hipMemset(h->scan_state.p, 0, h->scan_state.cap));     // tag 0 = "never written"
-        KPL_HIP(h, hipDeviceSynchronize());
-    }
+    // every array in the order of the launch stream; the ones the kernels expect zeroed are cleared in that order too
+    // (flags / cand.count / skip are kept zero by the compaction from then on; scan_state: tag 0 = "never written")
+    KPL_HIP(h, h->score_sorted.ensure(sizeof(float) * nn, st, h->parked));
+    KPL_HIP(h, h->feat.ensure(feat_bytes(n, h->prm.n_annulus * h->prm.n_bins), st, h->parked));
+    KPL_HIP(h, h->flags.ensure(sizeof(int) * (nn + 1), st, h->parked, true));
+    KPL_HIP(h, h->cand_count.ensure(sizeof(int), st, h->parked, true));
+    KPL_HIP(h, h->cand_list.ensure(sizeof(int) * nn, st, h->parked));
+    KPL_HIP(h, h->prefix.ensure(sizeof(int) * (nn + 2), st, h->parked));
+    KPL_HIP(h, h->scan_state.ensure(scan_state_bytes(n), st, h->parked, true));
     NmsDesc nd = make_nms(h->prm);
     nd.scan_poll_limit = h->scan_poll_limit;
     if (nd.draws_remove) {
-        if (h->skip.cap < sizeof(int) * nn) {
-            KPL_HIP(h, hipDeviceSynchronize());
-            KPL_HIP(h, h->skip.ensure(sizeof(int) * nn));
-            KPL_HIP(h, hipMemset(h->skip.p, 0, h->skip.cap));             // kept zero by compact_kernel
-            KPL_HIP(h, hipDeviceSynchronize());
-        }
-        KPL_HIP(h, h->draw_list.ensure(sizeof(int) * (nn * (2 + kDrawAdj) + 8)));     // list, adjacency counts, adjacency (kernels.hip draw_adj_offset)
-        KPL_HIP(h, h->draw_count.ensure(sizeof(int)));
+        KPL_HIP(h, h->skip.ensure(sizeof(int) * nn, st, h->parked, true));
+        KPL_HIP(h, h->draw_list.ensure(sizeof(int) * (nn * (2 + kDrawAdj) + 8), st, h->parked));     // list, adjacency counts, adjacency (kernels.hip draw_adj_offset)
+        KPL_HIP(h, h->draw_count.ensure(sizeof(int), st, h->parked));
     }
     v.large_list = nullptr;
     v.sort_keys = nullptr;
@@ -472,9 +488,9 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
         // its first call with KPL_ERR_RETRY and finds the array grown (sync_status)
         const double per_point = (h->kf_hint > 0.0 ? h->kf_hint : 1000.0) * 0.3 + 96.0;
         const size_t want = sizeof(unsigned long long) * (size_t)((double)nn * per_point);
-        KPL_HIP(h, h->seg_start.ensure(sizeof(unsigned) * nn));
-        KPL_HIP(h, h->seg_len.ensure(sizeof(int) * nn));
-        if (h->sort_keys.cap < want) KPL_HIP(h, h->sort_keys.ensure(want));
+        KPL_HIP(h, h->seg_start.ensure(sizeof(unsigned) * nn, st, h->parked));
+        KPL_HIP(h, h->seg_len.ensure(sizeof(int) * nn, st, h->parked));
+        if (h->sort_keys.cap < want) KPL_HIP(h, h->sort_keys.ensure(want, st, h->parked));
         v.sort_keys = h->sort_keys.as<unsigned long long>();
         v.seg_start = h->seg_start.as<unsigned>();
         v.seg_len = h->seg_len.as<int>();
@@ -484,10 +500,10 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
     if (h->prm.neighbor_order == KPL_NEIGHBORS_SORTED) {
         // segments of sorted neighbor keys for the points with large neighborhoods: 64 keys per point to begin with; a
         // view that needs more fails its first call with KPL_ERR_RETRY and finds the array grown (sync_status)
-        KPL_HIP(h, h->large_list.ensure(sizeof(int) * 2 * nn));         // all large points + the ones for the workgroup kernel
-        KPL_HIP(h, h->seg_start.ensure(sizeof(unsigned) * nn));
-        KPL_HIP(h, h->seg_len.ensure(sizeof(int) * nn));
-        if (h->sort_keys.cap < sizeof(unsigned long long) * 64 * nn) KPL_HIP(h, h->sort_keys.ensure(sizeof(unsigned long long) * 64 * nn));
+        KPL_HIP(h, h->large_list.ensure(sizeof(int) * 2 * nn, st, h->parked));         // all large points + the ones for the workgroup kernel
+        KPL_HIP(h, h->seg_start.ensure(sizeof(unsigned) * nn, st, h->parked));
+        KPL_HIP(h, h->seg_len.ensure(sizeof(int) * nn, st, h->parked));
+        if (h->sort_keys.cap < sizeof(unsigned long long) * 64 * nn) KPL_HIP(h, h->sort_keys.ensure(sizeof(unsigned long long) * 64 * nn, st, h->parked));
         v.large_list = h->large_list.as<int>();
         v.sort_keys = h->sort_keys.as<unsigned long long>();
         v.seg_start = h->seg_start.as<unsigned>();
@@ -530,9 +546,9 @@ int run_batch(kpl_detector *const *handles, int count, float *const *d_scores, i
     for (int k = 0; k < count; ++k) {
         kpl_detector *h = handles[k];
         int rc = check_params_for_compute(h, true);
-        if (!rc) rc = prepare_index(h, false, all.view[k]);      // allocates the view's tables ...
+        if (!rc) rc = prepare_index(h, false, all.view[k], st);  // allocates the view's tables ...
         if (!rc) rc = prepare_detect(h, d_scores ? d_scores[k] : nullptr, d_kp_idx[k], kp_caps[k], d_kp_counts[k],
-                                     d_stats, all.view[k]);      // ... and its scratch
+                                     d_stats, all.view[k], st);  // ... and its scratch
         if (rc) {
             if (h != h0) fail(h0, rc, "view %d: %s", k, kpl_last_error(h));
             return rc;
@@ -600,7 +616,7 @@ int normals_on_device(kpl_detector *h, int k, double radius, const float *viewpo
     static const float origin[3] = {0.0f, 0.0f, 0.0f};
     Batch b{};
     b.nviews = 1;
-    int rc = prepare_index(h, k > 0, b.view[0], k > 0 ? 0.0 : radius);
+    int rc = prepare_index(h, k > 0, b.view[0], st, k > 0 ? 0.0 : radius);
     if (rc) return rc;
     launch_index(b, st);
     const ViewDev &v = b.view[0];
@@ -827,6 +843,7 @@ void kpl_destroy(kpl_detector *h) {
                       &h->draw_list, &h->draw_count, &h->skip, &h->feat, &h->scan_state,
                       &h->large_list, &h->seg_start, &h->seg_len, &h->sort_keys};
     for (DevBuf *b : bufs) b->release();
+    for (void *q : h->parked) (void)hipFree(q);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->h_state) (void)hipHostFree(h->h_state);
     if (h->h_count) (void)hipHostFree(h->h_count);
@@ -1058,10 +1075,8 @@ int kpl_compute_batch_keypoints_device(kpl_detector *const *handles, int count, 
         if (h->device != h0->device) return fail(h0, KPL_ERR_INVALID_ARG, "all views of a batch must live on one device");
         for (int j = 0; j < k; ++j)
             if (handles[j] == h) return fail(h0, KPL_ERR_INVALID_ARG, "a handle appears twice in the batch");
-        if (h->out_scores.cap < sizeof(float) * (size_t)(h->n > 0 ? h->n : 1)) {
-            KPL_HIP(h0, hipDeviceSynchronize());         // (grow-only; an earlier call may still write the old array)
-            KPL_HIP(h0, h->out_scores.ensure(sizeof(float) * (size_t)(h->n > 0 ? h->n : 1)));
-        }
+        // (grow-only; an earlier call may still write the old array: released in the order of the stream)
+        KPL_HIP(h0, h->out_scores.ensure(sizeof(float) * (size_t)(h->n > 0 ? h->n : 1), (hipStream_t)stream, h->parked));
         scratch[k] = h->out_scores.as<float>();
     }
     return run_batch(handles, count, scratch, d_kp_idx, kp_caps, d_kp_counts, nullptr, true, (hipStream_t)stream, d_kp_scores);

@@ -174,3 +174,94 @@ def test_table_growth_is_ordered_before_the_kernels(kpl, cases):
         assert cases.same_bits(sc, o_sc), "iteration %d: %d NaN scores of %d" % (it, int(np.isnan(sc).sum()), len(sc))
         assert np.array_equal(det.getKeypointsIndices(), o_kp), it
         det.close()
+
+
+_GROWTH_NEXT_TO_LOAD = r"""
+import importlib, os, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+import torch
+from tests import helpers as cases
+from tools import synth
+from oracle import kplo
+kpl = importlib.import_module("keypoint-learning_amd")
+A, B = 5, 6
+xyz, nrm = cases.cloud(200, 150, seed=7)
+mr = cases.resolution()
+fa = cases.trained_forest(A, B)
+r, rn, thr = float(np.float32(6 * mr)), float(np.float32(4 * mr)), float(np.float32(0.6))
+dev = torch.device("cuda", 0)
+def make(x, n_):
+    det = kpl.KeypointLearningDetector()
+    det.setNAnnulus(A); det.setNBins(B); det.setNonMaxima(True); det.setNonMaxRadius(rn)
+    det.setNonMaximaDrawsRemove(False); det.setPredictionThreshold(thr); det.setRadiusSearch(r)
+    cases.load_arrays(det, fa)
+    dx, dn = torch.from_numpy(np.array(x)).to(dev), torch.from_numpy(np.array(n_)).to(dev)
+    ds = torch.empty(len(x), dtype=torch.float32, device=dev)
+    dk = torch.zeros(len(x) + 1, dtype=torch.int32, device=dev)
+    det.bindCloudDevice(dx.data_ptr(), 12, dn.data_ptr(), 12, len(x))
+    return det, (dx, dn, ds, dk)
+sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+xb, nb_ = synth.make_cloud(500, 400, seed=3)           # B: a 200 k-point view at 30 mesh resolutions (1 900 neighbors per point)
+detb, bb = make(xb, nb_)
+nbp = len(xb)
+mrb = kpl.KeypointLearningDetector().cloudResolution(xb)       # (on a handle of its own: the call leaves no view bound)
+detb.setRadiusSearch(float(np.float32(30 * mrb))); detb.setNonMaxRadius(float(np.float32(4 * mrb)))
+n = len(xyz)
+# a view for A whose grid needs far more cells than a fresh handle reserves: two far-away points stretch the bounding box
+xa = np.array(xyz)
+xa[0] = [-4000.0, -3000.0, 0.0]
+xa[1] = [4000.0, 3000.0, 50.0]
+deta, ba = make(xa, nrm)                  # (created, forest and view uploaded BEFORE B's queue is filled: set-up calls block)
+torch.cuda.synchronize()
+run_b = lambda: detb.computeDevice(bb[2].data_ptr(), bb[3][1:].data_ptr(), nbp, bb[3][0:1].data_ptr(), sb.cuda_stream)
+for _ in range(4):                        # (tables grown, neighborhood size learnt, the walk settled)
+    run_b()
+    while detb.syncStatus(sb.cuda_stream) == kpl.ERR_RETRY:
+        run_b()
+sb.synchronize()
+b_scores = bb[2].clone()
+torch.cuda.synchronize()
+for _ in range(150):                      # a call takes the GPU ~3 ms, the host 0.2 ms to enqueue: the queue runs tens of ms ahead
+    run_b()
+print("queued", not sb.query())
+# 1. A's FIRST call: every table of the handle is allocated (and some cleared) inside it
+deta.computeDevice(ba[2].data_ptr(), ba[3][1:].data_ptr(), n, ba[3][0:1].data_ptr(), sa.cuda_stream)
+print("first_call_returned_with_B_busy", not sb.query())
+sa.synchronize()
+# 2. the growth inside kpl_sync_status (the cell table of A's stretched grid), B's queue refilled
+for _ in range(150):
+    run_b()
+busy_before = not sb.query()
+rc = deta.syncStatus(sa.cuda_stream)
+print("growth", rc, busy_before, not sb.query(), deta.lastError())
+# 3. A's second call, into the grown table
+deta.computeDevice(ba[2].data_ptr(), ba[3][1:].data_ptr(), n, ba[3][0:1].data_ptr(), sa.cuda_stream)
+print("second_call_returned_with_B_busy", not sb.query())
+print("second", deta.syncStatus(sa.cuda_stream))
+torch.cuda.synchronize()
+of = cases.oracle_forest(fa)
+o_sc, o_kp = kplo.detect(xa, nrm, A, B, r, rn, thr, of)
+print("A_parity", bool(cases.same_bits(ba[2].cpu().numpy(), o_sc) and np.array_equal(ba[3][1:1 + int(ba[3][0].item())].cpu().numpy(), o_kp)))
+print("B_status", detb.syncStatus(sb.cuda_stream), bool(torch.equal(bb[2].view(torch.int32), b_scores.view(torch.int32))))
+"""
+
+
+def test_a_handle_that_grows_its_tables_does_not_hold_up_another_handles_stream():
+    """Growth is ordered by the launch stream (hipMallocAsync / hipMemsetAsync / hipFreeAsync), not by hipDeviceSynchronize:
+    while handle B has tens of milliseconds of calls queued on its stream, handle A -- on another stream -- makes its first call
+    (every table allocated, some cleared), has its cell table grown inside kpl_sync_status (KPL_ERR_RETRY) and runs again: each
+    of these RETURNS with B's stream still busy (a device-wide wait inside them would have drained it).  A's results are the
+    oracle's, B's those of B alone.  In a child process with GPU_MAX_HW_QUEUES=16: with the runtime's default of four hardware
+    queues the streams of a process share queues, and a stream that shares B's queue waits for B's kernels whatever libkpl
+    does (measured: kpl_sync_status 32 ms with four queues, 0.35 ms with sixteen)."""
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="16")
+    out = subprocess.run([sys.executable, "-c", _GROWTH_NEXT_TO_LOAD % {"root": ROOT}], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    got = dict(ln.split(" ", 1) for ln in out.stdout.strip().splitlines() if " " in ln)
+    assert got["queued"] == "True", out.stdout
+    assert got["first_call_returned_with_B_busy"] == "True", out.stdout
+    rc, before, after, msg = got["growth"].split(" ", 3)
+    assert int(rc) == 11 and before == "True" and after == "True" and "cells" in msg, out.stdout      # KPL_ERR_RETRY, B busy throughout
+    assert got["second_call_returned_with_B_busy"] == "True" and got["second"] == "0", out.stdout
+    assert got["A_parity"] == "True" and got["B_status"] == "0 True", out.stdout

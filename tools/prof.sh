@@ -19,14 +19,14 @@ f=$(find $R/gpurun_out/${tag}_trace -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cut -c1-160 "$f" | head -14
 # keep what travels back small: the per-dispatch trace is not needed, the stats are
 find $R/gpurun_out/${tag}_trace -name "*kernel_trace.csv" -delete
-bash $R/tools/pmc.sh ${tag}_fetch FETCH_SIZE "$@" < /dev/null | cut -c1-200 | grep -A2 "feature_kernel<false>\|forest_kernel<false>"
-bash $R/tools/pmc.sh ${tag}_write WRITE_SIZE "$@" < /dev/null | cut -c1-200 | grep -A2 "feature_kernel<false>\|forest_kernel<false>"
-bash $R/tools/pmc.sh ${tag}_sq "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE" "$@" < /dev/null | cut -c1-200 | grep -A9 "feature_kernel<false>\|forest_kernel<false>"
-bash $R/tools/pmc.sh ${tag}_ta "TA_BUSY_avr TA_BUSY_max GRBM_GUI_ACTIVE" "$@" < /dev/null | cut -c1-200 | grep -A4 "feature_kernel<false>\|forest_kernel<false>"
+bash $R/tools/pmc.sh ${tag}_fetch FETCH_SIZE "$@" < /dev/null | cut -c1-200 | grep -A2 "feature_kernel<false, 2>\|forest_kernel<false>"
+bash $R/tools/pmc.sh ${tag}_write WRITE_SIZE "$@" < /dev/null | cut -c1-200 | grep -A2 "feature_kernel<false, 2>\|forest_kernel<false>"
+bash $R/tools/pmc.sh ${tag}_sq "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE" "$@" < /dev/null | cut -c1-200 | grep -A9 "feature_kernel<false, 2>\|forest_kernel<false>"
+bash $R/tools/pmc.sh ${tag}_ta "TA_BUSY_avr TA_BUSY_max GRBM_GUI_ACTIVE" "$@" < /dev/null | cut -c1-200 | grep -A4 "feature_kernel<false, 2>\|forest_kernel<false>"
 # instruction classes for the VALU issue model (tools/valu_model.py) and the LDS side of the forest kernel
-bash $R/tools/pmc.sh ${tag}_valu "SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 GRBM_GUI_ACTIVE" "$@" < /dev/null | cut -c1-200 | grep -A9 "feature_kernel<false>\|forest_kernel<false>"
-bash $R/tools/pmc.sh ${tag}_lds "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_SMEM GRBM_GUI_ACTIVE" "$@" < /dev/null | cut -c1-200 | grep -A8 "feature_kernel<false>\|forest_kernel<false>"
+bash $R/tools/pmc.sh ${tag}_valu "SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 GRBM_GUI_ACTIVE" "$@" < /dev/null | cut -c1-200 | grep -A9 "feature_kernel<false, 2>\|forest_kernel<false>"
+bash $R/tools/pmc.sh ${tag}_lds "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_SMEM GRBM_GUI_ACTIVE" "$@" < /dev/null | cut -c1-200 | grep -A8 "feature_kernel<false, 2>\|forest_kernel<false>"
 # lane utilisation of the VALU: enabled lanes summed over the VALU instructions against 64 per instruction
-bash $R/tools/pmc.sh ${tag}_lanes "SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE" "$@" < /dev/null | cut -c1-200 | grep -A6 "feature_kernel<false>\|forest_kernel<false>" || echo "lane counters not available on this box"
+bash $R/tools/pmc.sh ${tag}_lanes "SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE" "$@" < /dev/null | cut -c1-200 | grep -A6 "feature_kernel<false, 2>\|forest_kernel<false>" || echo "lane counters not available on this box"
 # the VALU issue ceilings of this box (tools/valu_ceiling.hip)
 [ -x $R/tools/valu_ceiling ] && $R/tools/valu_ceiling > $R/gpurun_out/${tag}_valu_ceiling.json && echo "valu ceiling measured"

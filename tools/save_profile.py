@@ -42,7 +42,7 @@ def main():
         shutil.copy(stats[-1], os.path.join(prof, tag + "_kernel_stats.csv"))
         for r in csv.DictReader(open(stats[-1])):
             name = r["Name"]
-            for k in ("feature_kernel<false>", "forest_kernel<false>", "forest_pair_kernel<false, 2, 5>", "nms_kernel<false>",
+            for k in ("feature_kernel<false, 2>", "forest_kernel<false>", "forest_pair_kernel<false, 2, 5>", "nms_kernel<false>",
                       "cell_sort_store_kernel", "bucket_scatter_kernel", "bucket_hist_kernel", "compact_scan_kernel"):
                 if k in name:
                     avg_ns[k] = float(r["AverageNs"])
@@ -69,7 +69,7 @@ def main():
         shutil.copy(cpath, os.path.join(prof, tag + "_valu_ceiling.json"))
         ceiling = json.load(open(cpath))
     kernels = {}
-    for k in ("feature_kernel<false>", "forest_kernel<false>", "forest_pair_kernel<false, 2, 5>"):
+    for k in ("feature_kernel<false, 2>", "forest_kernel<false>", "forest_pair_kernel<false, 2, 5>"):
         c = pmc.get(k)
         if not c:
             continue
@@ -92,7 +92,7 @@ def main():
                     e[name] = round(c[name], 1)
             # VALU issue model: instructions by class x the issue ceilings measured on this box
             if ceiling and c.get("SQ_INSTS_VALU_ADD_F32") is not None:
-                mangled = {"feature_kernel<false>": "feature_kernelILb0", "forest_kernel<false>": "forest_kernelILb0",
+                mangled = {"feature_kernel<false, 2>": "feature_kernelILb0ELi2", "forest_kernel<false>": "forest_kernelILb0",
                            "forest_pair_kernel<false, 2, 5>": "forest_pair_kernelILb0ELi2ELi5"}[k]
                 e["valu_model"] = valu_model.model(c, c.get("GRBM_GUI_ACTIVE_valu", c["GRBM_GUI_ACTIVE"]) / XCDS, ceiling, mangled)
                 e["valu_issue_frac"] = e["valu_model"]["valu_issue_frac"]
