@@ -217,6 +217,13 @@ int kpl_compute_device(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_c
                        int *d_kp_count, void *stream);
 int kpl_compute_features_device(kpl_detector *h, const int *d_indices, int m,
                                 float *d_features, void *stream);
+/* computePointsForTrainingFeatures for a batch of up to 8 bound views (one handle per view, all on one device): the
+ * caller loop of /root/reference/src/main_train_detector.cpp:413-446 extracts a few hundred training points from each of
+ * many views -- alone, a view is a handful of waves.  The indices of all views are built in one batch of launches, the
+ * features in one launch.  Arrays are indexed by view: d_indices[k] = m[k] point indices, d_features[k] = m[k] x
+ * (n_annulus*n_bins) floats.  Only enqueues; deferred errors through kpl_sync_status of each handle. */
+int kpl_compute_features_batch_device(kpl_detector *const *handles, int count, const int *const *d_indices,
+                                      const int *m, float *const *d_features, void *stream);
 /* compute() for a batch of up to 8 independent views (one handle per view, each with its cloud
  * bound, forest loaded and parameters set; all on one device).  A single 200 k-point view is only
  * ~3 waves per SIMD on an MI355X; every kernel of the pipeline (index build, scoring, NMS,

@@ -88,6 +88,7 @@ SYMBOLS = {
     "kpl_compute_batch_device": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "kpl_compute_batch_keypoints_device": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "kpl_sync_status": (C.c_int, [_vp, _vp]),
+    "kpl_compute_features_batch_device": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp]),
     "kpl_set_feature_walk": (C.c_int, [_vp, C.c_int, C.c_int]),
     "kpl_debug_set_scan_poll_limit": (C.c_int, [_vp, C.c_int]),
     "kpl_get_feature_walk": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
@@ -150,6 +151,22 @@ def compute_batch_device(detectors, d_scores, d_kp_idx, kp_caps, d_kp_counts, st
     Cp = (C.c_int * k)(*kp_caps)
     rc = lib.kpl_compute_batch_device(C.cast(H, _vp), k, C.cast(S, _vp) if S else None, C.cast(K, _vp),
                                       C.cast(Cp, _vp), C.cast(N, _vp), stream)
+    if rc != OK:
+        raise KplError(rc, lib.kpl_last_error(detectors[0]._h).decode())
+
+
+def compute_features_batch_device(detectors, d_indices, ms, d_features, stream=None):
+    """kpl_compute_features_batch_device: computePointsForTrainingFeatures of up to 8 bound views in one launch.  One entry
+    per detector: device address of its int32 point indices, their number, device address of its m x F output."""
+    lib = load_library()
+    k = len(detectors)
+    for d in detectors:
+        d._push()
+    H = (_vp * k)(*[d._h for d in detectors])
+    I = (_vp * k)(*[(_vp(p) if p else _vp()) for p in d_indices])
+    M = (C.c_int * k)(*[int(m) for m in ms])
+    O = (_vp * k)(*[(_vp(p) if p else _vp()) for p in d_features])
+    rc = lib.kpl_compute_features_batch_device(C.cast(H, _vp), k, C.cast(I, _vp), C.cast(M, _vp), C.cast(O, _vp), stream)
     if rc != OK:
         raise KplError(rc, lib.kpl_last_error(detectors[0]._h).decode())
 

@@ -1082,21 +1082,81 @@ int kpl_compute_batch_keypoints_device(kpl_detector *const *handles, int count, 
     return run_batch(handles, count, scratch, d_kp_idx, kp_caps, d_kp_counts, nullptr, true, (hipStream_t)stream, d_kp_scores);
 }
 
+// computePointsForTrainingFeatures for up to kMaxBatch bound views in one go: the indices of the views that need one are
+// built in ONE batch of index launches, the features of all views in one launch (blockIdx.y = view)
+static int features_batch(kpl_detector *const *handles, int count, const int *const *d_indices, const int *m,
+                          float *const *d_features, hipStream_t st) {
+    kpl_detector *h0 = handles[0];
+    Batch idx{}, fix{};
+    QueryBatch qb{};
+    qb.nviews = count;
+    bool rebuilt[kMaxBatch] = {};
+    for (int k = 0; k < count; ++k) {
+        kpl_detector *h = handles[k];
+        if (m[k] < 0 || (m[k] > 0 && (!d_indices[k] || !d_features[k]))) return fail(h0, KPL_ERR_INVALID_ARG, "view %d: null index or feature buffer", k);
+        int rc = check_params_for_compute(h, false);
+        if (!rc && !h->bound) rc = fail(h, KPL_ERR_NO_CLOUD, "no cloud bound");
+        ViewDev v{};
+        if (!rc) rc = prepare_index(h, false, v, st);
+        if (rc) {
+            if (h != h0) fail(h0, rc, "view %d: %s", k, kpl_last_error(h));
+            return rc;
+        }
+        v.want_pos_of = 1;
+        if (!index_is_current(h)) {
+            idx.view[idx.nviews++] = v;
+            rebuilt[k] = true;
+        } else if (!h->pos_of_valid) {
+            fix.view[fix.nviews++] = v;
+        }
+        QueryView &q = qb.view[k];
+        q.pts = v.pts;
+        q.nrm = v.nrm;
+        q.nrmsrc = h->d_nrm;
+        q.ns = (unsigned)h->ns;
+        q.cell_start = v.cell_start;
+        q.pos_of = v.pos_of;
+        q.ds = v.ds;
+        q.f = make_feat(h->prm);
+        q.query = d_indices[k];
+        q.m = m[k];
+        q.n = h->n;
+        q.out = d_features[k];
+    }
+    if (idx.nviews) launch_index(idx, st);
+    if (fix.nviews) launch_pos_of(fix, st);
+    launch_features(qb, st);
+    KPL_HIP(h0, hipGetLastError());
+    for (int k = 0; k < count; ++k) {
+        if (rebuilt[k]) index_was_built(handles[k], false);
+        else handles[k]->pos_of_valid = true;
+    }
+    return KPL_OK;
+}
+
 int kpl_compute_features_device(kpl_detector *h, const int *d_indices, int m, float *d_features, void *stream) {
     if (!h) return KPL_ERR_INVALID_ARG;
     if (m < 0 || (m > 0 && (!d_indices || !d_features))) return fail(h, KPL_ERR_INVALID_ARG, "null index or feature buffer");
-    int rc = check_params_for_compute(h, false);
+    int rc = use_device(h);
     if (rc) return rc;
-    if (!h->bound) return fail(h, KPL_ERR_NO_CLOUD, "no cloud bound");
-    rc = use_device(h);
+    return features_batch(&h, 1, &d_indices, &m, &d_features, (hipStream_t)stream);
+}
+
+int kpl_compute_features_batch_device(kpl_detector *const *handles, int count, const int *const *d_indices, const int *m,
+                                      float *const *d_features, void *stream) {
+    if (!handles || count <= 0 || !d_indices || !m || !d_features) return KPL_ERR_INVALID_ARG;
+    for (int k = 0; k < count; ++k)
+        if (!handles[k]) return KPL_ERR_INVALID_ARG;
+    kpl_detector *h0 = handles[0];
+    if (count > kMaxBatch) return fail(h0, KPL_ERR_INVALID_ARG, "at most %d views per batch", kMaxBatch);
+    int rc = use_device(h0);
     if (rc) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    rc = ensure_index(h, st);
-    if (rc) return rc;
-    launch_features(h->pts.as<float4>(), h->nrm.as<float4>(), h->d_nrm, (unsigned)h->ns, h->cell_start.as<int>(),
-                    h->pos_of.as<int>(), h->dstate.as<DevState>(), make_feat(h->prm), d_indices, m, h->n, d_features, st);
-    KPL_HIP(h, hipGetLastError());
-    return KPL_OK;
+    for (int k = 0; k < count; ++k) {
+        if (handles[k]->device != h0->device) return fail(h0, KPL_ERR_INVALID_ARG, "all views of a batch must live on one device");
+        for (int j = 0; j < k; ++j)
+            if (handles[j] == handles[k]) return fail(h0, KPL_ERR_INVALID_ARG, "a handle appears twice in the batch");
+    }
+    return features_batch(handles, count, d_indices, m, d_features, (hipStream_t)stream);
 }
 
 int kpl_detect(kpl_detector *h, const void *xyz, size_t xyz_stride, const void *normals, size_t normals_stride,

@@ -192,11 +192,24 @@ size_t feat_bytes(int n, int F);
 // bytes of pts[] for a view of n points: a search step of the feature code loads a fixed number of
 // consecutive candidates from one address, so the array carries that many elements of tail
 size_t pts_bytes(int n);
-// features of listed points -> out[m*F]
+// features of listed points -> out[m*F], for up to kMaxBatch indexed views per launch (computePointsForTrainingFeatures)
 // (nrmsrc / ns: the caller's normals in original point order and their byte stride -- read by the sorted-search mode)
-void launch_features(const float4 *pts, const float4 *nrm, const char *nrmsrc, unsigned ns, const int *cell_start,
-                     const int *pos_of, const DevState *ds, FeatDesc f, const int *query, int m, int n,
-                     float *out, hipStream_t st);
+struct QueryView {
+    const float4 *pts, *nrm;
+    const char *nrmsrc;
+    unsigned ns;
+    const int *cell_start, *pos_of;
+    const DevState *ds;
+    FeatDesc f;
+    const int *query;     // [m] original point indices
+    int m, n;
+    float *out;           // [m x F]
+};
+struct QueryBatch {
+    int nviews;
+    QueryView view[kMaxBatch];
+};
+void launch_features(const QueryBatch &qb, hipStream_t st);
 
 // cloud resolution: val[n] scratch, out[0] = ordered double sum of the 2nd-NN distances, out[1] = count
 // (out holds 3 doubles; scratch holds resolution_scratch_bytes())

@@ -2804,61 +2804,56 @@ __global__ __launch_bounds__(1024) void forest_split_kernel(Batch b, int maxF, i
     }
 }
 
-// computePointsForTrainingFeatures, hpp:299-318: same feature code, sparse query list (64 / kGroup queries per wave).
-__global__ __launch_bounds__(kLanes) void features_kernel(const float4 *__restrict__ pts,
-                                                          const float4 *__restrict__ nrm,
-                                                          const int *__restrict__ cell_start,
-                                                          const int *__restrict__ pos_of,
-                                                          const DevState *__restrict__ ds, FeatDesc f,
-                                                          const int *__restrict__ query, int m,
-                                                          int n, int ecap, float *__restrict__ out) {
+// computePointsForTrainingFeatures, hpp:299-318: same feature code, sparse query lists (64 / kGroup queries per wave) of up to
+// 8 views per launch (blockIdx.y = view: the training set of /root/reference/src/main_train_detector.cpp:413-446 is a few
+// hundred points in each of many views -- one view alone is a handful of waves)
+__global__ __launch_bounds__(kLanes) void features_kernel(QueryBatch qb, int maxF, int ecap) {
     extern __shared__ float H[];
     constexpr int kPts = kLanes / kGroup;
-    uint2 *ent = reinterpret_cast<uint2 *>(H + f.F * kPts);
-    const GridDesc g = ds->grid;
+    const QueryView &q = qb.view[blockIdx.y];
+    if (q.f.sorted) return;                        // features_sorted_kernel
     const int pi = threadIdx.x / kGroup, gq = threadIdx.x % kGroup;
     const int qi = blockIdx.x * kPts + pi;
+    if (qi - pi >= q.m) return;
+    uint2 *ent = reinterpret_cast<uint2 *>(H + maxF * kPts);
+    const GridDesc g = q.ds->grid;
     int s = -1;
-    if (qi < m) {
-        const int i = query[qi];
-        s = (i >= 0 && i < n) ? pos_of[i] : -1;
+    if (qi < q.m) {
+        const int i = q.query[qi];
+        s = (i >= 0 && i < q.n) ? q.pos_of[i] : -1;
     }
-    const float4 p = s >= 0 ? pts[s] : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 np = s >= 0 ? nrm[s] : make_float4(0.f, 0.f, 0.f, 0.f);
-    point_features<kGroup>(pts, nrm, cell_start, g, f, p, np, H, ent, ecap, s >= 0);
-    if (qi >= m) return;
-    float *o = out + (size_t)qi * f.F;
-    for (int c = gq; c < f.F; c += kGroup) o[c] = s >= 0 ? H[c * kPts + pi] : NAN;
+    const float4 p = s >= 0 ? q.pts[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 np = s >= 0 ? q.nrm[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+    point_features<kGroup>(q.pts, q.nrm, q.cell_start, g, q.f, p, np, H, ent, ecap, s >= 0);
+    if (qi >= q.m) return;
+    float *o = q.out + (size_t)qi * q.f.F;
+    for (int c = gq; c < q.f.F; c += kGroup) o[c] = s >= 0 ? H[c * kPts + pi] : NAN;
 }
 
 // the same in sorted-search mode (nrmsrc: the caller's normals in original order, byte stride ns)
-__global__ __launch_bounds__(kLanes) void features_sorted_kernel(const float4 *__restrict__ pts,
-                                                                 const float4 *__restrict__ nrm,
-                                                                 const char *__restrict__ nrmsrc, unsigned ns,
-                                                                 const int *__restrict__ cell_start,
-                                                                 const int *__restrict__ pos_of,
-                                                                 const DevState *__restrict__ ds, FeatDesc f,
-                                                                 const int *__restrict__ query, int m,
-                                                                 int n, int ecap, int lcap, float *__restrict__ out) {
+__global__ __launch_bounds__(kLanes) void features_sorted_kernel(QueryBatch qb, int maxF, int ecap, int lcap) {
     extern __shared__ float H[];
     constexpr int G = kSortGroup, kPts = kLanes / G;
-    uint2 *ent = reinterpret_cast<uint2 *>(H + f.F * kPts);
-    unsigned long long *keys = reinterpret_cast<unsigned long long *>(ent + ecap * kPts);
-    const GridDesc g = ds->grid;
+    const QueryView &q = qb.view[blockIdx.y];
+    if (!q.f.sorted) return;
     const int pi = threadIdx.x / G, gq = threadIdx.x % G;
     const int qi = blockIdx.x * kPts + pi;
+    if (qi - pi >= q.m) return;
+    uint2 *ent = reinterpret_cast<uint2 *>(H + maxF * kPts);
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(ent + ecap * kPts);
+    const GridDesc g = q.ds->grid;
     int s = -1;
-    if (qi < m) {
-        const int i = query[qi];
-        s = (i >= 0 && i < n) ? pos_of[i] : -1;
+    if (qi < q.m) {
+        const int i = q.query[qi];
+        s = (i >= 0 && i < q.n) ? q.pos_of[i] : -1;
     }
-    const float4 p = s >= 0 ? pts[s] : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 np = s >= 0 ? nrm[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 p = s >= 0 ? q.pts[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 np = s >= 0 ? q.nrm[s] : make_float4(0.f, 0.f, 0.f, 0.f);
     bool deferred_unused;
-    point_features_sorted<G, false>(pts, nrmsrc, ns, cell_start, g, f, p, np, H, ent, ecap, keys, lcap, s >= 0, deferred_unused);
-    if (qi >= m) return;
-    float *o = out + (size_t)qi * f.F;
-    for (int c = gq; c < f.F; c += G) o[c] = s >= 0 ? H[c * kPts + pi] : NAN;
+    point_features_sorted<G, false>(q.pts, q.nrmsrc, q.ns, q.cell_start, g, q.f, p, np, H, ent, ecap, keys, lcap, s >= 0, deferred_unused);
+    if (qi >= q.m) return;
+    float *o = q.out + (size_t)qi * q.f.F;
+    for (int c = gq; c < q.f.F; c += G) o[c] = s >= 0 ? H[c * kPts + pi] : NAN;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -4747,19 +4742,26 @@ void launch_forest_stage(const Batch &b, hipStream_t st) {
     else forest_kernel<false><<<fgrid, fl.waves * kLanes, fl.lds, st>>>(b, maxF, fl.nlds_cap);
 }
 
-void launch_features(const float4 *pts, const float4 *nrm, const char *nrmsrc, unsigned ns, const int *cell_start,
-                     const int *pos_of, const DevState *ds, FeatDesc f, const int *query, int m, int n,
-                     float *out, hipStream_t st) {
-    if (m <= 0) return;
-    if (f.sorted) {
-        const int lcap = sorted_list_keys(f.F);
-        features_sorted_kernel<<<div_up(m, kLanes / kSortGroup), kLanes, sorted_lds_bytes<kSortGroup>(f.F, kSortWords, lcap), st>>>(
-            pts, nrm, nrmsrc, ns, cell_start, pos_of, ds, f, query, m, n, kSortWords, lcap, out);
-        return;
+void launch_features(const QueryBatch &qb, hipStream_t st) {
+    int max_m = 0, maxF = 1;
+    bool canonical = false, sorted = false;
+    for (int v = 0; v < qb.nviews; ++v) {
+        const QueryView &q = qb.view[v];
+        if (q.m <= 0) continue;
+        max_m = q.m > max_m ? q.m : max_m;
+        maxF = q.f.F > maxF ? q.f.F : maxF;
+        (q.f.sorted ? sorted : canonical) = true;
     }
-    const int ecap = accept_words<kGroup>(f.F);
-    features_kernel<<<div_up(m, kLanes / kGroup), kLanes, feature_lds_bytes<kGroup>(f.F, ecap), st>>>(pts, nrm, cell_start, pos_of, ds,
-                                                                                                      f, query, m, n, ecap, out);
+    if (max_m <= 0) return;
+    if (canonical) {
+        const int ecap = accept_words<kGroup>(maxF);
+        features_kernel<<<dim3(div_up(max_m, kLanes / kGroup), qb.nviews), kLanes, feature_lds_bytes<kGroup>(maxF, ecap), st>>>(qb, maxF, ecap);
+    }
+    if (sorted) {
+        const int lcap = sorted_list_keys(maxF);
+        features_sorted_kernel<<<dim3(div_up(max_m, kLanes / kSortGroup), qb.nviews), kLanes,
+                                 sorted_lds_bytes<kSortGroup>(maxF, kSortWords, lcap), st>>>(qb, maxF, kSortWords, lcap);
+    }
 }
 
 // NMS, draws pass (if any view asks for it), flag scan and ordered compaction of every view

@@ -67,3 +67,44 @@ def test_train_then_detect(tmp_path, kpl, oracle, cases, capsys):
     fa = forest_yaml.load_forest(str(rf / "t.yaml.gz"))
     o_scores, _ = oracle.detect(good, nrm, A, B, 6.0, 4.0, 0.0, cases.oracle_forest(fa), non_maxima=False)
     assert cases.same_bits(scores, o_scores)
+
+
+def test_batched_training_features_equal_the_single_view_entry_point(kpl, oracle, cases):
+    """kpl_compute_features_batch_device over 5 views of different sizes, radii and neighbor orders in one launch = what
+    kpl_compute_features gives view by view = the oracle's rows; indices out of range and non-finite points give NaN rows."""
+    import torch
+    from tools import synth
+    dev = torch.device("cuda", 0)
+    A, B = 5, 6
+    dets, keep, idx_p, out_p, ms, outs, want = [], [], [], [], [], [], []
+    for k, (nx, ny, rmul, srt) in enumerate([(80, 60, 6.0, False), (50, 40, 8.0, True), (90, 70, 5.0, False), (30, 30, 6.0, False), (64, 48, 7.0, True)]):
+        xyz, nrm = synth.make_cloud(nx, ny, seed=20 + k, nan_points=3 if k == 2 else 0)
+        xyz, nrm = synth.shuffle_cloud(xyz, nrm, 2000 + k)
+        mr = oracle.cloud_resolution(xyz[np.isfinite(xyz).all(axis=1)])
+        r = float(np.float32(rmul * mr))
+        rng = np.random.default_rng(k)
+        idx = rng.choice(len(xyz), size=200 + 37 * k, replace=False).astype(np.int32)
+        if k == 0:
+            idx[5], idx[9] = -1, len(xyz) + 3                          # out of range: NaN rows
+        det = kpl.KeypointLearningDetector()
+        det.setNAnnulus(A); det.setNBins(B); det.setRadiusSearch(r); det.setSortedSearch(srt)
+        dx, dn, di = torch.from_numpy(xyz).to(dev), torch.from_numpy(nrm).to(dev), torch.from_numpy(idx).to(dev)
+        do = torch.full((len(idx), A * B), -7.0, dtype=torch.float32, device=dev)
+        det.bindCloudDevice(dx.data_ptr(), 12, dn.data_ptr(), 12, len(xyz))
+        dets.append(det); keep.append((dx, dn, di)); idx_p.append(di.data_ptr()); out_p.append(do.data_ptr()); ms.append(len(idx)); outs.append(do)
+        single = kpl.KeypointLearningDetector()
+        single.setNAnnulus(A); single.setNBins(B); single.setRadiusSearch(r); single.setSortedSearch(srt)
+        single.setInputCloud(xyz); single.setNormals(nrm)
+        want.append(single.computePointsForTrainingFeatures(idx))
+        ok = (idx >= 0) & (idx < len(xyz))
+        ok[ok] &= np.isfinite(xyz[idx[ok]]).all(axis=1)
+        g = oracle.Grid(xyz, r)
+        rows = g.features(nrm, A, B, r, idx[ok], order=oracle.ORDER_SORTED if srt else oracle.ORDER_CANONICAL)
+        assert cases.same_bits(want[-1][ok], rows) and np.isnan(want[-1][~ok]).all()
+    torch.cuda.synchronize()
+    for attempt in range(4):
+        kpl.compute_features_batch_device(dets, idx_p, ms, out_p, None)
+        if kpl.ERR_RETRY not in [d.syncStatus(None) for d in dets]:
+            break
+    for o, w in zip(outs, want):
+        assert cases.same_bits(o.cpu().numpy(), w)

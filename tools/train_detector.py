@@ -110,13 +110,64 @@ def sklearn_to_arrays(clf, F):
     return forest_yaml.ForestArrays(root, var, thr, left, right, value, F, depth, cidx, qual)
 
 
+VIEWS_PER_BATCH = 8          # kpl_compute_features_batch_device: the training points of up to 8 views in one launch
+
+
+def batch_features(kpl, dets, pending, device):
+    """computePointsForTrainingFeatures of up to 8 views at once (the caller loop of main_train_detector.cpp:413-446, which
+    takes a few hundred points from each of many views): clouds, normals and indices to the device, ONE batched index build
+    and ONE feature launch for all of them (kpl_compute_features_batch_device), the rows back.  Returns (rows per view, seconds
+    on the device path)."""
+    import torch
+    dev = torch.device("cuda", device)
+    t0 = time.perf_counter()
+    keep, idx_p, out_p, ms, outs = [], [], [], [], []
+    F = dets[0]._p.n_annulus * dets[0]._p.n_bins
+    for det, (xyz, nrm, idx) in zip(dets, pending):
+        dx, dn = torch.from_numpy(xyz).to(dev), torch.from_numpy(np.ascontiguousarray(nrm, dtype=np.float32)).to(dev)
+        di = torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int32)).to(dev)
+        do = torch.empty((len(idx), F), dtype=torch.float32, device=dev)
+        det.bindCloudDevice(dx.data_ptr(), 12, dn.data_ptr(), 12, len(xyz))
+        keep.append((dx, dn, di))
+        idx_p.append(di.data_ptr()); out_p.append(do.data_ptr()); ms.append(len(idx)); outs.append(do)
+    torch.cuda.synchronize()
+    st = torch.cuda.current_stream().cuda_stream
+    use = dets[:len(pending)]
+    for attempt in range(6):                          # (a first view of a size grows the cell tables: KPL_ERR_RETRY)
+        kpl.compute_features_batch_device(use, idx_p, ms, out_p, st)
+        rcs = [d.syncStatus(st) for d in use]         # every handle, no short circuit
+        if kpl.ERR_RETRY not in rcs:
+            break
+    else:
+        raise SystemExit("the views keep asking for larger tables")
+    rows = [o.cpu().numpy() for o in outs]
+    return rows, time.perf_counter() - t0
+
+
 def collect(args, log=print):
     kpl = importlib.import_module("keypoint-learning_amd")
-    det = kpl.KeypointLearningDetector(device=args.device)
-    det.setNAnnulus(args.annuli)
-    det.setNBins(args.bins)
-    det.setRadiusSearch(args.radiusFeatures)
+    dets = []
+    for _ in range(VIEWS_PER_BATCH):
+        det = kpl.KeypointLearningDetector(device=args.device)
+        det.setNAnnulus(args.annuli)
+        det.setNBins(args.bins)
+        det.setRadiusSearch(args.radiusFeatures)
+        dets.append(det)
+    det = dets[0]
     feats, labels, views = [], [], 0
+    pending, names, t_feat = [], [], 0.0
+
+    def flush():
+        nonlocal t_feat
+        if not pending:
+            return
+        rows, dt = batch_features(kpl, dets, pending, args.device)
+        t_feat += dt
+        for name, r in zip(names, rows):
+            feats.append(r)
+            log("[END] Compute features for: " + name)
+        pending.clear()
+        names.clear()
     for model in sorted(os.listdir(args.pathDataset)):
         mdir = os.path.join(args.pathDataset, model)
         if not os.path.isdir(mdir):
@@ -142,14 +193,16 @@ def collect(args, log=print):
             idx = snap_to_cloud(xyz, np.concatenate([pos, neg]))
             lab = np.concatenate([np.zeros(len(pos), np.int32), np.ones(len(neg), np.int32)])   # :405-407
             log("[START] Compute features for: " + name)
-            det.setInputCloud(xyz)
-            det.setNormals(nrm)
-            feats.append(det.computePointsForTrainingFeatures(idx))
-            log("[END] Compute features for: " + name)
+            pending.append((xyz, nrm, idx))
+            names.append(name)
             labels.append(lab)
             views += 1
+            if len(pending) == VIEWS_PER_BATCH:
+                flush()
+    flush()
     if not feats:
         raise SystemExit("no view with a training set found")
+    collect.feature_seconds = t_feat
     return np.concatenate(feats).astype(np.float32), np.concatenate(labels), views
 
 
@@ -210,7 +263,10 @@ def main(argv=None):
         f.write("Trained with: %d positives and %d negatives.\nTrain duration in seconds: %s\n" % (npos, nneg, repr(t_train)))
     print(json.dumps({"forest": out, "views": views, "rows": int(len(lab)), "positives": npos, "negatives": nneg,
                       "ntrees": int(fa.ntrees), "nodes": int(fa.nnodes), "train_error": err_train,
-                      "test_error": err_test, "seconds": round(time.time() - t0, 3)}))
+                      "test_error": err_test, "seconds": round(time.time() - t0, 3),
+                      # upload + batched index build + batched feature launch + rows back, 8 views per batch
+                      "feature_extraction": {"views_per_batch": VIEWS_PER_BATCH, "seconds": round(collect.feature_seconds, 4),
+                                             "views_per_s": round(views / max(collect.feature_seconds, 1e-9), 1)}}))
     return 0
 
 
