@@ -109,6 +109,8 @@ struct kpl_detector {
     double kf_hint_radius = 0.0;  // ... measured at this feature radius
     int kf_hint_n = 0;            // ... on a view of this many points
     unsigned long long kf_seen_sum = 0, kf_seen_points = 0;     // DevState::kf_sum / kf_points at that read
+    int lcap_hint = 0;            // sorted-search mode: keys per point the lists of the register-sort kernel need (0: not known = 128),
+    double lcap_hint_radius = 0.0;    // ... for this feature radius
     double launched_radius = 0.0; // feature radius / points of the last scoring launch (what the next read-back describes)
     int launched_n = 0;
     float origin[3] = {0.0f, 0.0f, 0.0f};
@@ -209,6 +211,7 @@ FeatDesc make_feat(const kpl_params &p) {
     f.sorted = p.neighbor_order == KPL_NEIGHBORS_SORTED ? 1 : 0;
     f.walk = 0;
     f.lanes = 2;
+    f.lcap = 0;
     return f;
 }
 
@@ -417,6 +420,15 @@ int sync_status(kpl_detector *h, hipStream_t st) {
         KPL_HIP(h, hipMemsetAsync((char *)h->dstate.p + offsetof(DevState, scan_fail), 0, sizeof(int), st));
         KPL_HIP(h, hipStreamSynchronize(st));
     }
+    if (h->h_state->kf_max > 0) {
+        // sorted-search mode: the longest neighborhood the register-sort kernel scored (129 = a list ran full): the capacity
+        // of the next launch's lists, a few keys above it in steps of 8 (never below what was seen: no point is deferred
+        // that was not deferred before); the device's maximum starts over
+        const int seen = h->h_state->kf_max;
+        h->lcap_hint = seen > 124 ? 128 : ((seen + 4 + 7) / 8) * 8;
+        h->lcap_hint_radius = h->launched_radius;
+        KPL_HIP(h, hipMemsetAsync((char *)h->dstate.p + offsetof(DevState, kf_max), 0, sizeof(int), st));
+    }
     if (h->h_state->status == kStatusGridTooLarge)
         return fail(h, KPL_ERR_GRID_TOO_LARGE, "bounding box / radius needs more than 2^28 grid cells");
     if (h->h_state->status == kStatusBadOrigin)
@@ -481,6 +493,7 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
     v.key_cap = 0;
     FeatDesc feat = make_feat(h->prm);
     choose_walk(h, feat);
+    if (feat.sorted && h->lcap_hint > 0 && h->lcap_hint_radius == h->prm.radius_search) feat.lcap = h->lcap_hint;
     if (!feat.sorted && feat.walk == 1) {
         // two-pass walk: the accept words of every point's whole walk (8-byte entries in the array the sorted mode keeps its
         // keys in -- a view is in one mode or the other).  About one word per five neighbors on a surface (32 candidates

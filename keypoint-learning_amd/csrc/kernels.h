@@ -42,6 +42,7 @@ struct FeatDesc {
     // how the canonical order is walked -- never WHAT is computed: every combination gives the same bits (kernels.hip)
     int walk;        // 0: search and drain alternate, accept words in LDS (point_features); 1: two passes, the accept words of the whole walk through global memory (large neighborhoods)
     int lanes;       // lanes per point: 2 or 4
+    int lcap;        // sorted-search mode: keys per point of the register-sort kernel's lists in LDS (<= 128; 0 = 128)
 };
 
 struct NmsDesc {
@@ -159,6 +160,9 @@ struct DevState {
     // reads behind them (the bench lost 3 % with the counters next to it)
     alignas(128) unsigned long long kf_sum;
     unsigned long long kf_points;
+    // sorted-search mode: the longest neighborhood the register-sort kernel scored since the host last read it (129: a point
+    // whose list ran full and was deferred) -- the list capacity of the handle's next launch (api.cpp)
+    int kf_max;
     // two-pass walk (kernels.hip): entries handed out of each 32nd of the word list (ViewDev::sort_keys); zero between calls
     alignas(128) unsigned long long word_cursor[32];
 };

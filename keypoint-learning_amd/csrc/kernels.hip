@@ -2569,6 +2569,14 @@ __global__ __launch_bounds__(kLanes) void feature_sorted_kernel(Batch b, int max
                                             keys, lcap, w.scoreable && !large, deferred);
     else
         for (int c = gq; c < v.f.F; c += G) H[c * kPts + pi] = 0.0f;      // (what a point that is not scored leaves in its column)
+    // the longest neighborhood of the wave (a deferred point: "longer than the list") for the list capacity of the handle's
+    // next launch: a plain read of the running maximum first, the atomic only when the wave raises it (a handful per launch)
+    {
+        int m = (w.scoreable && !large) ? (deferred ? kSortedListKeys + 1 : kf) : 0;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) m = max(m, __shfl_xor(m, d));
+        if (threadIdx.x == 0 && m > __hip_atomic_load(&v.ds->kf_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&v.ds->kf_max, m);
+    }
     // a large box, or more neighbors than the list holds: a point for the collect / add kernels.  ONE atomic per wave for its
     // (up to 16) listed points: returning atomics on one address complete one after the other, ~18 ns each -- a view whose
     // 200 k points all went to the list one by one spent 3.7 ms on nothing else (profiles/r04_notes.md)
@@ -4634,7 +4642,12 @@ void launch_feature_stage(const Batch &b, hipStream_t st) {
     if (sorted) {       // the views in sorted-search mode (each kernel skips the views of the other mode)
         // the register-sort kernel lists the points with large neighborhoods instead of scoring them, the collect / add pair
         // takes them (both return at once where there are none)
-        const int lcap = sorted_list_keys(maxF);
+        // keys per point of the lists in LDS: what the views' handles ask for (FeatDesc::lcap, from the longest neighborhood
+        // their earlier calls saw; the register sort holds 128 either way) -- 96 keys instead of 128 are 10 instead of 8 waves
+        // per CU (8 x 200 k points at 6 mr: 2.11 -> 1.84 ms, profiles/r04_sorted_lcap.jsonl)
+        int lcap = 8;
+        for (int v = 0; v < b.nviews; ++v)
+            if (b.view[v].f.sorted) lcap = std::max(lcap, b.view[v].f.lcap > 0 && b.view[v].f.lcap <= kSortedListKeys ? b.view[v].f.lcap : kSortedListKeys);
         const size_t lds = sorted_lds_bytes<kSortGroup>(maxF, kSortWords, lcap);
         const dim3 grid(div_up(n, kLanes) * kSortGroup, b.nviews);
         // views of about the same size are dealt to the XCDs (view_block): what a view reads at random then stays in one L2
