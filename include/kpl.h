@@ -246,10 +246,16 @@ int kpl_compute_batch_keypoints_device(kpl_detector *const *handles, int count, 
  * cells; more cells than the handle's tables currently hold (they start at 8*n + 65536 cells); in
  * sorted-search mode, more neighbor keys of points with large neighborhoods than the handle's key
  * array holds (it starts at 64 keys per point; the reference's default radius on its own test views
- * needs ~2 300); a device-side consistency check that failed.  In all of them the enqueued call wrote
- * *d_kp_count = -1.  kpl_sync_status waits for `stream` and returns KPL_OK, KPL_ERR_GRID_TOO_LARGE,
- * KPL_ERR_RETRY after growing the tables / the key array (enqueue the call again; a first call may need
- * this twice), or KPL_ERR_INTERNAL (call again).  kpl_detect / kpl_compute_features do this internally. */
+ * needs ~2 300); in the two-pass walk of large neighborhoods (kpl_set_feature_walk), more accept words
+ * than the handle's word list holds; a device-side consistency check that failed.  In all of them the
+ * enqueued call wrote *d_kp_count = -1.  kpl_sync_status waits for `stream` and returns KPL_OK,
+ * KPL_ERR_GRID_TOO_LARGE, KPL_ERR_RETRY after growing the table in question (enqueue the call again; a
+ * first call may need this more than once, and a handle that switches to the two-pass walk after it has
+ * measured the neighborhood size of a view may need it once more then), or KPL_ERR_INTERNAL (call again).
+ * It also reads back what the feature kernels measured for the handle's next launch (mean and longest
+ * neighborhood: kpl_get_feature_walk).  Growth is ordered by `stream` (hipMallocAsync / hipMemsetAsync /
+ * hipFreeAsync): no other stream of the process waits.  kpl_detect / kpl_compute_features do all this
+ * internally. */
 int kpl_sync_status(kpl_detector *h, void *stream);
 
 /* Per-phase device timing with HIP events recorded on the caller's stream, around the kernels of
