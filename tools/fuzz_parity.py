@@ -1,6 +1,7 @@
 """Randomised parity soak: random small clouds, radii, histogram shapes, forests, thresholds and NMS modes through
-libkpl and through the oracle, in the canonical and (40 % of the cases) the sorted neighbor order; every score must match
-bit for bit and every keypoint list exactly.  Every 25th case also
+libkpl and through the oracle, in the canonical and (40 % of the cases) the sorted neighbor order, with the walk of the
+canonical order forced at random (one kernel / two passes, two / four lanes per point, or the handle's own choice: round 5);
+every score must match bit for bit and every keypoint list exactly.  Every 25th case also
 runs a random organized depth image (steps, holes, non-finite x) through the integral-image normal estimation.
     python tools/fuzz_parity.py [seconds] [seed] [--log FILE]
 A mismatch is reported with everything needed to classify it (scores vs list vs count, how many, where), the device's
@@ -58,6 +59,7 @@ def batch_case(kpl, rng):
         det.setNAnnulus(A); det.setNBins(B); det.setNonMaxima(nms); det.setNonMaxRadius(rn)
         det.setNonMaximaDrawsRemove(draws); det.setNonMaximaDrawsThreshold(dthr)
         det.setPredictionThreshold(thr); det.setRadiusSearch(r); det.setSortedSearch(srt)
+        det.setFeatureWalk(*WALKS[int(rng.integers(0, len(WALKS)))])
         helpers.load_arrays(det, fa)
         dx = torch.from_numpy(xyz).to(dev) if n else torch.zeros(1, 3, device=dev)
         dn = torch.from_numpy(nrm).to(dev) if n else torch.zeros(1, 3, device=dev)
@@ -69,7 +71,7 @@ def batch_case(kpl, rng):
                                   draws_remove=draws, draws_threshold=dthr, order=kplo.ORDER_SORTED if srt else kplo.ORDER_CANONICAL))
     args = (dets, [b[2].data_ptr() for b in bufs], [b[3][1:].data_ptr() if b[4] else None for b in bufs],
             [b[4] for b in bufs], [b[3][0:1].data_ptr() for b in bufs])
-    for attempt in range(2):
+    for attempt in range(4):
         kpl.compute_batch_device(*args, None)
         torch.cuda.synchronize()
         st = [d.syncStatus(None) for d in dets]
@@ -117,10 +119,14 @@ def failure_path(name="fuzz_failure.npz"):
     return os.path.join(d, name) if os.path.isdir(d) else name
 
 
-def configure(det, A, B, nms, rn, draws, dthr, thr, r, srt, fa):
+WALKS = [(-1, 2), (0, 2), (0, 4), (1, 2), (1, 4)]      # (kpl_set_feature_walk: AUTO / LANES / TWO_PASS, lanes per point)
+
+
+def configure(det, A, B, nms, rn, draws, dthr, thr, r, srt, fa, walk=(-1, 2)):
     det.setNAnnulus(A); det.setNBins(B); det.setNonMaxima(nms); det.setNonMaxRadius(rn)
     det.setNonMaximaDrawsRemove(draws); det.setNonMaximaDrawsThreshold(dthr)
     det.setPredictionThreshold(thr); det.setRadiusSearch(r); det.setSortedSearch(srt)
+    det.setFeatureWalk(*walk)
     helpers.load_arrays(det, fa)
 
 
@@ -173,6 +179,9 @@ def main():
         mr = kplo.cloud_resolution(xyz) if n > 1 else 1.0
         mr = mr if mr > 0 else 1.0
         r = float(np.float32(mr * rng.uniform(1.5, 9.0)))
+        if rng.random() < 0.15:                        # large neighborhoods: hundreds of points per cell (what the two-pass walk is for)
+            r = float(np.float32(mr * rng.uniform(9.0, 30.0)))
+        walk = WALKS[int(rng.integers(0, len(WALKS)))]
         # one case in 400: a radius so small against the extent of the cloud that the grid has 1e8 .. 2.7e8 cells (the limit is
         # 2^28): a cell table of ~1 GB that the handle has to grow -- the class of view behind the fuzz events of rounds 3 and 4
         # (an asynchronous clear of that table raced with the index build, profiles/r04_notes.md section 1)
@@ -194,7 +203,7 @@ def main():
                                  seed=int(rng.integers(1, 1 << 30)), target_nodes_per_tree=int(rng.integers(3, 1500 if many else 400)))
         if rng.random() < 0.5:                         # coarse leaf values: many exact score ties
             fa.value[:] = np.round(fa.value * 2) / 2
-        configure(det, A, B, nms, rn, draws, dthr, thr, r, srt, fa)
+        configure(det, A, B, nms, rn, draws, dthr, thr, r, srt, fa, walk)
         det.setInputCloud(np.ascontiguousarray(xyz).reshape(-1, 3)); det.setNormals(np.ascontiguousarray(nrm).reshape(-1, 3))
         try:
             _, sc = det.compute()
@@ -212,8 +221,8 @@ def main():
                      root=fa.root, var=fa.var, thrs=fa.thr, left=fa.left, right=fa.right, value=fa.value,
                      dev_scores=sc, dev_kp=kp, ora_scores=o_sc, ora_kp=o_kp)
             bad = np.nonzero(~((helpers.bits(sc) == helpers.bits(o_sc)) | (np.isnan(sc) & np.isnan(o_sc))))[0] if len(sc) == len(o_sc) else []
-            print("MISMATCH seed %d case %d kind %d n %d A %d B %d r %g rn %g thr %g nms %d draws %d sorted %d trees %d nodes %d -> %s"
-                  % (seed, cases, kind, n, A, B, r, rn, thr, nms, draws, srt, fa.ntrees, len(fa.var), out))
+            print("MISMATCH seed %d case %d kind %d n %d A %d B %d r %g rn %g thr %g nms %d draws %d sorted %d walk %s trees %d nodes %d -> %s"
+                  % (seed, cases, kind, n, A, B, r, rn, thr, nms, draws, srt, walk, fa.ntrees, len(fa.var), out))
             print("  WHAT DIFFERED: scores %s (%d of %d differ, first at %s); keypoint COUNT device %d oracle %d; LIST %s; only device %s only oracle %s"
                   % ("same" if len(bad) == 0 else "DIFFER", len(bad), n, bad[:6], len(kp), len(o_kp),
                      "same" if np.array_equal(kp, o_kp) else "DIFFERS", np.setdiff1d(kp, o_kp)[:8], np.setdiff1d(o_kp, kp)[:8]))
@@ -223,7 +232,7 @@ def main():
             _, sc2 = det.compute()
             print("  the same call again, same handle: scores %s keypoints %s" % (helpers.same_bits(sc2, o_sc), np.array_equal(det.getKeypointsIndices(), o_kp)))
             fresh = kpl.KeypointLearningDetector()
-            configure(fresh, A, B, nms, rn, draws, dthr, thr, r, srt, fa)
+            configure(fresh, A, B, nms, rn, draws, dthr, thr, r, srt, fa, walk)
             fresh.setInputCloud(np.ascontiguousarray(xyz).reshape(-1, 3)); fresh.setNormals(np.ascontiguousarray(nrm).reshape(-1, 3))
             _, sc3 = fresh.compute()
             print("  the same call on a fresh handle: scores %s keypoints %s" % (helpers.same_bits(sc3, o_sc), np.array_equal(fresh.getKeypointsIndices(), o_kp)))
