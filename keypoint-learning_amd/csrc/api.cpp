@@ -111,6 +111,8 @@ struct kpl_detector {
     unsigned long long kf_seen_sum = 0, kf_seen_points = 0;     // DevState::kf_sum / kf_points at that read
     int lcap_hint = 0;            // sorted-search mode: keys per point the lists of the register-sort kernel need (0: not known = 128),
     double lcap_hint_radius = 0.0;    // ... for this feature radius
+    bool all_large_hint = false;  // sorted-search mode: the last call at that radius listed >= 90 % of the view's points for the collect / add kernels
+    int all_large_n = 0;
     double launched_radius = 0.0; // feature radius / points of the last scoring launch (what the next read-back describes)
     int launched_n = 0;
     float origin[3] = {0.0f, 0.0f, 0.0f};
@@ -212,6 +214,7 @@ FeatDesc make_feat(const kpl_params &p) {
     f.walk = 0;
     f.lanes = 2;
     f.lcap = 0;
+    f.all_large = 0;
     return f;
 }
 
@@ -427,6 +430,8 @@ int sync_status(kpl_detector *h, hipStream_t st) {
         const int seen = h->h_state->kf_max;
         h->lcap_hint = seen > 124 ? 128 : ((seen + 4 + 7) / 8) * 8;
         h->lcap_hint_radius = h->launched_radius;
+        h->all_large_hint = h->launched_n > 0 && (long long)h->h_state->large_seen * 4 >= (long long)h->launched_n;
+        h->all_large_n = h->launched_n;
         KPL_HIP(h, hipMemsetAsync((char *)h->dstate.p + offsetof(DevState, kf_max), 0, sizeof(int), st));
     }
     if (h->h_state->status == kStatusGridTooLarge)
@@ -493,7 +498,10 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
     v.key_cap = 0;
     FeatDesc feat = make_feat(h->prm);
     choose_walk(h, feat);
-    if (feat.sorted && h->lcap_hint > 0 && h->lcap_hint_radius == h->prm.radius_search) feat.lcap = h->lcap_hint;
+    if (feat.sorted && h->lcap_hint > 0 && h->lcap_hint_radius == h->prm.radius_search) {
+        feat.lcap = h->lcap_hint;
+        feat.all_large = h->all_large_hint && (long long)n * 4 >= (long long)h->all_large_n * 3 && (long long)n * 3 <= (long long)h->all_large_n * 4 ? 1 : 0;
+    }
     if (!feat.sorted && feat.walk == 1) {
         // two-pass walk: the accept words of every point's whole walk (8-byte entries in the array the sorted mode keeps its
         // keys in -- a view is in one mode or the other).  About one word per five neighbors on a surface (32 candidates

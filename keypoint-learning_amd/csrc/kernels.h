@@ -43,6 +43,8 @@ struct FeatDesc {
     int walk;        // 0: search and drain alternate, accept words in LDS (point_features); 1: two passes, the accept words of the whole walk through global memory (large neighborhoods)
     int lanes;       // lanes per point: 2 or 4
     int lcap;        // sorted-search mode: keys per point of the register-sort kernel's lists in LDS (<= 128; 0 = 128)
+    int all_large;   // sorted-search mode: every point goes to the collect / add kernels without trying the register sort first
+                     // (the handle's last call listed nearly all of them anyway -- after searching for most)
 };
 
 struct NmsDesc {
@@ -163,6 +165,7 @@ struct DevState {
     // sorted-search mode: the longest neighborhood the register-sort kernel scored since the host last read it (129: a point
     // whose list ran full and was deferred) -- the list capacity of the handle's next launch (api.cpp)
     int kf_max;
+    int large_seen;    // sorted-search mode: DevState::large_count of the last call (copied before it is re-armed)
     // two-pass walk (kernels.hip): entries handed out of each 32nd of the word list (ViewDev::sort_keys); zero between calls
     alignas(128) unsigned long long word_cursor[32];
 };

@@ -2559,7 +2559,9 @@ __global__ __launch_bounds__(kLanes) void feature_sorted_kernel(Batch b, int max
     // a point with a large neighborhood is scored by sorted_collect_kernel + sorted_add_kernel (below): no rows here, and
     // its column of the feature block is theirs
     const int own_cell = own_cell_population(v.ds->grid, v.cell_start, w);
-    const bool large = own_cell > kLargeCell, huge = own_cell > kHugeCell;
+    // (all_large: the handle's last call ended up listing nearly every point, most of them after a search that filled their
+    // register lists for nothing -- 1.5 of 7.6 ms for 8 x 200 k points at 10 mesh resolutions)
+    const bool large = own_cell > kLargeCell || (v.f.all_large && w.scoreable), huge = own_cell > kHugeCell;
     uint2 *ent = reinterpret_cast<uint2 *>(H + maxF * kPts);
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(ent + ecap * kPts);
     bool deferred = false;
@@ -4402,6 +4404,7 @@ __global__ __launch_bounds__(kScanBlock) void compact_scan_kernel(Batch b) {
                 }
                 v.ds->keys_needed = v.ds->key_cursor + wmax * kWordShards;
                 v.ds->key_cursor = 0ull;
+                v.ds->large_seen = v.ds->large_count;
                 v.ds->large_count = 0;
                 v.ds->huge_count = 0;
                 // every block of this launch has published, hence started, hence read the tag: the next call's may be set
