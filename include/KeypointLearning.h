@@ -196,6 +196,9 @@ public:
     // pcl::search::KdTree) selects FLANN's sorted order, no tree (pcl::Keypoint then makes an UNSORTED one,
     // whose traversal order cannot be reproduced) the engine's canonical order.  setSortedSearch overrides it.
     void setSortedSearch(bool sorted) { sorted_search_ = sorted ? 1 : 0; }
+    // How the engine walks a neighborhood (KPL_WALK_*, kpl.h): a choice of speed, never of result.  The default
+    // (KPL_WALK_AUTO) follows what the handle measured on its earlier calls, or the view's bounding box on a first one.
+    void setFeatureWalk(int walk, int lanes_per_point = 2) { if (handle_) kpl_set_feature_walk(handle_, walk, lanes_per_point); }
     bool getSortedSearch() const { return sorted_search_ >= 0 ? sorted_search_ != 0 : (this->tree_ && this->tree_->getSortedResults()); }
     const char *lastError() const { return handle_ ? kpl_last_error(handle_) : kpl_status_string(create_status_); }
 

@@ -91,8 +91,11 @@ enum { KPL_NEIGHBORS_CANONICAL = 0, KPL_NEIGHBORS_SORTED = 1 };
 
 /* How the feature kernels WALK the canonical order (never what they compute: every choice gives the same bits --
  * tests/test_gpu_walks.py).  AUTO (default): picked per launch from the mean number of neighbors per point that the
- * handle's own earlier calls measured (read back by kpl_sync_status; until then, and whenever the feature radius or
- * the size of the view changes, LANES with two lanes per point).
+ * handle's own earlier calls measured (read back by kpl_sync_status).  Until then, and whenever the feature radius or
+ * the size of the view changes: LANES with two lanes per point for the device entry points; the host entry points -- which
+ * have the points in hand, and which a drop-in TestDetector run calls exactly once -- estimate the number from the view's
+ * bounding box (pi r^2 x points / the product of its two largest extents: a 2.5D view is a surface) and take TWO_PASS on a
+ * first call already when that says 600 or more.
  *   LANES     search and drain alternate in one kernel, the accept words of a point in LDS (neighborhoods of up to a few
  *             hundred points)
  *   TWO_PASS  the accept words of a point's whole walk go through global memory, a second kernel drains every list in one
@@ -269,6 +272,8 @@ typedef struct kpl_timing {
     float nms_ms;         /* NMS + flag scan + compaction                                     */
     float feature_ms;     /* the histogram feature kernel (the dominant kernel)               */
     float forest_ms;      /* the forest kernel                                                */
+    int walk;             /* KPL_WALK_* the LAST call's feature stage took (-1: sorted order, or no call yet) */
+    int lanes_per_point;  /* ... and its lanes per point                                      */
 } kpl_timing;
 int kpl_enable_timing(kpl_detector *h, int enable);
 int kpl_get_timing(kpl_detector *h, kpl_timing *out);

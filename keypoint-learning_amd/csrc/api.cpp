@@ -8,6 +8,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstddef>
@@ -104,6 +105,7 @@ struct kpl_detector {
     // how the feature kernels walk the neighborhoods (never WHAT they compute): kpl_set_feature_walk, or -- automatic -- the
     // mean K_f the handle's previous calls measured (DevState::kf_sum / kf_points, read back in sync_status)
     int walk_forced = KPL_WALK_AUTO, lanes_forced = 0;
+    int last_walk = -1, last_lanes = 0;        // what the last launch took (kpl_timing)
     int scan_poll_limit = 1 << 22;   // kpl_debug_set_scan_poll_limit (per handle)
     double kf_hint = -1.0;        // mean neighbors per point of the calls before the last status read; < 0: not known
     double kf_hint_radius = 0.0;  // ... measured at this feature radius
@@ -388,21 +390,6 @@ int build_index(kpl_detector *h, hipStream_t st, bool auto_cell = false) {
     return KPL_OK;
 }
 
-// the index AND pos_of[]: compute() builds the index without the map when nothing of the call reads it
-int ensure_index(kpl_detector *h, hipStream_t st) {
-    if (!index_is_current(h)) return build_index(h, st);
-    if (!h->pos_of_valid) {
-        Batch b{};
-        b.nviews = 1;
-        int rc = prepare_index(h, false, b.view[0], st);
-        if (rc) return rc;
-        launch_pos_of(b, st);
-        KPL_HIP(h, hipGetLastError());
-        h->pos_of_valid = true;
-    }
-    return KPL_OK;
-}
-
 // waits for `st`, reads the device status of the last index build and turns it into a status
 // code; grows the cell tables when they were too small so that a retry succeeds
 int sync_status(kpl_detector *h, hipStream_t st) {
@@ -498,6 +485,8 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
     v.key_cap = 0;
     FeatDesc feat = make_feat(h->prm);
     choose_walk(h, feat);
+    h->last_walk = feat.sorted ? -1 : feat.walk;
+    h->last_lanes = feat.sorted ? 0 : feat.lanes;
     if (feat.sorted && h->lcap_hint > 0 && h->lcap_hint_radius == h->prm.radius_search) {
         feat.lcap = h->lcap_hint;
         feat.all_large = h->all_large_hint && (long long)n * 4 >= (long long)h->all_large_n * 3 && (long long)n * 3 <= (long long)h->all_large_n * 4 ? 1 : 0;
@@ -649,6 +638,42 @@ int normals_on_device(kpl_detector *h, int k, double radius, const float *viewpo
     return KPL_OK;
 }
 
+// A handle that has measured nothing yet for this radius and view size (a drop-in TestDetector run makes ONE call) gets an
+// estimate from what the host-buffer entry points have in hand -- the points: a 2.5D view is a surface, so the number of
+// neighbors within r is about pi r^2 x points per unit of area, the area about the product of the two largest extents of the
+// bounding box (cheff001 at the reference's default radius 20: 2 040 estimated, 2 293 measured; the 200 k-point synthetic
+// views at 6 mesh resolutions: 79 / 69).  Only the choice of the walk hangs on it (choose_walk), never a result, and the first
+// kpl_sync_status replaces it by the measurement.  One pass over the points, on the first call of a (radius, size) only.
+void estimate_neighborhood(kpl_detector *h, const void *xyz, size_t xs, int n) {
+    const double r = h->prm.radius_search;
+    const bool hint_fits = h->kf_hint >= 0.0 && h->kf_hint_radius == r && h->kf_hint_n > 0 &&
+                           (long long)n * 4 >= (long long)h->kf_hint_n * 3 && (long long)n * 3 <= (long long)h->kf_hint_n * 4;
+    if (hint_fits || n < 1024 || !(r > 0.0) || h->prm.neighbor_order != KPL_NEIGHBORS_CANONICAL || h->walk_forced != KPL_WALK_AUTO) return;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    long long finite = 0;
+    const char *base = static_cast<const char *>(xyz);
+    for (int i = 0; i < n; ++i) {
+        float p[3];
+        memcpy(p, base + (size_t)i * xs, 12);
+        if (!(std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]))) continue;
+        ++finite;
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = p[k] < lo[k] ? p[k] : lo[k];
+            hi[k] = p[k] > hi[k] ? p[k] : hi[k];
+        }
+    }
+    if (finite < 1024) return;
+    double e[3] = {(double)hi[0] - lo[0], (double)hi[1] - lo[1], (double)hi[2] - lo[2]};
+    std::sort(e, e + 3);
+    const double area = e[2] * e[1];
+    if (!(area > 0.0)) return;
+    const double estimate = 3.14159265358979 * r * r * (double)finite / area;
+    if (estimate < 1.5 * kTwoPassFromKf) return;   // a rough figure: only a clear case leaves the default before a measurement
+    h->kf_hint = estimate;
+    h->kf_hint_radius = r;
+    h->kf_hint_n = n;
+}
+
 int ensure_copy_stream(kpl_detector *h) {
     if (h->copy_stream) return KPL_OK;
     KPL_HIP(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
@@ -693,6 +718,7 @@ int upload_view(kpl_detector *h, const void *xyz, size_t xs, const void *nrm, si
     h->n = n;
     h->bound = true;
     h->index_valid = false;
+    estimate_neighborhood(h, xyz, xs, n);
     return KPL_OK;
 }
 
@@ -1268,6 +1294,7 @@ int kpl_detect_keypoints_staged(kpl_detector *h, int *kp_idx_out, float *kp_scor
     h->n = n;
     h->bound = true;
     h->index_valid = false;
+    if (n > 0) estimate_neighborhood(h, h->hs_xyz, h->hs_xs, n);      // a first call only; the copies are on their way meanwhile
     return detect_staged(h, n, nullptr, kp_idx_out, kp_scores_out, kp_cap, kp_count, n > 0 ? h->ev_nrm : nullptr);
 }
 
@@ -1327,6 +1354,8 @@ int kpl_get_timing(kpl_detector *h, kpl_timing *out) {
     }
     h->spans.clear();
     h->ev_used = 0;
+    out->walk = h->last_walk;
+    out->lanes_per_point = h->last_lanes;
     return KPL_OK;
 }
 

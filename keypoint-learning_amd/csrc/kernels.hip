@@ -1116,7 +1116,7 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts, co
 // per point where its longest neighborhood needs 1 260, and the waves of the densest cells -- 2.7 x the candidates, 1.5 x
 // the neighbors of the average wave -- run 3 600, alone on their SIMDs for the second half of the launch (measured with
 // in-kernel stamps: profiles/r05_notes.md).  Here the accept words of a point's WHOLE walk go to a list in global
-// memory first (search_point_words: nothing but the search, no LDS, deep prefetch), and a second kernel drains every list
+// memory first (search_point_words_staged: nothing but the search, the candidates staged in LDS once per wave), and a second kernel drains every list
 // in one go (drain_point_words): its rounds are those of the wave's longest neighborhood, once.
 //   word list of a wave   ViewDev::sort_keys (an array of 8-byte records that the sorted-search mode uses for its keys; a
 //                         view is in one mode or the other), one contiguous block per wave of the search kernel:
@@ -1132,110 +1132,12 @@ __device__ __forceinline__ int point_features(const float4 *__restrict__ pts, co
 constexpr int kWalkLanes = 0, kWalkTwoPass = 1;      // FeatDesc::walk
 constexpr int kWordShards = 32;
 
-// maximum over the lanes of the wave (every lane returns it)
-__device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d));
-    return v;
-}
-
-// Pass 1: the accept words of the point's whole walk -> list[e * kPts] (the caller has added the point's column).
-// Returns K_f; entries = the number of words stored.  `block` is called once, with the number of word steps of the wave
-// (an upper bound of every point's entries), and returns the wave's block of the list or nullptr.
-template <int G, class Block>
-__device__ __forceinline__ int search_point_words(const float4 *__restrict__ pts, const int *__restrict__ cell_start,
-                                                  const GridDesc &g, const FeatDesc &fin, float4 p, bool active,
-                                                  Block block, int &entries) {
-    static_assert(G == 2 || G == 4, "lanes per point");
-    constexpr int kPts = kLanes / G, kStepBits = kStepW * G, kSteps = 32 / kStepBits;
-    const int tid = threadIdx.x, pi = tid / G, gq = tid % G;
-    const float r2 = pin_f(fin.r2);
-    CellBox b = make_box(g, p.x, p.y, p.z, fin.rr);
-    b.hi[1] = min(b.hi[1], b.lo[1] + 3);
-    b.hi[2] = min(b.hi[2], b.lo[2] + 3);
-    const int ny = active ? b.hi[1] - b.lo[1] + 1 : 0, nz = active ? b.hi[2] - b.lo[2] + 1 : 0;
-    const int wny = __any(ny > 3) ? 4 : __any(ny > 2) ? 3 : __any(ny > 1) ? 2 : __any(ny > 0) ? 1 : 0;
-    const int wnz = __any(nz > 3) ? 4 : __any(nz > 2) ? 3 : __any(nz > 1) ? 2 : __any(nz > 0) ? 1 : 0;
-    const int t_max = max(cell_start[g.ncells] - 1, 0);
-    auto row_range = [&](int ky, int kz, int &r0, int &r1) {
-        const bool valid = (ky < ny) & (kz < nz);
-        const int row = valid ? ((b.lo[2] + kz) * g.dims[1] + b.lo[1] + ky) * g.dims[0] : 0;
-        const int x = ld4(cell_start, row + (valid ? b.lo[0] : 0));
-        const int y = ld4(cell_start, row + (valid ? b.hi[0] + 1 : 0));
-        r0 = valid ? x : 0;
-        r1 = valid ? y : 0;
-    };
-    // the word steps of the wave: every row slot costs it the words of its longest instance
-    int steps = 0;
-    for (int kz = 0; kz < wnz; ++kz)
-        for (int ky = 0; ky < wny; ++ky) {
-            int r0, r1;
-            row_range(ky, kz, r0, r1);
-            steps += wave_max_i((r1 - r0 + 31) >> 5);
-        }
-    entries = 0;
-    uint2 *list = block(steps);
-    if (list == nullptr) return 0;
-    list += pi;
-    int ky = 0, kz = 0;
-    bool slots_left = wny > 0 && wnz > 0;
-    int n0 = 0, n1 = 0;
-    if (slots_left) row_range(0, 0, n0, n1);
-    int t = 0, t1 = 0;                            // current row of the group: next candidate of lane 0, end
-    const int mine = kStepW * gq;                 // this lane's 4 candidates of a step start here
-    const int nib_shift = 4 * (G - 1 - gq);
-    // the candidates of a whole word are in flight while the word before is tested
-    Cand cur[kSteps], nxt[kSteps];
-#pragma unroll
-    for (int st = 0; st < kSteps; ++st) cur[st] = load_cand(pts, 0);
-    bool first_pending = true;
-    int kf = 0, ecnt = 0;
-    for (;;) {
-        if (!__any(t < t1)) {
-            if (!slots_left) break;
-            t = n0;
-            t1 = n1;
-#pragma unroll
-            for (int st = 0; st < kSteps; ++st) cur[st] = load_cand(pts, min(t + st * kStepBits + mine, t_max));
-            if (++ky == wny) {
-                ky = 0;
-                ++kz;
-            }
-            slots_left = kz < wnz;
-            if (slots_left) row_range(ky, kz, n0, n1);
-            continue;
-        }
-        const int wbase = t;
-#pragma unroll
-        for (int st = 0; st < kSteps; ++st) nxt[st] = load_cand(pts, min(t + 32 + st * kStepBits + mine, t_max));
-        unsigned w = 0u;
-#pragma unroll
-        for (int st = 0; st < kSteps; ++st) w = (w << kStepBits) | group_or<G>(search_step(0u, p, cur[st], r2) << nib_shift);
-#pragma unroll
-        for (int st = 0; st < kSteps; ++st) cur[st] = nxt[st];
-        t += 32;
-        const int nv = min(max(t1 - wbase, 0), 32);                  // candidates of this word inside the row
-        w = nv > 0 ? (w & (0xffffffffu << ((32 - nv) & 31))) : 0u;
-        kf += __popc(w);
-        if (first_pending & (w != 0u)) {                             // hpp:336
-            w = drop_first_bit(w);
-            first_pending = false;
-        }
-        if (w != 0u) {
-            if (gq == 0) list[ecnt * kPts] = make_uint2((unsigned)wbase, __brev(w));     // first candidate = bit 0
-            ++ecnt;
-        }
-    }
-    entries = ecnt;
-    return kf;
-}
-
 // Pass 1 for the cells that hold MANY points (what the two-pass walk exists for): with hundreds of points per cell the
 // 64 / G points of a wave -- consecutive storage positions -- nearly always share ONE cell, hence one search box, and walk
-// the same rows.  search_point_words lets every lane fetch its candidates itself: 8 twelve-byte loads per word and lane,
-// every lane at an address of its own -- the texture addresser of the CU takes them a lane at a time, and a kernel that
-// does nothing but search is bound by it (cheff001: 0.53 ms).  Here the wave fetches the candidates ONCE, for all its
-// points:
+// the same rows.  Were every lane to fetch its candidates itself (as point_features does): 8 twelve-byte loads per word
+// and lane, every lane at an address of its own -- the texture addresser of the CU takes them a lane at a time, and a kernel
+// that does nothing but search is bound by it (cheff001: 0.53 ms, measured in round 5).  Here the wave fetches the
+// candidates ONCE, for all its points:
 //   group    the points of the wave that lie in the same grid cell (usually all of them; a wave that straddles cells
 //            takes its groups one after the other).  Their boxes differ by a cell at most: the wave walks the UNION of
 //            them -- rows (cz, cy) ascending, every row the run of cells lo_x .. hi_x --, a superset of every point's
@@ -1243,9 +1145,9 @@ __device__ __forceinline__ int search_point_words(const float4 *__restrict__ pts
 //            coordinate and fails the distance test like any other candidate.
 //   stage    the row in windows of W consecutive storage positions, copied to LDS by the whole wave
 //            (global_load_lds_dwordx4: 1 KiB per instruction, no registers, all of a window in flight together)
-//   search   as in search_point_words -- 4 G candidates per step, accept words of 32 candidates, the first accepted
+//   search   as in point_features -- 4 G candidates per step, accept words of 32 candidates, the first accepted
 //            neighbor of a point dropped (hpp:336) -- but every group reads the SAME candidates, from LDS
-// The words of a point are cut at other positions than in search_point_words (rows start at the union's first cell);
+// The words of a point are cut at other positions than in point_features (rows start at the union's first cell);
 // the neighbors they stand for, and their order, are the same.
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void global_cvoid;
@@ -2481,7 +2383,7 @@ __global__ __launch_bounds__(kLanes) void feature_kernel(Batch b, int maxF, int 
 }
 
 // the same for the views whose neighborhoods are LARGE (FeatDesc::walk == kWalkTwoPass), first pass: the accept words of
-// every point's whole walk -> its wave's block of the word list (search_point_words); no LDS
+// every point's whole walk -> its wave's block of the word list (search_point_words_staged)
 constexpr int kSearchGroup = 8;        // lanes per point of the search pass: a word of 32 candidates is ONE step of the 8 lanes; 8 points per wave --
                                        // the waves of the densest cells walk 2.7 x the words of the average wave, the launch lasts as long as they do
 constexpr int kSearchWindow = 128;     // candidates per staged window (two windows of 2 KB of LDS per wave: the ~31 waves per CU of a 63 k-point view are resident together)

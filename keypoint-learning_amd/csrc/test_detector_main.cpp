@@ -63,7 +63,9 @@ const char *kUsage =
     "  --hostStaging                 setHostStaging(true): the setters copy cloud and normals into pinned buffers of the\n"
     "                                engine, compute() uploads them by DMA.\n"
     "  --sortedSearch                hand the detector a sorted search tree (setSearchMethod(pcl::search::KdTree(true))):\n"
-    "                                neighbors in ascending (distance, index) order instead of the engine's canonical order.\n";
+    "                                neighbors in ascending (distance, index) order instead of the engine's canonical order.\n"
+    "  --walk arg (=auto)            how the engine walks a neighborhood: auto, lanes2, lanes4, twopass2, twopass4\n"
+    "                                (setFeatureWalk; a choice of speed, the results are the same bits).\n";
 
 bool parse(int argc, char **argv, Options &o) {
     static const char *flags[] = {"help", "flipNormals", "subSampling", "radiusInMr", "json", "printResolution", "detectorNormals", "checkProtected", "sortedSearch", "hostStaging"};
@@ -272,6 +274,15 @@ int main(int argc, char **argv) {
     if (vm.has("sortedSearch"))          // the inherited pcl::Keypoint::setSearchMethod; KdTree's constructor default is sorted = true
         detector->setSearchMethod(pcl::search::KdTree<PointInT>::Ptr(new pcl::search::KdTree<PointInT>(true)));
     if (vm.has("hostStaging")) detector->setHostStaging(true);
+    if (vm.has("walk")) {
+        const std::string w = vm.str("walk", "auto");
+        if (w == "auto") detector->setFeatureWalk(KPL_WALK_AUTO);
+        else if (w == "lanes2") detector->setFeatureWalk(KPL_WALK_LANES, 2);
+        else if (w == "lanes4") detector->setFeatureWalk(KPL_WALK_LANES, 4);
+        else if (w == "twopass2") detector->setFeatureWalk(KPL_WALK_TWO_PASS, 2);
+        else if (w == "twopass4") detector->setFeatureWalk(KPL_WALK_TWO_PASS, 4);
+        else { fprintf(stderr, "the argument ('%s') for option '--walk' is invalid\n", w.c_str()); return -1; }
+    }
     auto t_set = std::chrono::steady_clock::now();
     detector->setInputCloud(cloud);
     if (!own_normals) detector->setNormals(normals);          // else: impl/KeypointLearning.hpp:125-148

@@ -71,10 +71,7 @@ def test_every_walk_on_awkward_views(kpl, oracle, cases, walk, lanes, case):
     assert np.array_equal(det.getKeypointsIndices(), o_kp)
 
 
-def test_the_automatic_walk_follows_what_the_handle_measured(kpl, cases, gold):
-    """first call: nothing known -> every lane for itself, two lanes per point; after it the handle knows ~2 300 neighbors
-    per point on this radius -> the two-pass walk (four lanes per point: a 63 k-point view); a small radius on the same
-    handle makes the hint stale -> back to the default, and its own measurement keeps it there."""
+def _cheff_detector(kpl, gold):
     det = kpl.KeypointLearningDetector()
     det.setNonMaxima(True)
     det.setNonMaxRadius(float(gold["r_nms"]))
@@ -82,20 +79,76 @@ def test_the_automatic_walk_follows_what_the_handle_measured(kpl, cases, gold):
     det.setPredictionThreshold(float(gold["thr"]))
     det.setRadiusSearch(float(gold["r_feat"]))
     assert det.loadForest(FOREST), det.lastError()
-    det.setInputCloud(gold["xyz"])
-    det.setNormals(gold["nrm"])
+    return det
+
+
+def test_the_automatic_walk_follows_what_the_handle_measured(kpl, cases, gold):
+    """device entry points, first call: nothing known -> every lane for itself, two lanes per point; after it the handle
+    knows ~2 300 neighbors per point on this radius -> the two-pass walk (four lanes per point); a small radius on the same
+    handle makes the hint stale -> back to the default, and its own measurement keeps it there."""
+    import torch
+    det = _cheff_detector(kpl, gold)
+    dev = torch.device("cuda", 0)
+    n = len(gold["xyz"])
+    dx, dn = torch.from_numpy(gold["xyz"]).to(dev), torch.from_numpy(gold["nrm"]).to(dev)
+    ds = torch.empty(n, dtype=torch.float32, device=dev)
+    dk = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+    det.bindCloudDevice(dx.data_ptr(), 12, dn.data_ptr(), 12, n)
     assert det.getFeatureWalk() == (kpl.WALK_LANES, 2, -1.0)
-    _, s1 = det.compute()
+
+    def run():
+        det.computeDevice(ds.data_ptr(), dk[1:].data_ptr(), n, dk[0:1].data_ptr())
+        assert det.syncStatus(None) == kpl.OK
+        t = det.getTiming()
+        return ds.cpu().numpy(), dk[1:1 + int(dk[0].item())].cpu().numpy(), (t["walk"], t["lanes_per_point"])
+    s1, k1, took1 = run()
+    assert took1 == (kpl.WALK_LANES, 2)
     walk, lanes, kf = det.getFeatureWalk()
     assert walk == kpl.WALK_TWO_PASS and lanes == 4 and 1500 < kf < 3500, (walk, lanes, kf)
-    _, s2 = det.compute()                                        # ... through the two-pass walk now
+    s2, k2, took2 = run()                                        # ... through the two-pass walk now
+    assert took2 == (kpl.WALK_TWO_PASS, 4)
     assert cases.same_bits(s1, gold["scores_canonical"]) and cases.same_bits(s2, gold["scores_canonical"])
-    assert np.array_equal(det.getKeypointsIndices(), gold["kp_canonical"])
+    assert np.array_equal(k1, gold["kp_canonical"]) and np.array_equal(k2, gold["kp_canonical"])
     det.setRadiusSearch(float(gold["r_feat"]) / 5.0)             # ~1/25 of the neighbors: the hint no longer applies
     assert det.getFeatureWalk()[:2] == (kpl.WALK_LANES, 2)
-    det.compute()
+    _, _, took3 = run()
+    assert took3 == (kpl.WALK_LANES, 2)
     walk, lanes, kf = det.getFeatureWalk()
     assert walk == kpl.WALK_LANES and lanes == 2 and 20 < kf < 400, (walk, lanes, kf)
+
+
+@pytest.mark.parametrize("staging", [False, True])
+def test_a_first_host_call_estimates_the_neighborhood_from_the_bounding_box(kpl, oracle, cases, gold, staging):
+    """a drop-in TestDetector run makes ONE call on a fresh handle: the host entry points have the points in hand and
+    estimate the neighbors per point from the view's bounding box -- cheff001 at the reference's default radius takes the
+    two-pass walk on its very first call (and gives the golden bits); a 6-mesh-resolution view (~70 neighbors) does not."""
+    def first_call(det, xyz, nrm):
+        if staging:
+            sx, sn = det.hostStaging(len(xyz))
+            sx[:], sn[:] = xyz, nrm
+            det.computeStaged()
+            scores = None
+        else:
+            det.setInputCloud(xyz)
+            det.setNormals(nrm)
+            _, scores = det.compute()
+        t = det.getTiming()
+        return scores, (t["walk"], t["lanes_per_point"])
+    det = _cheff_detector(kpl, gold)
+    scores, took = first_call(det, gold["xyz"], gold["nrm"])
+    assert took == (kpl.WALK_TWO_PASS, 4)
+    if scores is not None:
+        assert cases.same_bits(scores, gold["scores_canonical"])
+    assert np.array_equal(det.getKeypointsIndices(), gold["kp_canonical"])
+    A, B = 5, 6
+    xyz, nrm = cases.cloud()
+    mr = cases.resolution()
+    small = kpl.KeypointLearningDetector()
+    small.setNAnnulus(A); small.setNBins(B); small.setNonMaxima(True); small.setNonMaxRadius(float(np.float32(4 * mr)))
+    small.setNonMaximaDrawsRemove(False); small.setPredictionThreshold(0.6); small.setRadiusSearch(float(np.float32(6 * mr)))
+    cases.load_arrays(small, cases.trained_forest(A, B))
+    _, took = first_call(small, xyz, nrm)
+    assert took == (kpl.WALK_LANES, 2)
 
 
 def test_two_pass_word_list_grows_through_retry(kpl, oracle, cases):
