@@ -669,6 +669,9 @@ void estimate_neighborhood(kpl_detector *h, const void *xyz, size_t xs, int n) {
     if (!(area > 0.0)) return;
     const double estimate = 3.14159265358979 * r * r * (double)finite / area;
     if (estimate < 1.5 * kTwoPassFromKf) return;   // a rough figure: only a clear case leaves the default before a measurement
+    // ... and a VOLUME of points is not a surface (a million points in a cube, r = 1/50 of its edge: 1 260 estimated, 33 real):
+    // the two-pass walk sizes its word lists by the hint, so an estimate is not allowed to ask for more than 1 GiB of them
+    if ((double)n * (estimate * 0.3 + 96.0) * 8.0 > 1073741824.0) return;
     h->kf_hint = estimate;
     h->kf_hint_radius = r;
     h->kf_hint_n = n;
