@@ -494,15 +494,19 @@ def main():
         # sorted order, the one order a PCL build can be compared with bit for bit (tests/test_gpu_sorted.py holds the parity)
         for d in dets[:nb]:
             d.setSortedSearch(True)
-        for _ in range(3):
-            run_group(0)
-        torch.cuda.synchronize()
+        for _ in range(3):       # (kpl_sync_status: the deferred status, growth of the key array on RETRY -- and the hints of
+            run_group(0)         # the sorted mode, list capacity and all-large, which a handle takes from its earlier calls)
+            torch.cuda.synchronize()
+            rcs = [d.syncStatus(None) for d in dets[:nb]]
+        assert all(rc == kpl.OK for rc in rcs), rcs
         dets[0].enableTiming(True)
         c0 = time.perf_counter()
         for _ in range(20):
             run_group(0)
         torch.cuda.synchronize()
         sorted_ms = (time.perf_counter() - c0) * 1e3 / 20
+        rcs = [d.syncStatus(None) for d in dets[:nb]]
+        assert all(rc == kpl.OK for rc in rcs), rcs
         t_sorted = dets[0].getTiming()
         dets[0].enableTiming(False)
         for d in dets[:nb]:
