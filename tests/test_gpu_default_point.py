@@ -82,6 +82,25 @@ def test_test_detector_with_no_radius_options_runs_the_reference_defaults(tmp_pa
     assert np.array_equal(got[:, 3], gold["scores_" + order][kp])
 
 
+@pytest.mark.parametrize("walk", ["auto", "lanes2", "lanes4", "twopass2", "twopass4"])
+def test_test_detector_walk_option_changes_no_output(tmp_path, gold, walk):
+    """--walk (setFeatureWalk of the drop-in class): whatever walk is forced, the keypoint file is the oracle's; an unknown
+    value is refused like any invalid argument"""
+    cloud, kp_file = str(tmp_path / "cheff001.pcd"), str(tmp_path / "kp.pcd")
+    _write_ascii_pcd(cloud, gold["xyz"])
+    out = subprocess.run([EXE, "--pathCloud", cloud, "--pathRF", FOREST, "--pathKP", kp_file, "--json", "--walk", walk],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    kp = gold["kp_canonical"]
+    got = _read_keypoints(kp_file)
+    assert len(got) == len(kp)
+    assert np.array_equal(got[:, :3], gold["xyz"][kp])
+    assert np.array_equal(got[:, 3], gold["scores_canonical"][kp])
+    if walk == "auto":
+        bad = subprocess.run([EXE, "--pathCloud", cloud, "--pathRF", FOREST, "--walk", "sideways"], capture_output=True, text=True, timeout=900)
+        assert bad.returncode != 0 and "--walk" in bad.stderr
+
+
 def test_detect_views_at_the_default_operating_point_sorted(tmp_path, gold):
     """DetectViews (C++, batches + RCCL gather) with its defaults = the reference main's, sorted search: the first round needs
     KPL_ERR_RETRY for the key array (kpl_sync_status grows it), the keypoint files equal the oracle's sorted result"""

@@ -1,4 +1,4 @@
-"""tools/time_sorted.py [canonical] [rmul=<radius in mesh resolutions, default 6>]: the feature stage of one batch of 8 synthetic 200 k-point views (the bench workload) in
+"""tools/time_sorted.py [canonical] [noshuffle] [rmul=<radius in mesh resolutions, default 6>]: the feature stage of one batch of 8 synthetic 200 k-point views (the bench workload) in
 sorted-search mode, timed with the handle's events.  Timing only -- used with scratch builds of ablated kernels
 (KPL_LIB_PATH=build/variants/libkpl_<name>.so, tools/build_variant.sh) to see where the time of the stage goes."""
 import importlib
@@ -26,7 +26,8 @@ def main():
     dets, keep, ps, pk, pc = [], [], [], [], []
     for k in range(nb):
         xyz, nrm = synth.make_cloud(nx, ny, seed=1 + k)
-        xyz, nrm = synth.shuffle_cloud(xyz, nrm, 1001 + k)
+        if "noshuffle" not in sys.argv[1:]:           # (scan order instead of a random one: the caller's arrays, which the sorted mode
+            xyz, nrm = synth.shuffle_cloud(xyz, nrm, 1001 + k)      # reads the normals of the neighbors from by ORIGINAL index, become local)
         n = len(xyz)
         det = kpl.KeypointLearningDetector(device=0)
         mr = det.cloudResolution(xyz)
