@@ -170,7 +170,7 @@ def test_device_resident_entry_points(kpl, oracle, cases):
     det = detector(kpl, 5, 6, r, rn, thr, CFG_FOREST)
     dev = torch.device("cuda", 0)
     n = len(xyz)
-    dx, dn = torch.from_numpy(xyz).to(dev), torch.from_numpy(nrm).to(dev)
+    dx, dn = torch.from_numpy(np.array(xyz)).to(dev), torch.from_numpy(np.array(nrm)).to(dev)
     ds = torch.empty(n, dtype=torch.float32, device=dev)
     dk = torch.empty(n, dtype=torch.int32, device=dev)
     dc = torch.zeros(1, dtype=torch.int32, device=dev)
