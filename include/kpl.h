@@ -104,7 +104,8 @@ enum { KPL_NEIGHBORS_CANONICAL = 0, KPL_NEIGHBORS_SORTED = 1 };
  * lanes_per_point: 2 or 4. */
 enum { KPL_WALK_AUTO = -1, KPL_WALK_LANES = 0, KPL_WALK_TWO_PASS = 1 };
 int kpl_set_feature_walk(kpl_detector *h, int walk, int lanes_per_point);
-/* what the next launch would use, and the mean neighbors per point it is based on (< 0: not measured yet) */
+/* what the next launch would use, and the mean neighbors per point it is based on (measured by the handle's last call, or
+ * estimated from the bounding box by a first host call; < 0: neither yet) */
 int kpl_get_feature_walk(const kpl_detector *h, int *walk, int *lanes_per_point, double *mean_neighbors);
 
 /* Test hook, per handle: look-back polls of the keypoint compaction's single-pass scan before the call is failed with
