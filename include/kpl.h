@@ -19,7 +19,9 @@
  * the stream of the earlier *_device call (kpl_sync_status or hipStreamSynchronize) -- nothing orders them
  * implicitly, not even the null stream (and a clear or copy the CALLER issues on the null stream -- hipMemset, hipMemcpy --
  * is not ordered against a non-blocking stream either, nor complete when it returns: hipDeviceSynchronize() before handing
- * such a buffer to a *_device entry point on another stream).
+ * such a buffer to a *_device entry point on another stream).  The same holds for two *_device calls of ONE handle on
+ * DIFFERENT streams: the scratch -- and its growth, which is ordered by the stream of the call that grows it -- belongs to
+ * the handle, so wait for the earlier stream first (one handle per stream is the intended use).
  * There is NO CPU fallback: without a usable HIP device every compute call fails with
  * KPL_ERR_DEVICE.
  */
@@ -128,7 +130,7 @@ typedef struct kpl_stats {
 /* ---- lifetime ------------------------------------------------------------------------- */
 /* ctor of KeypointLearningDetector (KeypointLearning.h:81-90); `device` = HIP device ordinal. */
 int kpl_create(kpl_detector **out, int device);
-/* dtor (KeypointLearning.h:93-97). */
+/* dtor (KeypointLearning.h:93-97).  Waits for the device (kernels of the handle's last *_device calls may still be running). */
 void kpl_destroy(kpl_detector *h);
 const char *kpl_last_error(const kpl_detector *h);
 const char *kpl_status_string(int status);

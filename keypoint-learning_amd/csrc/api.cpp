@@ -71,8 +71,12 @@ struct DevBuf {
     }
     void release() {
         if (p) {
-            if (pooled) (void)hipFreeAsync(p, nullptr);
-            else (void)hipFree(p);
+            if (pooled) {       // hipFree waits for every stream of the device before it releases; hipFreeAsync does not
+                (void)hipDeviceSynchronize();
+                (void)hipFreeAsync(p, nullptr);
+            } else {
+                (void)hipFree(p);
+            }
         }
         p = nullptr;
         cap = 0;
@@ -113,7 +117,7 @@ struct kpl_detector {
     unsigned long long kf_seen_sum = 0, kf_seen_points = 0;     // DevState::kf_sum / kf_points at that read
     int lcap_hint = 0;            // sorted-search mode: keys per point the lists of the register-sort kernel need (0: not known = 128),
     double lcap_hint_radius = 0.0;    // ... for this feature radius
-    bool all_large_hint = false;  // sorted-search mode: the last call at that radius listed >= 90 % of the view's points for the collect / add kernels
+    bool all_large_hint = false;  // sorted-search mode: the last call at that radius listed a quarter of the view's points or more for the collect / add kernels
     int all_large_n = 0;
     double launched_radius = 0.0; // feature radius / points of the last scoring launch (what the next read-back describes)
     int launched_n = 0;
@@ -886,6 +890,9 @@ int kpl_create(kpl_detector **out, int device) {
 void kpl_destroy(kpl_detector *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    // kernels of the handle's last calls may still be running, on streams this function knows nothing about: the arrays that
+    // came from hipMallocAsync are released with hipFreeAsync, which -- unlike the hipFree of earlier rounds -- waits for nothing
+    (void)hipDeviceSynchronize();
     DevBuf *bufs[] = {&h->org_scratch, &h->d_nodes, &h->stage_xyz, &h->stage_nrm, &h->stage_idx, &h->stage_feat,
                       &h->dstate, &h->cid, &h->btable, &h->cell_start, &h->tmp_idx, &h->scan_tmp,
                       &h->pts, &h->nrm, &h->pos_of, &h->score_sorted, &h->flags, &h->prefix, &h->stats,
