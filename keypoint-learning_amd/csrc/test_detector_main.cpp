@@ -304,11 +304,14 @@ int main(int argc, char **argv) {
     if (!json) printf("Keypoint computed\n");
 
     if (vm.has("pathKP")) save_pcd_ascii(vm.str("pathKP", ""), *keypoint);
+    int walk_lanes = 0;
+    const int walk_taken = detector->getFeatureWalk(&walk_lanes);
     if (json)
         printf("{\"points\": %zu, \"keypoints\": %zu, \"mr\": %.9g, \"radiusFeatures\": %.9g, \"radiusNMS\": %.9g, "
                "\"threshold\": %.9g, \"annuli\": %d, \"bins\": %d, \"prepare_s\": %.6f, \"set_s\": %.6f, \"compute_first_s\": %.6f, "
-               "\"compute_s\": %.6f}\n",
-               cloud->size(), keypoint->size(), mr, radius_features, radius_nms, threshold, annuli, bins, prep_s, set_s, first_s, warm_s);
+               "\"compute_s\": %.6f, \"walk\": \"%s\", \"lanes_per_point\": %d}\n",
+               cloud->size(), keypoint->size(), mr, radius_features, radius_nms, threshold, annuli, bins, prep_s, set_s, first_s, warm_s,
+               walk_taken == KPL_WALK_TWO_PASS ? "two-pass" : walk_taken == KPL_WALK_LANES ? "lanes" : "sorted", walk_lanes);
     else
         printf("%zu keypoints out of %zu points (compute: %.3f ms)\nDONE\n", keypoint->size(), cloud->size(), warm_s * 1e3);
     return 0;

@@ -91,6 +91,9 @@ def test_test_detector_walk_option_changes_no_output(tmp_path, gold, walk):
     out = subprocess.run([EXE, "--pathCloud", cloud, "--pathRF", FOREST, "--pathKP", kp_file, "--json", "--walk", walk],
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
+    info = json.loads(out.stdout.strip().splitlines()[-1])
+    took = {"auto": ("two-pass", 4), "lanes2": ("lanes", 2), "lanes4": ("lanes", 4), "twopass2": ("two-pass", 2), "twopass4": ("two-pass", 4)}[walk]
+    assert (info["walk"], info["lanes_per_point"]) == took         # auto: ~2 300 neighbors per point, known from the first call on
     kp = gold["kp_canonical"]
     got = _read_keypoints(kp_file)
     assert len(got) == len(kp)

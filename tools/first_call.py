@@ -33,7 +33,7 @@ def main():
                     print(out.stderr[-2000:])
                     return 1
                 row = json.loads(out.stdout.strip().splitlines()[-1])
-                row["walk"] = walk
+                row["walk_option"] = walk
                 print(json.dumps(row), flush=True)
     return 0
 
