@@ -199,7 +199,8 @@ public:
     // How the engine walks a neighborhood (KPL_WALK_*, kpl.h): a choice of speed, never of result.  The default
     // (KPL_WALK_AUTO) follows what the handle measured on its earlier calls, or the view's bounding box on a first one.
     void setFeatureWalk(int walk, int lanes_per_point = 2) { if (handle_) kpl_set_feature_walk(handle_, walk, lanes_per_point); }
-    // ... and what the last compute() took (KPL_WALK_LANES / KPL_WALK_TWO_PASS; -1: sorted order, or no call yet)
+    // ... and what the last compute() took (KPL_WALK_LANES / KPL_WALK_TWO_PASS; -1: sorted order, or no call yet).  Read through
+    // kpl_get_timing, which also hands out -- and clears -- the per-phase times if kpl_enable_timing was switched on
     int getFeatureWalk(int *lanes_per_point = nullptr) const {
         kpl_timing t;
         if (!handle_ || kpl_get_timing(handle_, &t) != KPL_OK) return -1;
