@@ -44,7 +44,7 @@ class ForestSummary(C.Structure):
 class Timing(C.Structure):
     _fields_ = [("calls", C.c_int), ("index_ms", C.c_float), ("score_ms", C.c_float),
                 ("nms_ms", C.c_float), ("feature_ms", C.c_float), ("forest_ms", C.c_float),
-                ("walk", C.c_int), ("lanes_per_point", C.c_int)]
+                ("walk", C.c_int), ("lanes_per_point", C.c_int), ("accept_words", C.c_int)]
 
 
 class Stats(C.Structure):
@@ -488,7 +488,8 @@ class KeypointLearningDetector:
         t = Timing()
         self._check(self._lib.kpl_get_timing(self._h, C.byref(t)))
         return {"calls": t.calls, "index_ms": t.index_ms, "score_ms": t.score_ms, "nms_ms": t.nms_ms,
-                "feature_ms": t.feature_ms, "forest_ms": t.forest_ms, "walk": t.walk, "lanes_per_point": t.lanes_per_point}
+                "feature_ms": t.feature_ms, "forest_ms": t.forest_ms, "walk": t.walk, "lanes_per_point": t.lanes_per_point,
+                "accept_words": t.accept_words}
 
     def collectStats(self, stream=None):
         self._push()

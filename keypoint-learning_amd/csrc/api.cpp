@@ -109,7 +109,7 @@ struct kpl_detector {
     // how the feature kernels walk the neighborhoods (never WHAT they compute): kpl_set_feature_walk, or -- automatic -- the
     // mean K_f the handle's previous calls measured (DevState::kf_sum / kf_points, read back in sync_status)
     int walk_forced = KPL_WALK_AUTO, lanes_forced = 0;
-    int last_walk = -1, last_lanes = 0;        // what the last launch took (kpl_timing)
+    int last_walk = -1, last_lanes = 0, last_words = 0;        // what the last launch took (kpl_timing)
     int scan_poll_limit = 1 << 22;   // kpl_debug_set_scan_poll_limit (per handle)
     double kf_hint = -1.0;        // mean neighbors per point of the calls before the last status read; < 0: not known
     double kf_hint_radius = 0.0;  // ... measured at this feature radius
@@ -219,6 +219,7 @@ FeatDesc make_feat(const kpl_params &p) {
     f.sorted = p.neighbor_order == KPL_NEIGHBORS_SORTED ? 1 : 0;
     f.walk = 0;
     f.lanes = 2;
+    f.words = 0;
     f.lcap = 0;
     f.all_large = 0;
     return f;
@@ -233,6 +234,7 @@ FeatDesc make_feat(const kpl_params &p) {
 // 1 900; 500 k points: 1.11 against 1.12 at 376, 4.96 against 5.51 at 1 690; cheff001 at the reference's default radius,
 // K_f = 2 293: 1.09 against 1.78 ms) -- one drain per point instead of one per 24 accept words of the fullest list of the wave.
 constexpr double kTwoPassFromKf = 400.0;
+constexpr double kShortListsBelowKf = 80.0, kMediumListsBelowKf = 140.0;   // mean neighbors per point up to which 12 / 16 accept words are used
 void choose_walk(const kpl_detector *h, FeatDesc &f) {
     f.walk = 0;
     f.lanes = 2;
@@ -247,6 +249,9 @@ void choose_walk(const kpl_detector *h, FeatDesc &f) {
         f.walk = 1;
         f.lanes = 4;
     }
+    // the one-kernel walk: how many accept words a point collects between two drains (kernels.hip accept_words: small
+    // neighborhoods run 8-10 % faster with short lists, large ones 13-17 % slower)
+    if (hint_fits && f.walk == 0) f.words = h->kf_hint <= kShortListsBelowKf ? 12 : h->kf_hint <= kMediumListsBelowKf ? 16 : 0;
 }
 
 NmsDesc make_nms(const kpl_params &p) {
@@ -491,6 +496,7 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
     choose_walk(h, feat);
     h->last_walk = feat.sorted ? -1 : feat.walk;
     h->last_lanes = feat.sorted ? 0 : feat.lanes;
+    h->last_words = (!feat.sorted && feat.walk == 0) ? (feat.words > 0 ? feat.words : 24) : 0;
     if (feat.sorted && h->lcap_hint > 0 && h->lcap_hint_radius == h->prm.radius_search) {
         feat.lcap = h->lcap_hint;
         feat.all_large = h->all_large_hint && (long long)n * 4 >= (long long)h->all_large_n * 3 && (long long)n * 3 <= (long long)h->all_large_n * 4 ? 1 : 0;
@@ -1366,6 +1372,7 @@ int kpl_get_timing(kpl_detector *h, kpl_timing *out) {
     h->ev_used = 0;
     out->walk = h->last_walk;
     out->lanes_per_point = h->last_lanes;
+    out->accept_words = h->last_words;
     return KPL_OK;
 }
 

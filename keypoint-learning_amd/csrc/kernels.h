@@ -42,6 +42,7 @@ struct FeatDesc {
     // how the canonical order is walked -- never WHAT is computed: every combination gives the same bits (kernels.hip)
     int walk;        // 0: search and drain alternate, accept words in LDS (point_features); 1: two passes, the accept words of the whole walk through global memory (large neighborhoods)
     int lanes;       // lanes per point: 2 or 4
+    int words;       // one-kernel walk: accept words a point collects between two drains (0 = 24; fewer for small neighborhoods, kernels.hip accept_words)
     int lcap;        // sorted-search mode: keys per point of the register-sort kernel's lists in LDS (<= 128; 0 = 128)
     int all_large;   // sorted-search mode: every point goes to the collect / add kernels without trying the register sort first
                      // (the handle's last call listed nearly all of them anyway -- after searching for most)

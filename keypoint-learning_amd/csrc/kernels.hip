@@ -4464,9 +4464,16 @@ static int cu_count() {
 // and every launch with larger neighborhoods 10-25 % slower; the host cannot know the neighborhood size.
 // Fewer words for the largest histograms so that a handful of waves still fit a CU (160 KB of LDS).
 constexpr int kLdsPerCu = 160 * 1024;
+// Round 5: the host now DOES know the neighborhood size (FeatDesc::words, chosen by api.cpp from the mean K_f the handle's
+// last call measured), and the kernel has come down to 96 registers since, so that fewer words are more resident waves (24
+// words: 10 KB per wave = 4 waves per SIMD; 16 and fewer: 5) -- and a smaller list also makes the waves of a launch alternate
+// between search (texture path) and drain (VALU) at different times instead of all searching first.  Feature kernel alone
+// on the GPU, 8 x 200 k points at K_f = 69: 24 words 0.625 ms, 16: 0.588, 14: 0.566, 12: 0.563; the bench 1 900 -> 1 950
+// Mpoints/s.  One 500 k-point view, 24 / 16 / 12 words: K_f = 32: 0.146 / 0.140 / 0.135 ms, 69: 0.217 / 0.208 / 0.200, 124:
+// 0.325 / 0.310 / 0.340, 192: 0.464 / 0.525 / 0.542; cheff000 (K_f = 100, up to 159): 12 words cost 7 %, 16 nothing.
 template <int G>
-static int accept_words(int F) {
-    int e = 24;
+static int accept_words(int F, int wanted = 0) {
+    int e = wanted > 0 && wanted < 24 ? wanted : 24;
     while (e > 4 && feature_lds_bytes<G>(F, e) * 6 > (size_t)kLdsPerCu) e -= 4;
     return e;
 }
@@ -4518,15 +4525,26 @@ void launch_feature_stage(const Batch &b, hipStream_t st) {
         else if (f.walk == kWalkTwoPass) (f.lanes == 4 ? two4 : two2) = true;
         else (f.lanes == 4 ? lanes4 : lanes2) = true;
     }
+    // accept words per point: what the views of that walk ask for (the largest of them: a launch has one list capacity)
+    auto words_wanted = [&](int lanes) {
+        int e = 0;
+        for (int v = 0; v < b.nviews; ++v) {
+            const FeatDesc &f = b.view[v].f;
+            if (f.sorted || f.walk != kWalkLanes || f.lanes != lanes) continue;
+            const int w = f.words > 0 ? f.words : 24;
+            e = w > e ? w : e;
+        }
+        return e;
+    };
     if (lanes2) {
-        const int ecap = accept_words<2>(maxF);
+        const int ecap = accept_words<2>(maxF, words_wanted(2));
         const size_t lds = feature_lds_bytes<2>(maxF, ecap);
         const dim3 grid(div_up(n, kLanes) * 2, b.nviews);
         if (stats) feature_kernel<true, 2><<<grid, kLanes, lds, st>>>(b, maxF, ecap);
         else feature_kernel<false, 2><<<grid, kLanes, lds, st>>>(b, maxF, ecap);
     }
     if (lanes4) {
-        const int ecap = accept_words<4>(maxF);
+        const int ecap = accept_words<4>(maxF, words_wanted(4));
         const size_t lds = feature_lds_bytes<4>(maxF, ecap);
         const dim3 grid(div_up(n, kLanes) * 4, b.nviews);
         if (stats) feature_kernel<true, 4><<<grid, kLanes, lds, st>>>(b, maxF, ecap);

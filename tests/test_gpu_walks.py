@@ -151,6 +151,34 @@ def test_a_first_host_call_estimates_the_neighborhood_from_the_bounding_box(kpl,
     assert took == (kpl.WALK_LANES, 2)
 
 
+def test_short_accept_lists_follow_the_measured_neighborhood(kpl, oracle, cases):
+    """the one-kernel walk collects up to 24 accept words per point between two drains until the handle has measured the
+    neighborhood: ~70 neighbors per point -> 12 words from the second call on (more resident waves, search and drain of the
+    waves out of step), ~130 -> 16; every capacity gives the oracle's bits"""
+    A, B = 5, 6
+    xyz, nrm = cases.cloud()
+    mr = cases.resolution()
+    fa = cases.trained_forest(A, B)
+    of = cases.oracle_forest(fa)
+    for rmul, words, lo, hi in [(6.0, 12, 40, 80), (8.0, 16, 80, 140), (11.0, 24, 140, 400)]:
+        r, rn, thr = float(np.float32(rmul * mr)), float(np.float32(4 * mr)), float(np.float32(0.6))
+        det = kpl.KeypointLearningDetector()
+        det.setNAnnulus(A); det.setNBins(B); det.setNonMaxima(True); det.setNonMaxRadius(rn)
+        det.setNonMaximaDrawsRemove(False); det.setPredictionThreshold(thr); det.setRadiusSearch(r)
+        cases.load_arrays(det, fa)
+        det.setInputCloud(xyz)
+        det.setNormals(nrm)
+        o_scores, o_kp = oracle.detect(xyz, nrm, A, B, r, rn, thr, of)
+        for call in range(2):
+            _, scores = det.compute()
+            t = det.getTiming()
+            assert (t["walk"], t["lanes_per_point"]) == (kpl.WALK_LANES, 2)
+            assert t["accept_words"] == (24 if call == 0 else words), (rmul, call, t, det.getFeatureWalk())
+            assert cases.same_bits(scores, o_scores)
+            assert np.array_equal(det.getKeypointsIndices(), o_kp)
+        assert lo < det.getFeatureWalk()[2] <= hi, det.getFeatureWalk()
+
+
 def test_two_pass_word_list_grows_through_retry(kpl, oracle, cases):
     """a random volume, ~7 500 neighbors and ~30 000 candidates per point -- about 1 000 accept words per point where a
     fresh handle reserves ~500: the device entry point cannot grow the list itself, the first call reports KPL_ERR_RETRY
