@@ -278,7 +278,7 @@ typedef struct kpl_timing {
     int walk;             /* KPL_WALK_* the LAST call's feature stage took (-1: sorted order, or no call yet) */
     int lanes_per_point;  /* ... and its lanes per point                                      */
     int accept_words;     /* ... and, for KPL_WALK_LANES, the accept words a point collected between two drains as asked for
-                             (24, or 16 / 12 once the handle has measured a small neighborhood; 0 otherwise) */
+                             (24, or 20 / 16 / 12 once the handle has measured a smaller neighborhood; 0 otherwise) */
 } kpl_timing;
 int kpl_enable_timing(kpl_detector *h, int enable);
 int kpl_get_timing(kpl_detector *h, kpl_timing *out);

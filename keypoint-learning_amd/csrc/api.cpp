@@ -234,7 +234,10 @@ FeatDesc make_feat(const kpl_params &p) {
 // 1 900; 500 k points: 1.11 against 1.12 at 376, 4.96 against 5.51 at 1 690; cheff001 at the reference's default radius,
 // K_f = 2 293: 1.09 against 1.78 ms) -- one drain per point instead of one per 24 accept words of the fullest list of the wave.
 constexpr double kTwoPassFromKf = 400.0;
-constexpr double kShortListsBelowKf = 80.0, kMediumListsBelowKf = 140.0;   // mean neighbors per point up to which 12 / 16 accept words are used
+// mean neighbors per point up to which 12 / 16 / 20 accept words are used (one 500 k-point view, feature stage in ms at 12 / 16 /
+// 20 / 24 words -- K_f = 48: 0.166 / 0.173 / 0.172 / 0.180; 95: 0.260 / 0.257 / 0.257 / 0.271; 124: 0.342 / 0.313 / 0.312 / 0.327;
+// 157: 0.453 / 0.406 / 0.376 / 0.393; 192: 0.546 / 0.529 / 0.479 / 0.466; profiles/r05_accept_words.jsonl)
+constexpr double kWords12BelowKf = 80.0, kWords16BelowKf = 140.0, kWords20BelowKf = 175.0;
 void choose_walk(const kpl_detector *h, FeatDesc &f) {
     f.walk = 0;
     f.lanes = 2;
@@ -251,7 +254,8 @@ void choose_walk(const kpl_detector *h, FeatDesc &f) {
     }
     // the one-kernel walk: how many accept words a point collects between two drains (kernels.hip accept_words: small
     // neighborhoods run 8-10 % faster with short lists, large ones 13-17 % slower)
-    if (hint_fits && f.walk == 0) f.words = h->kf_hint <= kShortListsBelowKf ? 12 : h->kf_hint <= kMediumListsBelowKf ? 16 : 0;
+    if (hint_fits && f.walk == 0)
+        f.words = h->kf_hint <= kWords12BelowKf ? 12 : h->kf_hint <= kWords16BelowKf ? 16 : h->kf_hint <= kWords20BelowKf ? 20 : 0;
 }
 
 NmsDesc make_nms(const kpl_params &p) {
