@@ -44,6 +44,12 @@ out = {"steps": len(feat), "ms_per_step": span / len(feat) / 1e6,
        "other_kernels_running_frac": covered(other, 1) / span,
        "feature_avg_ms": sum(b - a for a, b, _ in feat) / len(feat) / 1e6}
 print(json.dumps(out))
+# the dispatches of two steps in the middle of the timed region, in start order: offset, duration (us), kernel
+mid = feat[len(feat) // 2][0]
+seq = [e for e in ev if e[0] >= mid and e[0] < mid + int(2.2 * span / len(feat))]
+with open(sys.argv[2].replace(".json", "_sequence.txt"), "w") as f:
+    for a, b2, name in seq:
+        f.write("%9.1f %8.1f  %s\n" % ((a - mid) / 1e3, (b2 - a) / 1e3, name[:60]))
 open(sys.argv[2], "w").write(json.dumps(out) + "\n")
 PY
 find $R/gpurun_out/${tag}_trace -name "*kernel_trace.csv" -delete
