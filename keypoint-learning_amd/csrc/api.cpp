@@ -241,19 +241,17 @@ constexpr double kWords12BelowKf = 80.0, kWords16BelowKf = 140.0, kWords20BelowK
 void choose_walk(const kpl_detector *h, FeatDesc &f) {
     f.walk = 0;
     f.lanes = 2;
+    const bool hint_fits = h->kf_hint >= 0.0 && h->kf_hint_radius == h->prm.radius_search && h->kf_hint_n > 0 &&
+                           (long long)h->n * 4 >= (long long)h->kf_hint_n * 3 && (long long)h->n * 3 <= (long long)h->kf_hint_n * 4;
     if (h->walk_forced != KPL_WALK_AUTO) {
         f.walk = h->walk_forced == KPL_WALK_TWO_PASS ? 1 : 0;
         f.lanes = h->lanes_forced == 4 ? 4 : 2;
-        return;
-    }
-    const bool hint_fits = h->kf_hint >= 0.0 && h->kf_hint_radius == h->prm.radius_search && h->kf_hint_n > 0 &&
-                           (long long)h->n * 4 >= (long long)h->kf_hint_n * 3 && (long long)h->n * 3 <= (long long)h->kf_hint_n * 4;
-    if (hint_fits && h->kf_hint >= kTwoPassFromKf) {
+    } else if (hint_fits && h->kf_hint >= kTwoPassFromKf) {
         f.walk = 1;
         f.lanes = 4;
     }
-    // the one-kernel walk: how many accept words a point collects between two drains (kernels.hip accept_words: small
-    // neighborhoods run 8-10 % faster with short lists, large ones 13-17 % slower)
+    // the one-kernel walk, chosen or forced: how many accept words a point collects between two drains (kernels.hip
+    // accept_words: small neighborhoods run 8-10 % faster with short lists, large ones 13-17 % slower)
     if (hint_fits && f.walk == 0)
         f.words = h->kf_hint <= kWords12BelowKf ? 12 : h->kf_hint <= kWords16BelowKf ? 16 : h->kf_hint <= kWords20BelowKf ? 20 : 0;
 }

@@ -4526,15 +4526,19 @@ void launch_feature_stage(const Batch &b, hipStream_t st) {
         else (f.lanes == 4 ? lanes4 : lanes2) = true;
     }
     // accept words per point: what the views of that walk ask for (the largest of them: a launch has one list capacity)
+    // -- and only for a launch that has more waves than are resident with 24 words (4 per SIMD): a 63 k-point view alone is two
+    // waves per SIMD whatever the lists, and short lists only make it drain more often (0.063 -> 0.071 ms at K_f = 70)
     auto words_wanted = [&](int lanes) {
         int e = 0;
+        long long waves = 0;
         for (int v = 0; v < b.nviews; ++v) {
             const FeatDesc &f = b.view[v].f;
             if (f.sorted || f.walk != kWalkLanes || f.lanes != lanes) continue;
             const int w = f.words > 0 ? f.words : 24;
             e = w > e ? w : e;
+            waves += div_up(b.view[v].n, kLanes / lanes);
         }
-        return e;
+        return waves > 4ll * 4 * cu_count() ? e : 24;
     };
     if (lanes2) {
         const int ecap = accept_words<2>(maxF, words_wanted(2));

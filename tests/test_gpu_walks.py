@@ -154,13 +154,15 @@ def test_a_first_host_call_estimates_the_neighborhood_from_the_bounding_box(kpl,
 def test_short_accept_lists_follow_the_measured_neighborhood(kpl, oracle, cases):
     """the one-kernel walk collects up to 24 accept words per point between two drains until the handle has measured the
     neighborhood: ~70 neighbors per point -> 12 words from the second call on (more resident waves, search and drain of the
-    waves out of step), ~125 -> 16, ~155 -> 20; every capacity gives the oracle's bits"""
+    waves out of step), ~125 -> 16, ~155 -> 20; every capacity gives the oracle's bits.  The launch takes the short lists only
+    when it has more waves than are resident with 24 words (> 131 k points at two lanes per point): the first case is that big."""
     A, B = 5, 6
-    xyz, nrm = cases.cloud()
-    mr = cases.resolution()
     fa = cases.trained_forest(A, B)
     of = cases.oracle_forest(fa)
-    for rmul, words, lo, hi in [(6.0, 12, 40, 80), (8.0, 16, 80, 140), (9.0, 20, 140, 175), (11.0, 24, 175, 400)]:
+    for (nx, ny), rmul, words, lo, hi in [((440, 330), 6.0, 12, 40, 80), ((80, 60), 6.0, 12, 40, 80), ((80, 60), 8.0, 16, 80, 140),
+                                          ((440, 330), 9.0, 20, 140, 175), ((80, 60), 11.0, 24, 175, 400)]:
+        xyz, nrm = cases.cloud(nx, ny)
+        mr = cases.resolution(nx, ny)
         r, rn, thr = float(np.float32(rmul * mr)), float(np.float32(4 * mr)), float(np.float32(0.6))
         det = kpl.KeypointLearningDetector()
         det.setNAnnulus(A); det.setNBins(B); det.setNonMaxima(True); det.setNonMaxRadius(rn)
@@ -168,7 +170,7 @@ def test_short_accept_lists_follow_the_measured_neighborhood(kpl, oracle, cases)
         cases.load_arrays(det, fa)
         det.setInputCloud(xyz)
         det.setNormals(nrm)
-        o_scores, o_kp = oracle.detect(xyz, nrm, A, B, r, rn, thr, of)
+        o_scores, o_kp = oracle.detect(xyz, nrm, A, B, r, rn, thr, of, threads=cases.usable_cores())
         for call in range(2):
             _, scores = det.compute()
             t = det.getTiming()
