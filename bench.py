@@ -299,6 +299,7 @@ def main():
         of = kplo.Forest(fa.root, fa.var, fa.thr, fa.left, fa.right, fa.value, fa.var_count)
         ncores = usable_cores()
         same_scores, same_kp, n_kp_total = True, True, 0
+        oracle_results = []
         for k, (xyz, nrm, mr) in enumerate(views):
             r_feat, r_nms = float(np.float32(6.0 * mr)), float(np.float32(4.0 * mr))
             o_scores, o_kp = kplo.detect(xyz, nrm, A, B, r_feat, r_nms, thr, of, threads=ncores)
@@ -307,6 +308,7 @@ def main():
             same_scores &= bool(np.array_equal(g_scores.view(np.uint32), o_scores.view(np.uint32)))
             same_kp &= bool(np.array_equal(g_kp, o_kp))
             n_kp_total += int(len(o_kp))
+            oracle_results.append((o_scores, o_kp))
         parity = {"scores_bit_exact": same_scores, "keypoints_identical": same_kp, "views_checked": nv,
                   "n_keypoints": n_kp_total}
         if not (same_scores and same_kp) and not args.no_parity:
@@ -368,6 +370,18 @@ def main():
     if any(rc != kpl.OK for rc in rcs):
         raise SystemExit("bench.py: a timed step failed on the device: statuses %s (%s)" %
                          (rcs, "; ".join(d.lastError() for d, rc in zip(dets, rcs) if rc != kpl.OK)))
+    # ... and the outputs of the LAST timed steps are the oracle's too: the timed steps run with what the handles measured in
+    # the gate above (walk, accept words per point), not with the first call's defaults the gate itself saw
+    if parity is not None and not args.no_parity:
+        again_scores, again_kp = True, True
+        for k, (o_scores, o_kp) in enumerate(oracle_results):
+            again_scores &= bool(np.array_equal(d_scores[k].cpu().numpy().view(np.uint32), o_scores.view(np.uint32)))
+            again_kp &= bool(np.array_equal(d_kp[k][:int(d_cnt[k].item())].cpu().numpy(), o_kp))
+        parity["after_the_timed_steps"] = {"scores_bit_exact": again_scores, "keypoints_identical": again_kp,
+                                           "feature_stage": {k: v for k, v in dets[0].getTiming().items()
+                                                             if k in ("walk", "lanes_per_point", "accept_words")}}
+        if not (again_scores and again_kp):
+            raise SystemExit("PARITY FAILURE vs oracle after the timed steps: %s" % parity)
     per_rank = None
     if use_dist:        # every repetition: the slowest rank counts; every rank's own times travel too
         tt = torch.tensor(rep_s, dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
