@@ -128,6 +128,17 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+    # the reference-regeneration kit's driver built against THIS repo's drop-in header (tools/refgen/refgen_driver.cpp,
+    # -DREFGEN_WITH_KPL): the kit's end-to-end self-test on the GPU box (tests/test_gpu_refgen.py)
+    rsrc = os.path.join(HERE, "..", "tools", "refgen", "refgen_driver.cpp")
+    rexe = os.path.join(HERE, "..", "tools", "refgen", "refgen_driver_kpl")
+    if os.path.exists(rsrc) and (force or _stale(rexe, [rsrc, LIB, os.path.join(HERE, "..", "include", "KeypointLearning.h"),
+                                                        os.path.join(HERE, "..", "include", "kpl_pcl_shim.h")])):
+        cmd = ["g++", "-O2", "-std=c++14", "-DREFGEN_WITH_KPL", "-I", os.path.join(HERE, "..", "include"), rsrc, "-o", rexe,
+               "-L", HERE, "-lkpl", "-Wl,-rpath,$ORIGIN/../../keypoint-learning_amd", "-Wl,-rpath,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
     return LIB
 
 
