@@ -112,6 +112,8 @@ public:
             staged_normals_ = false;
         }
         this->input_ = cloud;
+        // the view's size is known from here on: the engine's tables for it are sized now, not inside compute() (kpl_reserve)
+        if (handle_ && cloud) kpl_reserve(handle_, (int)cloud->points.size(), sizeof(PointInT), sizeof(NormalT));
         if (host_staging_) stage_points();
     }
     virtual void setNormals(const PointCloudNConstPtr &normals) {
@@ -199,13 +201,13 @@ public:
     // How the engine walks a neighborhood (KPL_WALK_*, kpl.h): a choice of speed, never of result.  The default
     // (KPL_WALK_AUTO) follows what the handle measured on its earlier calls, or the view's bounding box on a first one.
     void setFeatureWalk(int walk, int lanes_per_point = 2) { if (handle_) kpl_set_feature_walk(handle_, walk, lanes_per_point); }
-    // ... and what the last compute() took (KPL_WALK_LANES / KPL_WALK_TWO_PASS; -1: sorted order, or no call yet).  Read through
-    // kpl_get_timing, which also hands out -- and clears -- the per-phase times if kpl_enable_timing was switched on
+    // ... and what the last compute() took (KPL_WALK_LANES / KPL_WALK_TWO_PASS; -1: sorted order, or no call yet): a plain
+    // read of the handle (kpl_get_last_launch), the per-phase times of kpl_get_timing are left alone
     int getFeatureWalk(int *lanes_per_point = nullptr) const {
-        kpl_timing t;
-        if (!handle_ || kpl_get_timing(handle_, &t) != KPL_OK) return -1;
-        if (lanes_per_point) *lanes_per_point = t.lanes_per_point;
-        return t.walk;
+        kpl_launch_info li;
+        if (!handle_ || kpl_get_last_launch(handle_, &li) != KPL_OK) return -1;
+        if (lanes_per_point) *lanes_per_point = li.lanes_per_point;
+        return li.walk;
     }
     bool getSortedSearch() const { return sorted_search_ >= 0 ? sorted_search_ != 0 : (this->tree_ && this->tree_->getSortedResults()); }
     const char *lastError() const { return handle_ ? kpl_last_error(handle_) : kpl_status_string(create_status_); }

@@ -16,8 +16,10 @@
  * kpl_estimate_normals*, kpl_cloud_resolution) run on a private non-blocking stream of the handle and
  * return when their results are in the caller's buffers; the *_device entry points only enqueue on the
  * stream they are given.  Both kinds use the handle's scratch: before mixing them on ONE handle, wait for
- * the stream of the earlier *_device call (kpl_sync_status or hipStreamSynchronize) -- nothing orders them
- * implicitly, not even the null stream (and a clear or copy the CALLER issues on the null stream -- hipMemset, hipMemcpy --
+ * the stream of the earlier *_device call (kpl_sync_status or hipStreamSynchronize) if you need its RESULTS -- the handle's
+ * scratch is ordered for you: a call that arrives on another stream than the handle's previous one makes its stream wait
+ * (hipStreamWaitEvent, no host wait) for what the handle queued on the earlier stream, which therefore must still exist.
+ * Nothing else is ordered implicitly, not even the null stream (and a clear or copy the CALLER issues on the null stream -- hipMemset, hipMemcpy --
  * is not ordered against a non-blocking stream either, nor complete when it returns: hipDeviceSynchronize() before handing
  * such a buffer to a *_device entry point on another stream).  The same holds for two *_device calls of ONE handle on
  * DIFFERENT streams: the scratch -- and its growth, which is ordered by the stream of the call that grows it -- belongs to
@@ -35,7 +37,7 @@
 extern "C" {
 #endif
 
-#define KPL_VERSION 140
+#define KPL_VERSION 150
 
 typedef enum kpl_status {
     KPL_OK = 0,
@@ -110,10 +112,16 @@ int kpl_set_feature_walk(kpl_detector *h, int walk, int lanes_per_point);
  * estimated from the bounding box by a first host call; < 0: neither yet) */
 int kpl_get_feature_walk(const kpl_detector *h, int *walk, int *lanes_per_point, double *mean_neighbors);
 
-/* Test hook, per handle: look-back polls of the keypoint compaction's single-pass scan before the call is failed with
- * KPL_ERR_INTERNAL (default 2^22, never reached in practice); polls < 0 makes every block but the first give up at once, which
- * is how tests/test_gpu_status.py drives the failure path.  No environment variable, no process-wide state. */
-int kpl_debug_set_scan_poll_limit(kpl_detector *h, int polls);
+/* What the handle's LAST scoring launch took -- a plain read of the handle, no wait, nothing cleared (kpl_get_timing, which
+ * carries the same three walk fields, waits for its events and clears the recorded times). */
+typedef struct kpl_launch_info {
+    int walk;               /* KPL_WALK_LANES / KPL_WALK_TWO_PASS; -1: sorted order, or no call yet                       */
+    int lanes_per_point;
+    int accept_words;       /* KPL_WALK_LANES: accept words a point collected between two drains (24 / 20 / 16 / 12)      */
+    int sorted_list_keys;   /* sorted order: keys per point of the register-sort lists (128, or what the handle measured) */
+    int sorted_all_large;   /* sorted order: 1 = every point went straight to the wave / workgroup-per-point kernels      */
+} kpl_launch_info;
+int kpl_get_last_launch(const kpl_detector *h, kpl_launch_info *out);
 
 /* Counters for the algorithmic-bytes model of SURVEY.md 8(d), filled by kpl_collect_stats. */
 typedef struct kpl_stats {
@@ -138,6 +146,14 @@ int kpl_version(void);
 /* sha256 (hex) of the sources this library was built from (the .hip and .cpp files of csrc, their headers and this file), as
  * keypoint-learning_amd/build.py computes it: ties a shipped binary to a source tree (tests/test_abi.py). */
 const char *kpl_source_hash(void);
+
+/* What the class can do for a view BEFORE compute() -- setInputCloud knows the number of points: sizes the handle's staging
+ * arrays (strides of the caller's records; 0 = none), the index tables and the scratch of the scoring path for views of up
+ * to n_points, so that the first compute() allocates nothing.  Optional, grow-only, never shrinks; everything it does a
+ * first call would do itself.  (Measured on MI355X, profiles/r06_first_call.jsonl: allocation is ~0.3 ms of a first call;
+ * what made a first compute() 16-22 ms until round 5 were two stream creations and the first use of the copy paths, which
+ * kpl_create now sets up on a thread of its own while the caller loads its forest and cloud.)  No reference counterpart. */
+int kpl_reserve(kpl_detector *h, int n_points, size_t xyz_stride, size_t normals_stride);
 
 /* ---- parameters ----------------------------------------------------------------------- */
 void kpl_default_params(kpl_params *p);

@@ -47,6 +47,11 @@ class Timing(C.Structure):
                 ("walk", C.c_int), ("lanes_per_point", C.c_int), ("accept_words", C.c_int)]
 
 
+class LaunchInfo(C.Structure):
+    _fields_ = [("walk", C.c_int), ("lanes_per_point", C.c_int), ("accept_words", C.c_int),
+                ("sorted_list_keys", C.c_int), ("sorted_all_large", C.c_int)]
+
+
 class Stats(C.Structure):
     _fields_ = [(k, C.c_int64) for k in ("n_points", "n_scored", "n_thresholded", "sum_kf",
                                          "sum_kn", "sum_depth", "n_keypoints", "n_cells")]
@@ -89,9 +94,10 @@ SYMBOLS = {
     "kpl_compute_batch_device": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "kpl_compute_batch_keypoints_device": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "kpl_sync_status": (C.c_int, [_vp, _vp]),
+    "kpl_reserve": (C.c_int, [_vp, C.c_int, C.c_size_t, C.c_size_t]),
+    "kpl_get_last_launch": (C.c_int, [_vp, C.POINTER(LaunchInfo)]),
     "kpl_compute_features_batch_device": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp]),
     "kpl_set_feature_walk": (C.c_int, [_vp, C.c_int, C.c_int]),
-    "kpl_debug_set_scan_poll_limit": (C.c_int, [_vp, C.c_int]),
     "kpl_get_feature_walk": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "kpl_enable_timing": (C.c_int, [_vp, C.c_int]),
     "kpl_get_timing": (C.c_int, [_vp, C.POINTER(Timing)]),
@@ -480,6 +486,16 @@ class KeypointLearningDetector:
         if rc not in (OK, ERR_RETRY):
             self._check(rc)
         return rc
+
+    def getLastLaunch(self):
+        """what the last scoring launch took (no wait, nothing cleared): walk, lanes per point, accept words, sorted-mode list
+        capacity and whether every point went straight to the collect / add kernels"""
+        li = LaunchInfo()
+        self._check(self._lib.kpl_get_last_launch(self._h, C.byref(li)))
+        return {k: getattr(li, k) for k, _ in li._fields_}
+
+    def reserve(self, n_points, xyz_stride=12, normals_stride=12):
+        self._check(self._lib.kpl_reserve(self._h, int(n_points), xyz_stride, normals_stride))
 
     def enableTiming(self, on=True):
         self._check(self._lib.kpl_enable_timing(self._h, int(on)))

@@ -12,7 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libkpl.so")
 SOURCES = ["kernels.hip", "organized_normals.hip", "api.cpp", "forest.cpp"]
-HEADERS = ["kernels.h", "exact_math.h", "soft_pair.h", "organized_normals.h", "forest.h", os.path.join("..", "..", "include", "kpl.h")]
+HEADERS = ["kernels.h", "exact_math.h", "soft_pair.h", "organized_normals.h", "forest.h", os.path.join("..", "..", "include", "kpl.h"),
+           os.path.join("..", "..", "include", "kpl_debug.h")]
 TOOLS = {"TestDetector": ["test_detector_main.cpp"], "DetectViews": ["batch_views_main.cpp"]}
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -63,6 +64,20 @@ def build(force=False, verbose=False):
         subprocess.check_call(cmd)
         with open(stamp, "w") as f:
             f.write(sha + "\n")
+    # the same library with the test hooks of include/kpl_debug.h (api.cpp compiled with -DKPL_TEST_HOOKS): what
+    # tests/test_gpu_status.py loads in child processes to force the failure paths; the shipped libkpl.so has no such symbol
+    hooks = os.path.join(HERE, "..", "tests", "csrc", "libkpl_testhooks.so")
+    if force or _stale(hooks, deps + [LIB]):
+        ho = os.path.join(CSRC, "api_testhooks.o")
+        cmd = [HIPCC] + FLAGS + ['-DKPL_SOURCE_SHA="%s"' % sha, "-DKPL_TEST_HOOKS", "-c", os.path.join(CSRC, "api.cpp"), "-o", ho]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        objs = [os.path.splitext(x)[0] + ".o" for x in srcs if not x.endswith("api.cpp")] + [ho]
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", hooks] + objs + ["-lz", "-Wl,-rpath,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
     for name, tsrcs in TOOLS.items():
         tpaths = [os.path.join(CSRC, s) for s in tsrcs]
         if not all(os.path.exists(p) for p in tpaths):

@@ -5,6 +5,9 @@
 // Reference counterparts: pcl::keypoints::KeypointLearningDetector
 // (/root/reference/include/KeypointLearning.h:55-206, include/impl/KeypointLearning.hpp).
 #include "../../include/kpl.h"
+#ifdef KPL_TEST_HOOKS
+#include "../../include/kpl_debug.h"
+#endif
 
 #include <hip/hip_runtime.h>
 
@@ -17,6 +20,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "forest.h"
@@ -25,6 +29,22 @@
 #include "soft_pair.h"
 
 using namespace kpl;
+
+// -DKPL_TRACE_HOST (scratch builds only, tools/first_call.py --trace): host-side time stamps of the steps of a call on stderr
+#ifdef KPL_TRACE_HOST
+#include <chrono>
+static void kpl_trace(const char *what) {
+    static auto t0 = std::chrono::steady_clock::now();
+    static auto last = t0;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[kpl %9.3f ms +%8.3f] %s\n", std::chrono::duration<double, std::milli>(now - t0).count(),
+            std::chrono::duration<double, std::milli>(now - last).count(), what);
+    last = now;
+}
+#define KPL_TRACE(what) kpl_trace(what)
+#else
+#define KPL_TRACE(what) ((void)0)
+#endif
 
 namespace {
 
@@ -110,7 +130,7 @@ struct kpl_detector {
     // mean K_f the handle's previous calls measured (DevState::kf_sum / kf_points, read back in sync_status)
     int walk_forced = KPL_WALK_AUTO, lanes_forced = 0;
     int last_walk = -1, last_lanes = 0, last_words = 0;        // what the last launch took (kpl_timing)
-    int scan_poll_limit = 1 << 22;   // kpl_debug_set_scan_poll_limit (per handle)
+    int scan_poll_limit = 1 << 22;   // per handle; only a library built with -DKPL_TEST_HOOKS can change it (include/kpl_debug.h)
     double kf_hint = -1.0;        // mean neighbors per point of the calls before the last status read; < 0: not known
     double kf_hint_radius = 0.0;  // ... measured at this feature radius
     int kf_hint_n = 0;            // ... on a view of this many points
@@ -121,6 +141,8 @@ struct kpl_detector {
     int all_large_n = 0;
     double launched_radius = 0.0; // feature radius / points of the last scoring launch (what the next read-back describes)
     int launched_n = 0;
+    bool launched_all_large = false;   // ... and whether it ran with FeatDesc::all_large
+    int last_lcap = 0;            // sorted-search mode: list capacity / all_large of the last launch (kpl_get_last_launch)
     float origin[3] = {0.0f, 0.0f, 0.0f};
 
     DevBuf stage_xyz, stage_nrm, stage_idx, stage_feat;
@@ -145,6 +167,21 @@ struct kpl_detector {
     std::vector<void *> parked;   // hipMalloc'ed arrays that stream-ordered growth replaced: freed with the handle
     void *h_res = nullptr;        // pinned landing zone of the keypoint lists (host-buffer entry points)
     size_t h_res_cap = 0;
+    // What the HOST entry points need and the device entry points do not -- the handle's two streams (8-9 ms each to create
+    // on this runtime: a hardware queue), the pinned landing buffer, and the first use of the copy paths (the first 128 KiB
+    // device-to-pinned copy of a process takes 7-8 ms, so does its first copy out of pageable memory;
+    // tools/probes/host_cost_probe.cpp, profiles/r06_first_call.jsonl) -- is set up by a thread that kpl_create starts and the
+    // first host entry point joins (streams_ready): a drop-in TestDetector run loads its forest and reads its cloud in the
+    // meantime, and its ONE compute() no longer pays 17 of its 18 ms for set-up.  Until the join the thread owns
+    // stream / copy_stream / ev_xyz / ev_nrm / h_res*, nothing else.
+    // the stream of the handle's last enqueuing call: the scratch -- and its stream-ordered growth -- belongs to the handle, so a
+    // call that arrives on ANOTHER stream first makes that stream wait for what the earlier one has queued (enter_stream)
+    hipStream_t last_st = nullptr;
+    bool has_last_st = false;
+    hipEvent_t ev_last = nullptr;
+    std::thread setup;
+    bool setup_pending = false;
+    hipError_t setup_err = hipSuccess;
 
     // optional per-phase event timing (kpl_enable_timing)
     bool timing = false;
@@ -199,6 +236,22 @@ int use_device(kpl_detector *h) {
     return KPL_OK;
 }
 
+// Called by every enqueuing entry point with the stream it is about to use.  One handle per stream is the intended use and costs
+// nothing here; a handle that moves to another stream (a device entry point on the caller's stream, then a host entry point on
+// the handle's own, or two caller streams) gets the ordering its scratch needs without a host wait: an event recorded on the
+// earlier stream now -- behind everything the handle has queued there -- and a wait for it on the new one.  The earlier stream
+// must still exist (include/kpl.h).
+int enter_stream(kpl_detector *h, hipStream_t st) {
+    if (h->has_last_st && h->last_st != st) {
+        if (!h->ev_last) KPL_HIP(h, hipEventCreateWithFlags(&h->ev_last, hipEventDisableTiming));
+        KPL_HIP(h, hipEventRecord(h->ev_last, h->last_st));
+        KPL_HIP(h, hipStreamWaitEvent(st, h->ev_last, 0));
+    }
+    h->last_st = st;
+    h->has_last_st = true;
+    return KPL_OK;
+}
+
 FeatDesc make_feat(const kpl_params &p) {
     FeatDesc f;
     f.A = p.n_annulus;
@@ -238,11 +291,21 @@ constexpr double kTwoPassFromKf = 400.0;
 // 20 / 24 words -- K_f = 48: 0.166 / 0.173 / 0.172 / 0.180; 95: 0.260 / 0.257 / 0.257 / 0.271; 124: 0.342 / 0.313 / 0.312 / 0.327;
 // 157: 0.453 / 0.406 / 0.376 / 0.393; 192: 0.546 / 0.529 / 0.479 / 0.466; profiles/r05_accept_words.jsonl)
 constexpr double kWords12BelowKf = 80.0, kWords16BelowKf = 140.0, kWords20BelowKf = 175.0;
+// the handle's measured (or estimated) neighborhood size describes THIS view: same feature radius, size within 25 %
+bool kf_hint_fits(const kpl_detector *h, int n) {
+    return h->kf_hint >= 0.0 && h->kf_hint_radius == h->prm.radius_search && h->kf_hint_n > 0 &&
+           (long long)n * 4 >= (long long)h->kf_hint_n * 3 && (long long)n * 3 <= (long long)h->kf_hint_n * 4;
+}
+// how many accept words a point collects between two drains in the one-kernel walk (kernels.hip accept_words: small
+// neighborhoods run 8-10 % faster with short lists, large ones 13-17 % slower); 0 = the default of 24
+int words_for(const kpl_detector *h) {
+    if (!kf_hint_fits(h, h->n)) return 0;
+    return h->kf_hint <= 80.0 ? 12 : h->kf_hint <= 140.0 ? 16 : h->kf_hint <= 175.0 ? 20 : 0;
+}
 void choose_walk(const kpl_detector *h, FeatDesc &f) {
     f.walk = 0;
     f.lanes = 2;
-    const bool hint_fits = h->kf_hint >= 0.0 && h->kf_hint_radius == h->prm.radius_search && h->kf_hint_n > 0 &&
-                           (long long)h->n * 4 >= (long long)h->kf_hint_n * 3 && (long long)h->n * 3 <= (long long)h->kf_hint_n * 4;
+    const bool hint_fits = kf_hint_fits(h, h->n);
     if (h->walk_forced != KPL_WALK_AUTO) {
         f.walk = h->walk_forced == KPL_WALK_TWO_PASS ? 1 : 0;
         f.lanes = h->lanes_forced == 4 ? 4 : 2;
@@ -250,11 +313,9 @@ void choose_walk(const kpl_detector *h, FeatDesc &f) {
         f.walk = 1;
         f.lanes = 4;
     }
-    // the one-kernel walk, chosen or forced: how many accept words a point collects between two drains (kernels.hip
-    // accept_words: small neighborhoods run 8-10 % faster with short lists, large ones 13-17 % slower)
-    if (hint_fits && f.walk == 0)
-        f.words = h->kf_hint <= kWords12BelowKf ? 12 : h->kf_hint <= kWords16BelowKf ? 16 : h->kf_hint <= kWords20BelowKf ? 20 : 0;
+    if (f.walk == 0) f.words = words_for(h);        // (thresholds: kWords12BelowKf / 16 / 20 above)
 }
+static_assert(kWords12BelowKf == 80.0 && kWords16BelowKf == 140.0 && kWords20BelowKf == 175.0, "words_for() spells these out");
 
 NmsDesc make_nms(const kpl_params &p) {
     NmsDesc d;
@@ -331,21 +392,11 @@ int ensure_cells(kpl_detector *h, int64_t cap, hipStream_t st) {
     return KPL_OK;
 }
 
-// Index stage ("initCompute"), fully asynchronous: bounding box -> grid descriptor (on the device)
-// -> cell ids + counts -> scan -> scatter -> rank/store.  The host does not learn the grid size;
-// a view whose grid does not fit the current cell tables sets DevState::status (kpl_sync_status).
-// prepare_index checks, allocates and fills the index half of the view descriptor.
-int prepare_index(kpl_detector *h, bool auto_cell, ViewDev &v, hipStream_t st, double cell = 0.0) {
-    int rc = (auto_cell || cell > 0.0) ? KPL_OK : check_params_for_compute(h, false);
-    if (rc) return rc;
-    if (!h->bound) return fail(h, KPL_ERR_NO_CLOUD, "no cloud bound");
-    if (h->n >= (1 << 28)) return fail(h, KPL_ERR_UNSUPPORTED, "more than 2^28 - 1 points per view");
-    rc = use_device(h);
-    if (rc) return rc;
-    const int n = h->n;
+// the tables of the index build for a view of n points, in the order of `st` (prepare_index, kpl_reserve)
+int ensure_index_tables(kpl_detector *h, int n, hipStream_t st) {
     const size_t nn = (size_t)(n > 0 ? n : 1);
     if (h->cells_cap == 0) {
-        rc = ensure_cells(h, (int64_t)8 * n + 65536, st);
+        int rc = ensure_cells(h, (int64_t)8 * n + 65536, st);
         if (rc) return rc;
     }
     KPL_HIP(h, h->cid.ensure(sizeof(int) * nn, st, h->parked));
@@ -356,6 +407,44 @@ int prepare_index(kpl_detector *h, bool auto_cell, ViewDev &v, hipStream_t st, d
     KPL_HIP(h, h->pts.ensure(pts_bytes(n), st, h->parked));            // incl. the tail the search steps read past the last point
     KPL_HIP(h, h->nrm.ensure(sizeof(float4) * nn, st, h->parked));
     KPL_HIP(h, h->pos_of.ensure(sizeof(int) * nn, st, h->parked));
+    return KPL_OK;
+}
+
+// the scratch of the scoring / NMS half that depends on the view size and the parameters only (prepare_detect, kpl_reserve);
+// every array in the order of the launch stream, the ones the kernels expect zeroed cleared in that order too (flags /
+// cand.count / skip are kept zero by the compaction from then on; scan_state: tag 0 = "never written")
+int ensure_detect_scratch(kpl_detector *h, int n, hipStream_t st) {
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    KPL_HIP(h, h->score_sorted.ensure(sizeof(float) * nn, st, h->parked));
+    KPL_HIP(h, h->feat.ensure(feat_bytes(n, h->prm.n_annulus * h->prm.n_bins), st, h->parked));
+    KPL_HIP(h, h->flags.ensure(sizeof(int) * (nn + 1), st, h->parked, true));
+    KPL_HIP(h, h->cand_count.ensure(sizeof(int), st, h->parked, true));
+    KPL_HIP(h, h->cand_list.ensure(sizeof(int) * nn, st, h->parked));
+    KPL_HIP(h, h->prefix.ensure(sizeof(int) * (nn + 2), st, h->parked));
+    KPL_HIP(h, h->scan_state.ensure(scan_state_bytes(n), st, h->parked, true));
+    if (h->prm.non_maxima && h->prm.non_maxima_draws_remove) {
+        KPL_HIP(h, h->skip.ensure(sizeof(int) * nn, st, h->parked, true));
+        KPL_HIP(h, h->draw_list.ensure(sizeof(int) * (nn * (2 + kDrawAdj) + 8), st, h->parked));     // list, adjacency counts, adjacency (kernels.hip draw_adj_offset)
+        KPL_HIP(h, h->draw_count.ensure(sizeof(int), st, h->parked));
+    }
+    return KPL_OK;
+}
+
+// Index stage ("initCompute"), fully asynchronous: bounding box -> grid descriptor (on the device)
+// -> cell ids + counts -> scan -> scatter -> rank/store.  The host does not learn the grid size;
+// a view whose grid does not fit the current cell tables sets DevState::status (kpl_sync_status).
+// prepare_index checks, allocates and fills the index half of the view descriptor.
+int prepare_index(kpl_detector *h, bool auto_cell, ViewDev &v, hipStream_t st, double cell = 0.0) {
+    int rc = (auto_cell || cell > 0.0) ? KPL_OK : check_params_for_compute(h, false);
+    if (rc) return rc;
+    if (!h->bound) return fail(h, KPL_ERR_NO_CLOUD, "no cloud bound");
+    if (h->n >= (1 << 28)) return fail(h, KPL_ERR_UNSUPPORTED, "more than 2^28 - 1 points per view");
+    rc = use_device(h);
+    if (!rc) rc = enter_stream(h, st);
+    if (rc) return rc;
+    const int n = h->n;
+    rc = ensure_index_tables(h, n, st);
+    if (rc) return rc;
     v.xyz = h->d_xyz;
     v.nrmsrc = h->d_nrm;
     v.xs = (unsigned)h->xs;
@@ -407,9 +496,13 @@ int sync_status(kpl_detector *h, hipStream_t st) {
     KPL_HIP(h, hipMemcpyAsync(h->h_state, h->dstate.p, sizeof(DevState), hipMemcpyDeviceToHost, st));
     KPL_HIP(h, hipStreamSynchronize(st));
     if (h->h_state->kf_points > h->kf_seen_points) {        // what the scoring launches since the last read measured
-        h->kf_hint = (double)(h->h_state->kf_sum - h->kf_seen_sum) / (double)(h->h_state->kf_points - h->kf_seen_points);
-        h->kf_hint_radius = h->launched_radius;
-        h->kf_hint_n = h->launched_n;
+        // (only a call that ran to its end describes the view: the search kernel of a call that fails with "word list too
+        // small" samples waves that walked nothing, and a hint pulled down by those zeros flips the walk for one call)
+        if (h->h_state->status == kStatusOk) {
+            h->kf_hint = (double)(h->h_state->kf_sum - h->kf_seen_sum) / (double)(h->h_state->kf_points - h->kf_seen_points);
+            h->kf_hint_radius = h->launched_radius;
+            h->kf_hint_n = h->launched_n;
+        }
         h->kf_seen_sum = h->h_state->kf_sum;
         h->kf_seen_points = h->h_state->kf_points;
     }
@@ -431,6 +524,18 @@ int sync_status(kpl_detector *h, hipStream_t st) {
         h->all_large_hint = h->launched_n > 0 && (long long)h->h_state->large_seen * 4 >= (long long)h->launched_n;
         h->all_large_n = h->launched_n;
         KPL_HIP(h, hipMemsetAsync((char *)h->dstate.p + offsetof(DevState, kf_max), 0, sizeof(int), st));
+    } else if (h->launched_all_large && h->h_state->status == kStatusOk) {
+        // A launch with all_large sends every point to the collect / add kernels, so the register-sort kernel measures nothing
+        // (kf_max stays 0) and the hint would never be looked at again: a stream of views of one size at one radius that went
+        // from dense to sparse would stay on the slow path for good.  What such a launch does measure is the number of keys it
+        // stored (keys_needed: every neighbor of every listed point, chunk tails included) and the points it listed: when
+        // the mean is back within what the register lists hold, the next launch tries them again (and measures again).
+        const long long listed = h->h_state->large_seen;
+        const double mean_keys = listed > 0 ? (double)h->h_state->keys_needed / (double)listed : 0.0;
+        if (mean_keys < 100.0) {
+            h->all_large_hint = false;
+            h->lcap_hint = 0;               // (not known: 128 keys per point until the next launch has measured)
+        }
     }
     if (h->h_state->status == kStatusGridTooLarge)
         return fail(h, KPL_ERR_GRID_TOO_LARGE, "bounding box / radius needs more than 2^28 grid cells");
@@ -445,8 +550,11 @@ int sync_status(kpl_detector *h, hipStream_t st) {
         // sorted-search mode: the neighbor keys of the points with large neighborhoods did not fit; two-pass walk: the accept
         // words of the view did not (kernels.hip) -- the same array, grown to what the failed call counted
         const unsigned long long need = h->h_state->keys_needed;
-        if (need > 0xfffffff0ull)
+        if (need > 0xfffffff0ull) {
+            h->kf_hint = -1.0;              // (an automatic choice of the two-pass walk is not repeated: the lanes walk needs no list)
+            h->index_valid = false;
             return fail(h, KPL_ERR_CAPACITY, "%llu neighbor keys / accept words in one view (limit 2^32)", need);
+        }
         h->index_valid = false;
         KPL_HIP(h, h->sort_keys.ensure(sizeof(unsigned long long) * (size_t)(need + need / 16 + 4096), st, h->parked));
         return fail(h, KPL_ERR_RETRY, "the view needs room for %llu neighbor keys / accept words: array grown, call again", need);
@@ -470,25 +578,14 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
     if (kp_cap < 0 || !d_kp_count || (kp_cap > 0 && !d_kp_idx))
         return fail(h, KPL_ERR_INVALID_ARG, "bad keypoint output buffers");
     rc = use_device(h);
+    if (!rc) rc = enter_stream(h, st);
     if (rc) return rc;
     const int n = h->n;
     const size_t nn = (size_t)(n > 0 ? n : 1);
-    // every array in the order of the launch stream; the ones the kernels expect zeroed are cleared in that order too
-    // (flags / cand.count / skip are kept zero by the compaction from then on; scan_state: tag 0 = "never written")
-    KPL_HIP(h, h->score_sorted.ensure(sizeof(float) * nn, st, h->parked));
-    KPL_HIP(h, h->feat.ensure(feat_bytes(n, h->prm.n_annulus * h->prm.n_bins), st, h->parked));
-    KPL_HIP(h, h->flags.ensure(sizeof(int) * (nn + 1), st, h->parked, true));
-    KPL_HIP(h, h->cand_count.ensure(sizeof(int), st, h->parked, true));
-    KPL_HIP(h, h->cand_list.ensure(sizeof(int) * nn, st, h->parked));
-    KPL_HIP(h, h->prefix.ensure(sizeof(int) * (nn + 2), st, h->parked));
-    KPL_HIP(h, h->scan_state.ensure(scan_state_bytes(n), st, h->parked, true));
+    rc = ensure_detect_scratch(h, n, st);
+    if (rc) return rc;
     NmsDesc nd = make_nms(h->prm);
     nd.scan_poll_limit = h->scan_poll_limit;
-    if (nd.draws_remove) {
-        KPL_HIP(h, h->skip.ensure(sizeof(int) * nn, st, h->parked, true));
-        KPL_HIP(h, h->draw_list.ensure(sizeof(int) * (nn * (2 + kDrawAdj) + 8), st, h->parked));     // list, adjacency counts, adjacency (kernels.hip draw_adj_offset)
-        KPL_HIP(h, h->draw_count.ensure(sizeof(int), st, h->parked));
-    }
     v.large_list = nullptr;
     v.sort_keys = nullptr;
     v.seg_start = nullptr;
@@ -496,9 +593,6 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
     v.key_cap = 0;
     FeatDesc feat = make_feat(h->prm);
     choose_walk(h, feat);
-    h->last_walk = feat.sorted ? -1 : feat.walk;
-    h->last_lanes = feat.sorted ? 0 : feat.lanes;
-    h->last_words = (!feat.sorted && feat.walk == 0) ? (feat.words > 0 ? feat.words : 24) : 0;
     if (feat.sorted && h->lcap_hint > 0 && h->lcap_hint_radius == h->prm.radius_search) {
         feat.lcap = h->lcap_hint;
         feat.all_large = h->all_large_hint && (long long)n * 4 >= (long long)h->all_large_n * 3 && (long long)n * 3 <= (long long)h->all_large_n * 4 ? 1 : 0;
@@ -507,12 +601,38 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
         // two-pass walk: the accept words of every point's whole walk (8-byte entries in the array the sorted mode keeps its
         // keys in -- a view is in one mode or the other).  About one word per five neighbors on a surface (32 candidates
         // a word, 4.6 candidates per neighbor) and a third more for the lock step of a wave; a view that needs more fails
-        // its first call with KPL_ERR_RETRY and finds the array grown (sync_status)
-        const double per_point = (h->kf_hint > 0.0 ? h->kf_hint : 1000.0) * 0.3 + 96.0;
-        const size_t want = sizeof(unsigned long long) * (size_t)((double)nn * per_point);
+        // its first call with KPL_ERR_RETRY and finds the array grown (sync_status).  The hint sizes the list only when it
+        // describes this view.  An AUTOMATIC choice is bounded: a list beyond 8 GiB or 2^32 entries (a million points at the
+        // reference's default radius would ask for 6 GB), or one the device cannot allocate, sends the launch back to the
+        // one-kernel walk, which needs no list -- the same bits, slower for such neighborhoods, but it runs.
+        const bool forced = h->walk_forced == KPL_WALK_TWO_PASS;
+        const double per_point = (kf_hint_fits(h, n) && h->kf_hint > 0.0 ? h->kf_hint : 1000.0) * 0.3 + 96.0;
+        double entries = (double)nn * per_point;
+        bool ok = forced || (entries * 8.0 <= 8.0 * 1073741824.0 && entries <= 4.0e9);
+        if (entries > 4.2e9) entries = 4.2e9;                                // (forced: entry numbers are 32-bit, the kernels say RETRY / CAPACITY)
+        const size_t want = sizeof(unsigned long long) * (size_t)entries;
+        if (ok && h->sort_keys.cap < want) {
+            const hipError_t e = h->sort_keys.ensure(want, st, h->parked);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                if (forced) return fail(h, KPL_ERR_DEVICE, "word list of the two-pass walk (%zu bytes): %s", want, hipGetErrorString(e));
+                ok = false;
+            }
+        }
+        if (!ok) {
+            feat.walk = 0;
+            feat.lanes = 2;
+            feat.words = words_for(h);
+        }
+    }
+    h->last_walk = feat.sorted ? -1 : feat.walk;
+    h->last_lanes = feat.sorted ? 0 : feat.lanes;
+    h->last_words = (!feat.sorted && feat.walk == 0) ? (feat.words > 0 ? feat.words : 24) : 0;
+    h->last_lcap = feat.sorted ? (feat.lcap > 0 ? feat.lcap : 128) : 0;
+    h->launched_all_large = feat.sorted && feat.all_large;
+    if (!feat.sorted && feat.walk == 1) {
         KPL_HIP(h, h->seg_start.ensure(sizeof(unsigned) * nn, st, h->parked));
         KPL_HIP(h, h->seg_len.ensure(sizeof(int) * nn, st, h->parked));
-        if (h->sort_keys.cap < want) KPL_HIP(h, h->sort_keys.ensure(want, st, h->parked));
         v.sort_keys = h->sort_keys.as<unsigned long long>();
         v.seg_start = h->seg_start.as<unsigned>();
         v.seg_len = h->seg_len.as<int>();
@@ -569,6 +689,7 @@ int run_batch(kpl_detector *const *handles, int count, float *const *d_scores, i
         kpl_detector *h = handles[k];
         int rc = check_params_for_compute(h, true);
         if (!rc) rc = prepare_index(h, false, all.view[k], st);  // allocates the view's tables ...
+        KPL_TRACE("run_batch: index tables ensured");
         if (!rc) rc = prepare_detect(h, d_scores ? d_scores[k] : nullptr, d_kp_idx[k], kp_caps[k], d_kp_counts[k],
                                      d_stats, all.view[k], st);  // ... and its scratch
         if (rc) {
@@ -584,9 +705,11 @@ int run_batch(kpl_detector *const *handles, int count, float *const *d_scores, i
         rebuilt[k] = rebuild_k;
     }
     all.nviews = count;
+    KPL_TRACE("run_batch: tables and scratch ensured");
     const size_t ev0 = mark(h0, st);
     if (idx.nviews) {
         launch_index_points(idx, st);
+        KPL_TRACE("run_batch: index kernels (points) launched");
         // (host views: the normals arrive on the copy stream while the kernels above run -- from pinned staging buffers
         // their DMA is in flight already, from pageable memory the copy is issued now)
         if (count == 1 && h0->pending_nrm) {
@@ -599,18 +722,23 @@ int run_batch(kpl_detector *const *handles, int count, float *const *d_scores, i
         launch_index_records(idx, st);
     }
     if (fix.nviews) launch_pos_of(fix, st);
+    KPL_TRACE("run_batch: index kernels (records) launched");
     const size_t ev1 = mark(h0, st);
     launch_feature_stage(all, st);
+    KPL_TRACE("run_batch: feature stage launched");
     const size_t ev1b = mark(h0, st);
     launch_forest_stage(all, st);
+    KPL_TRACE("run_batch: forest stage launched");
     const size_t ev2 = mark(h0, st);
     launch_post(all, st);
+    KPL_TRACE("run_batch: NMS + compaction launched");
     const size_t ev3 = mark(h0, st);
     if (idx.nviews) span(h0, 0, ev0, ev1);
     span(h0, 1, ev1, ev1b);
     span(h0, 3, ev1b, ev2);
     span(h0, 2, ev2, ev3);
     KPL_HIP(h0, hipGetLastError());
+    KPL_TRACE("run_batch: hipGetLastError");
     for (int k = 0; k < count; ++k) {
         const bool with_map = all.view[k].want_pos_of != 0;
         if (rebuilt[k]) index_was_built(handles[k], false, with_map);
@@ -689,11 +817,42 @@ void estimate_neighborhood(kpl_detector *h, const void *xyz, size_t xs, int n) {
     h->kf_hint_n = n;
 }
 
-int ensure_copy_stream(kpl_detector *h) {
-    if (h->copy_stream) return KPL_OK;
-    KPL_HIP(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
-    KPL_HIP(h, hipEventCreateWithFlags(&h->ev_xyz, hipEventDisableTiming));
-    KPL_HIP(h, hipEventCreateWithFlags(&h->ev_nrm, hipEventDisableTiming));
+constexpr size_t kLandingEntries = 32768;      // keypoint indices (+ responses) that come back with the count, on speculation
+
+void setup_host_path(kpl_detector *h) {
+    hipError_t e = hipSetDevice(h->device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_xyz, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_nrm, hipEventDisableTiming);
+    const size_t landing = kLandingEntries * (sizeof(int) + sizeof(float));
+    if (e == hipSuccess) e = hipHostMalloc(&h->h_res, landing + landing / 2 + 4096, hipHostMallocDefault);
+    if (e == hipSuccess) h->h_res_cap = landing + landing / 2 + 4096;
+    // first use of the copy paths, on the stream that will use them (results are thrown away)
+    void *tmp = nullptr;
+    const size_t warm = kLandingEntries * sizeof(int);
+    if (e == hipSuccess) e = hipMallocAsync(&tmp, 2 * warm, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(tmp, 0, 2 * warm, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(h->h_res, tmp, warm, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) {
+        std::vector<char> pageable(2 * warm, 0);
+        e = hipMemcpyAsync(tmp, pageable.data(), 2 * warm, hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);       // (the vector must outlive the copy)
+    }
+    if (tmp) (void)hipFreeAsync(tmp, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    h->setup_err = e;
+}
+
+// every entry point that uses the handle's own streams passes through here first
+int streams_ready(kpl_detector *h) {
+    if (h->setup_pending) {
+        h->setup.join();
+        h->setup_pending = false;
+        KPL_TRACE("streams_ready: joined the set-up thread");
+    }
+    if (h->setup_err != hipSuccess)
+        return fail(h, KPL_ERR_DEVICE, "set-up of the handle's streams failed: %s", hipGetErrorString(h->setup_err));
     return KPL_OK;
 }
 
@@ -705,10 +864,14 @@ int upload_view(kpl_detector *h, const void *xyz, size_t xs, const void *nrm, si
     if (xs < 12 || ns < 12 || (xs & 3) || (ns & 3))
         return fail(h, KPL_ERR_INVALID_ARG, "strides must be multiples of 4 and >= 12 bytes");
     int rc = use_device(h);
+    if (!rc) rc = streams_ready(h);
+    if (!rc) rc = enter_stream(h, h->stream);       // (the staging arrays may still be read by a call on another stream)
     if (rc) return rc;
     const size_t nn = (size_t)(n > 0 ? n : 1);
+    KPL_TRACE("upload_view: begin");
     KPL_HIP(h, h->stage_xyz.ensure(nn * xs));
     KPL_HIP(h, h->stage_nrm.ensure(nn * ns));
+    KPL_TRACE("upload_view: staging arrays");
     if (n > 0) {
         // the last element may be shorter than the stride in the caller's array.  Enqueued on the
         // handle's stream (pageable memory: the runtime stages it, the call returns once it has);
@@ -716,7 +879,7 @@ int upload_view(kpl_detector *h, const void *xyz, size_t xs, const void *nrm, si
         KPL_HIP(h, hipMemcpyAsync(h->stage_xyz.p, xyz, (size_t)(n - 1) * xs + 12, hipMemcpyHostToDevice, h->stream));
         h->pending_nrm = nullptr;
         if (nrm != xyz) {
-            if (defer_normals && ensure_copy_stream(h) == KPL_OK) {
+            if (defer_normals) {
                 h->pending_nrm = nrm;
                 h->pending_nrm_bytes = (size_t)(n - 1) * ns + 12;
             } else {
@@ -733,7 +896,9 @@ int upload_view(kpl_detector *h, const void *xyz, size_t xs, const void *nrm, si
     h->n = n;
     h->bound = true;
     h->index_valid = false;
+    KPL_TRACE("upload_view: copies issued");
     estimate_neighborhood(h, xyz, xs, n);
+    KPL_TRACE("upload_view: neighborhood estimated");
     return KPL_OK;
 }
 
@@ -775,19 +940,24 @@ int detect_staged(kpl_detector *h, int n, float *scores_out, int *kp_idx_out, fl
     };
     int rc = ensure_landing((size_t)spec);
     if (rc) return rc;
+    KPL_TRACE("detect_staged: output arrays + pinned landing buffer");
     for (int attempt = 0;; ++attempt) {
         rc = run_batch(&h, 1, &d_scores, &d_kp, &n, &d_count, nullptr, true, st, &d_kps, attempt == 0 ? normals_ready : nullptr);
         if (rc) return rc;
         KPL_HIP(h, hipMemcpyAsync(h->h_count, h->out_count.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        KPL_TRACE("detect_staged: count copy issued");
         if (spec > 0) {
             KPL_HIP(h, hipMemcpyAsync(h->h_res, h->out_kp.p, sizeof(int) * (size_t)spec, hipMemcpyDeviceToHost, st));
+            KPL_TRACE("detect_staged: index list copy issued");
             if (kp_scores_out)
                 KPL_HIP(h, hipMemcpyAsync((char *)h->h_res + sizeof(int) * (size_t)spec, h->out_kp_score.p,
                                           sizeof(float) * (size_t)spec, hipMemcpyDeviceToHost, st));
         }
         if (scores_out && n > 0)
             KPL_HIP(h, hipMemcpyAsync(scores_out, h->out_scores.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, st));
+        KPL_TRACE("detect_staged: run_batch + copies issued");
         rc = sync_status(h, st);
+        KPL_TRACE(rc == KPL_ERR_RETRY ? "detect_staged: synced, RETRY" : "detect_staged: synced");
         if (rc == KPL_ERR_RETRY && attempt < 6) continue;    // cell tables / key segments / word lists were grown: run again
         if (rc) return rc;
         break;
@@ -873,6 +1043,7 @@ int kpl_create(kpl_detector **out, int device) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count)
         return KPL_ERR_DEVICE;
+    KPL_TRACE("kpl_create: begin");
     kpl_detector *h = new (std::nothrow) kpl_detector();
     if (!h) return KPL_ERR_DEVICE;
     h->device = device;
@@ -880,8 +1051,7 @@ int kpl_create(kpl_detector **out, int device) {
     if (hipSetDevice(device) != hipSuccess ||
         hipHostMalloc((void **)&h->h_state, sizeof(DevState), hipHostMallocDefault) != hipSuccess ||
         h->dstate.ensure(sizeof(DevState)) != hipSuccess ||
-        hipHostMalloc((void **)&h->h_count, 16 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
-        hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        hipHostMalloc((void **)&h->h_count, 16 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
         kpl_destroy(h);
         return KPL_ERR_DEVICE;
     }
@@ -891,12 +1061,22 @@ int kpl_create(kpl_detector **out, int device) {
         kpl_destroy(h);
         return KPL_ERR_DEVICE;
     }
+    preload_code();                  // the code objects of both kernel files, now instead of under the first launch
+    try {
+        h->setup = std::thread(setup_host_path, h);
+        h->setup_pending = true;
+    } catch (...) {                  // no thread to be had: set up here
+        setup_host_path(h);
+    }
+    KPL_TRACE("kpl_create: end");
     *out = h;
     return KPL_OK;
 }
 
 void kpl_destroy(kpl_detector *h) {
     if (!h) return;
+    if (h->setup_pending) h->setup.join();
+    h->setup_pending = false;
     (void)hipSetDevice(h->device);
     // kernels of the handle's last calls may still be running, on streams this function knows nothing about: the arrays that
     // came from hipMallocAsync are released with hipFreeAsync, which -- unlike the hipFree of earlier rounds -- waits for nothing
@@ -915,6 +1095,7 @@ void kpl_destroy(kpl_detector *h) {
     if (h->h_res) (void)hipHostFree(h->h_res);
     if (h->hs_xyz) (void)hipHostFree(h->hs_xyz);
     if (h->hs_nrm) (void)hipHostFree(h->hs_nrm);
+    if (h->ev_last) (void)hipEventDestroy(h->ev_last);
     if (h->ev_xyz) (void)hipEventDestroy(h->ev_xyz);
     if (h->ev_nrm) (void)hipEventDestroy(h->ev_nrm);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
@@ -943,11 +1124,13 @@ int kpl_set_feature_walk(kpl_detector *h, int walk, int lanes_per_point) {
     return KPL_OK;
 }
 
+#ifdef KPL_TEST_HOOKS                 // include/kpl_debug.h: not in the shipped library
 int kpl_debug_set_scan_poll_limit(kpl_detector *h, int polls) {
     if (!h) return KPL_ERR_INVALID_ARG;
     h->scan_poll_limit = polls;
     return KPL_OK;
 }
+#endif
 
 int kpl_get_feature_walk(const kpl_detector *h, int *walk, int *lanes_per_point, double *mean_neighbors) {
     if (!h) return KPL_ERR_INVALID_ARG;
@@ -956,6 +1139,16 @@ int kpl_get_feature_walk(const kpl_detector *h, int *walk, int *lanes_per_point,
     if (walk) *walk = f.walk ? KPL_WALK_TWO_PASS : KPL_WALK_LANES;
     if (lanes_per_point) *lanes_per_point = f.lanes;
     if (mean_neighbors) *mean_neighbors = h->kf_hint;
+    return KPL_OK;
+}
+
+int kpl_get_last_launch(const kpl_detector *h, kpl_launch_info *out) {
+    if (!h || !out) return KPL_ERR_INVALID_ARG;
+    out->walk = h->last_walk;
+    out->lanes_per_point = h->last_lanes;
+    out->accept_words = h->last_words;
+    out->sorted_list_keys = h->last_lcap;
+    out->sorted_all_large = h->launched_all_large ? 1 : 0;
     return KPL_OK;
 }
 
@@ -1256,9 +1449,10 @@ int kpl_host_staging(kpl_detector *h, int n, size_t xyz_stride, size_t normals_s
     if (xyz_stride < 12 || normals_stride < 12 || (xyz_stride & 3) || (normals_stride & 3))
         return fail(h, KPL_ERR_INVALID_ARG, "strides must be multiples of 4 and >= 12 bytes");
     int rc = use_device(h);
+    if (!rc) rc = streams_ready(h);
     if (rc) return rc;
     const size_t nn = (size_t)(n > 0 ? n : 1), bx = nn * xyz_stride, bn = nn * normals_stride;
-    if (bx > h->hs_xyz_cap || bn > h->hs_nrm_cap) KPL_HIP(h, hipStreamSynchronize(h->copy_stream ? h->copy_stream : h->stream));
+    if (bx > h->hs_xyz_cap || bn > h->hs_nrm_cap) KPL_HIP(h, hipStreamSynchronize(h->copy_stream));
     if (bx > h->hs_xyz_cap) {
         if (h->hs_xyz) (void)hipHostFree(h->hs_xyz);
         h->hs_xyz = nullptr;
@@ -1273,8 +1467,6 @@ int kpl_host_staging(kpl_detector *h, int n, size_t xyz_stride, size_t normals_s
         KPL_HIP(h, hipHostMalloc(&h->hs_nrm, bn + bn / 4, hipHostMallocDefault));
         h->hs_nrm_cap = bn + bn / 4;
     }
-    rc = ensure_copy_stream(h);
-    if (rc) return rc;
     h->hs_xs = xyz_stride;
     h->hs_ns = normals_stride;
     h->hs_n = n;
@@ -1291,6 +1483,7 @@ int kpl_detect_keypoints_staged(kpl_detector *h, int *kp_idx_out, float *kp_scor
     int rc = check_params_for_compute(h, true);
     if (rc) return rc;
     rc = use_device(h);
+    if (!rc) rc = streams_ready(h);
     if (rc) return rc;
     const int n = h->hs_n;
     const size_t nn = (size_t)(n > 0 ? n : 1);
@@ -1314,6 +1507,35 @@ int kpl_detect_keypoints_staged(kpl_detector *h, int *kp_idx_out, float *kp_scor
     h->index_valid = false;
     if (n > 0) estimate_neighborhood(h, h->hs_xyz, h->hs_xs, n);      // a first call only; the copies are on their way meanwhile
     return detect_staged(h, n, nullptr, kp_idx_out, kp_scores_out, kp_cap, kp_count, n > 0 ? h->ev_nrm : nullptr);
+}
+
+int kpl_reserve(kpl_detector *h, int n_points, size_t xyz_stride, size_t normals_stride) {
+    if (!h) return KPL_ERR_INVALID_ARG;
+    if (n_points < 0 || n_points >= (1 << 28)) return fail(h, KPL_ERR_INVALID_ARG, "n_points must be in 0 .. 2^28 - 1");
+    if ((xyz_stride && (xyz_stride < 12 || (xyz_stride & 3))) || (normals_stride && (normals_stride < 12 || (normals_stride & 3))))
+        return fail(h, KPL_ERR_INVALID_ARG, "strides must be 0 (no staging arrays) or multiples of 4 and >= 12 bytes");
+    int rc = use_device(h);
+    if (!rc) rc = streams_ready(h);
+    if (rc) return rc;
+    const size_t nn = (size_t)(n_points > 0 ? n_points : 1);
+    hipStream_t st = h->stream;
+    rc = enter_stream(h, st);
+    if (rc) return rc;
+    // the staging arrays of the host entry points belong to the bound view when it is a host view: never replaced here
+    const bool staged_view = h->bound && h->d_xyz == h->stage_xyz.as<char>();
+    if (!staged_view) {
+        if (xyz_stride) KPL_HIP(h, h->stage_xyz.ensure(nn * xyz_stride));
+        if (normals_stride) KPL_HIP(h, h->stage_nrm.ensure(nn * normals_stride));
+    }
+    rc = ensure_index_tables(h, n_points, st);
+    if (!rc && h->prm.n_annulus >= 1 && h->prm.n_bins >= 1 && (int64_t)h->prm.n_annulus * h->prm.n_bins <= 255)
+        rc = ensure_detect_scratch(h, n_points, st);
+    if (rc) return rc;
+    KPL_HIP(h, h->out_kp.ensure(sizeof(int) * nn));
+    KPL_HIP(h, h->out_kp_score.ensure(sizeof(float) * nn));
+    KPL_HIP(h, h->out_count.ensure(sizeof(int)));
+    KPL_HIP(h, hipStreamSynchronize(st));       // a set-up call: what it cleared is clear when it returns
+    return KPL_OK;
 }
 
 int kpl_sync_status(kpl_detector *h, void *stream) {
@@ -1500,6 +1722,7 @@ int kpl_estimate_normals_organized(kpl_detector *h, const void *xyz, size_t xyz_
         (curvature_out && (curvature_stride < 4 || (curvature_stride & 3))))
         return fail(h, KPL_ERR_INVALID_ARG, "strides must be multiples of 4 (points and normals >= 12 bytes)");
     int rc = use_device(h);
+    if (!rc) rc = streams_ready(h);
     if (rc) return rc;
     if (n == 0) return KPL_OK;
     const size_t nn = (size_t)n;

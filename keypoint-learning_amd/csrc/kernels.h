@@ -171,6 +171,8 @@ struct DevState {
     alignas(128) unsigned long long word_cursor[32];
 };
 void init_dev_state(DevState *host_copy);
+// loads the code objects of both kernel files now (kpl_create) instead of under the first launch of a compute()
+void preload_code();
 
 // ---- the three stages of compute(), each over every view of the batch ------------------------
 // index build ("initCompute"): needs the input + index fields of ViewDev

@@ -4355,6 +4355,16 @@ inline int div_up(int a, int b) { return (a + b - 1) / b; }
 // =============================================================================================
 // launch wrappers
 // =============================================================================================
+// Loads the code objects of libkpl's two kernel files (the runtime loads a code object when the first of its kernels is looked
+// up): kpl_create calls this so that no compute() pays for it.  Errors are not fatal here -- a launch would report them.
+void preload_organized_normals_code();
+void preload_code() {
+    hipFuncAttributes attr;
+    (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&bbox_kernel));
+    preload_organized_normals_code();
+    (void)hipGetLastError();
+}
+
 void init_dev_state(DevState *host_copy) {
     memset(host_copy, 0, sizeof(*host_copy));
     host_copy->scan_epoch = 1u;         // 0 = "never written" in the words of the compaction's scan

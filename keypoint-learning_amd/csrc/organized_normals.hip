@@ -210,6 +210,11 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 }  // namespace
 
+void preload_organized_normals_code() {        // (kernels.hip, preload_code)
+    hipFuncAttributes attr;
+    (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&on_init_kernel));
+}
+
 size_t organized_normals_scratch_bytes(int W, int H) {
     const size_t n = (size_t)(W > 0 ? W : 1) * (size_t)(H > 0 ? H : 1);
     return align256(n) + align256(sizeof(float) * n) + align256(sizeof(double) * 3 * (size_t)(W + 1) * (size_t)(H + 1));

@@ -1,0 +1,121 @@
+"""Round 6: the hints a handle carries from call to call must follow the views (advisor findings of round 5), kpl_reserve,
+the side-effect-free launch record, and a handle that changes streams."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _det(kpl, cases, A, B, r, rn, thr, sorted_search):
+    det = kpl.KeypointLearningDetector()
+    det.setNAnnulus(A); det.setNBins(B); det.setNonMaxima(True); det.setNonMaxRadius(rn)
+    det.setNonMaximaDrawsRemove(False); det.setPredictionThreshold(thr); det.setRadiusSearch(r)
+    det.setSortedSearch(sorted_search)
+    cases.load_arrays(det, cases.trained_forest(A, B))
+    return det
+
+
+def test_sorted_mode_hints_follow_a_stream_that_goes_from_dense_to_sparse(kpl, oracle, cases):
+    """One handle, one radius, views of one size: dense frames switch the handle to "every point straight to the collect / add
+    kernels" (all_large); that path measures no neighborhood lengths, and until round 5 the hint then stayed for good.  Now the
+    keys such a launch stores per listed point are looked at: sparse frames bring the register lists back."""
+    A, B = 5, 6
+    dense, nrm = cases.cloud(120, 100, seed=3)
+    mr = oracle.cloud_resolution(dense)
+    r, rn, thr = float(np.float32(10.5 * mr)), float(np.float32(4 * mr)), float(np.float32(0.5))
+    sparse = np.ascontiguousarray(dense * np.float32([3.0, 3.0, 1.0]))       # the same points, a ninth of the density
+    det = _det(kpl, cases, A, B, r, rn, thr, True)
+    of = cases.oracle_forest(cases.trained_forest(A, B))
+    want = {}
+    for name, xyz in (("dense", dense), ("sparse", sparse)):
+        want[name] = oracle.detect(xyz, nrm, A, B, r, rn, thr, of, order=oracle.ORDER_SORTED, threads=cases.usable_cores())
+    record = []
+    for name, xyz in [("dense", dense)] * 3 + [("sparse", sparse)] * 4 + [("dense", dense)] * 3:
+        det.setInputCloud(xyz)
+        det.setNormals(nrm)
+        _, scores = det.compute()
+        assert cases.same_bits(scores, want[name][0]), (name, len(record))
+        assert np.array_equal(det.getKeypointsIndices(), want[name][1]), (name, len(record))
+        record.append((name, det.getLastLaunch()["sorted_all_large"], det.getLastLaunch()["sorted_list_keys"]))
+    assert record[2][1] == 1, record                     # dense frames: every point listed at once
+    assert record[3][1] == 1, record                     # the first sparse frame still runs with the old hint ...
+    assert record[5][1] == 0 and record[6][1] == 0, record   # ... the later ones do not
+    assert record[6][2] < 128, record                    # and the list capacity follows what the register sort measured again
+    assert record[9][1] == 1, record                     # dense again: back to the wave / workgroup kernels
+
+
+def test_reserve_sizes_a_handle_before_its_first_call(kpl, oracle, cases):
+    A, B = 5, 6
+    xyz, nrm = cases.cloud()
+    mr = cases.resolution()
+    r, rn, thr = float(np.float32(6 * mr)), float(np.float32(4 * mr)), float(np.float32(0.85))
+    det = _det(kpl, cases, A, B, r, rn, thr, False)
+    det.reserve(len(xyz), 12, 12)
+    det.reserve(len(xyz) // 2, 16, 32)                   # smaller: nothing shrinks, nothing breaks
+    det.setInputCloud(xyz)
+    det.setNormals(nrm)
+    _, scores = det.compute()
+    o_scores, o_kp = oracle.detect(xyz, nrm, A, B, r, rn, thr, cases.oracle_forest(cases.trained_forest(A, B)))
+    assert cases.same_bits(scores, o_scores) and np.array_equal(det.getKeypointsIndices(), o_kp)
+    det.reserve(4 * len(xyz), 12, 12)                    # growing under a bound host view leaves the view alone
+    _, scores = det.compute()
+    assert cases.same_bits(scores, o_scores)
+    lib = kpl.load_library()
+    assert lib.kpl_reserve(det._h, -1, 12, 12) == kpl.ERR_INVALID_ARG
+    assert lib.kpl_reserve(det._h, 10, 7, 12) == kpl.ERR_INVALID_ARG
+    assert lib.kpl_reserve(None, 10, 12, 12) == kpl.ERR_INVALID_ARG
+
+
+def test_last_launch_is_a_plain_read_that_leaves_the_timing_alone(kpl, cases):
+    import torch
+    A, B = 5, 6
+    xyz, nrm = cases.cloud()
+    mr = cases.resolution()
+    det = _det(kpl, cases, A, B, float(np.float32(6 * mr)), float(np.float32(4 * mr)), 0.85, False)
+    dev = torch.device("cuda", 0)
+    dx, dn = torch.from_numpy(np.ascontiguousarray(xyz)).to(dev), torch.from_numpy(np.ascontiguousarray(nrm)).to(dev)
+    dk = torch.zeros(len(xyz) + 1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    det.bindCloudDevice(dx.data_ptr(), 12, dn.data_ptr(), 12, len(xyz))
+    det.enableTiming(True)
+    for _ in range(3):
+        det.computeDevice(None, dk[1:].data_ptr(), len(xyz), dk[0:1].data_ptr())
+    assert det.syncStatus(None) == kpl.OK
+    li = det.getLastLaunch()
+    assert li["walk"] == kpl.WALK_LANES and li["lanes_per_point"] == 2 and li["accept_words"] in (12, 16, 20, 24)
+    assert det.getLastLaunch() == li
+    t = det.getTiming()                                  # still everything that was recorded
+    assert t["calls"] == 3 and t["feature_ms"] > 0.0 and t["walk"] == li["walk"]
+
+
+def test_a_handle_that_moves_between_streams_is_ordered_without_a_host_wait(kpl, oracle, cases):
+    """device entry point on a caller's stream, then -- without waiting -- a host entry point on the handle's own stream with
+    another view: the second call grows and rewrites the handle's scratch while the first may still be running on the other
+    stream (advisor finding, round 5).  Both results must be the oracle's."""
+    import torch
+    A, B = 5, 6
+    big, bn = cases.cloud(160, 120, seed=5)
+    small, sn = cases.cloud()
+    mr = cases.resolution()
+    r, rn, thr = float(np.float32(6 * mr)), float(np.float32(4 * mr)), float(np.float32(0.5))
+    of = cases.oracle_forest(cases.trained_forest(A, B))
+    w_small = oracle.detect(small, sn, A, B, r, rn, thr, of)
+    w_big = oracle.detect(big, bn, A, B, r, rn, thr, of)
+    dev = torch.device("cuda", 0)
+    ds, dsn = torch.from_numpy(np.ascontiguousarray(small)).to(dev), torch.from_numpy(np.ascontiguousarray(sn)).to(dev)
+    sc = torch.zeros(len(small), dtype=torch.float32, device=dev)
+    dk = torch.zeros(len(small) + 1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    for rep in range(6):
+        det = _det(kpl, cases, A, B, r, rn, thr, False)
+        det.bindCloudDevice(ds.data_ptr(), 12, dsn.data_ptr(), 12, len(small))
+        det.computeDevice(sc.data_ptr(), dk[1:].data_ptr(), len(small), dk[0:1].data_ptr(), side.cuda_stream)
+        det.setInputCloud(big)                           # host view, larger: every table of the handle is replaced
+        det.setNormals(bn)
+        _, scores = det.compute()
+        assert cases.same_bits(scores, w_big[0]) and np.array_equal(det.getKeypointsIndices(), w_big[1]), rep
+        side.synchronize()
+        k = int(dk[0].item())
+        assert k == len(w_small[1]) and np.array_equal(dk[1:1 + k].cpu().numpy(), w_small[1]), rep
+        assert cases.same_bits(sc.cpu().numpy(), w_small[0]), rep

@@ -11,12 +11,15 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+HOOKS_LIB = os.path.join(ROOT, "tests", "csrc", "libkpl_testhooks.so")     # api.cpp built with -DKPL_TEST_HOOKS (build.py)
+
 _FORCED_TIMEOUT = r"""
-import importlib, os, sys
+import ctypes, importlib, os, sys
 import numpy as np
 sys.path.insert(0, %(root)r)
 from tests import helpers
-kpl = importlib.import_module("keypoint-learning_amd")
+kpl = importlib.import_module("keypoint-learning_amd")      # KPL_LIB_PATH = the library with the test hooks (include/kpl_debug.h)
+kpl.load_library().kpl_debug_set_scan_poll_limit.argtypes = [ctypes.c_void_p, ctypes.c_int]
 A, B = 5, 6
 xyz, nrm = helpers.cloud(120, 90)                      # 10 800 points: three blocks of the compaction's scan
 mr = helpers.resolution()
@@ -48,7 +51,8 @@ print("recovered", bool(np.array_equal(k1, k2) and helpers.same_bits(s1, s2)), l
 def test_scan_look_back_timeout_is_an_error_not_a_count():
     """compact_scan_kernel's look-back gives up -> KPL_ERR_INTERNAL from the host entry point (kernels.hip; forced through
     kpl_debug_set_scan_poll_limit on that handle, in a child process), and the handle recovers."""
-    out = subprocess.run([sys.executable, "-c", _FORCED_TIMEOUT % {"root": ROOT}], capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, "-c", _FORCED_TIMEOUT % {"root": ROOT}], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, KPL_LIB_PATH=HOOKS_LIB))
     assert out.returncode == 0, out.stderr[-2000:]
     lines = out.stdout.strip().splitlines()
     assert lines[0].startswith("status 12 internal"), out.stdout
@@ -80,7 +84,8 @@ try:
 except kpl.KplError as e:
     print("again", e.status)          # the limit of this handle is still -1: fails again, never hangs
 """
-    out = subprocess.run([sys.executable, "-c", code % {"root": ROOT}], capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, "-c", code % {"root": ROOT}], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, KPL_LIB_PATH=HOOKS_LIB))
     assert out.returncode == 0, out.stderr[-2000:]
     lines = out.stdout.strip().splitlines()
     assert lines[0] == "raised 12 -1", out.stdout

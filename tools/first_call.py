@@ -27,8 +27,11 @@ def main():
                 f.write("%.9g %.9g %.9g\n" % (p[0], p[1], p[2]))
         for walk in ["auto", "lanes2", "twopass4"]:
             for rep in range(2):
-                out = subprocess.run([EXE, "--pathCloud", cloud, "--pathRF", FOREST, "--json", "--walk", walk] + sys.argv[1:],
+                extra = [a for a in sys.argv[1:] if a != "--trace"]
+                out = subprocess.run([EXE, "--pathCloud", cloud, "--pathRF", FOREST, "--json", "--walk", walk] + extra,
                                      capture_output=True, text=True, timeout=600)
+                if "--trace" in sys.argv[1:]:      # a scratch libkpl built with -DKPL_TRACE_HOST (LD_PRELOAD) stamps its steps on stderr
+                    print(out.stderr, flush=True)
                 if out.returncode != 0:
                     print(out.stderr[-2000:])
                     return 1
