@@ -113,7 +113,9 @@ public:
         }
         this->input_ = cloud;
         // the view's size is known from here on: the engine's tables for it are sized now, not inside compute() (kpl_reserve)
+#ifndef KPL_NO_RESERVE
         if (handle_ && cloud) kpl_reserve(handle_, (int)cloud->points.size(), sizeof(PointInT), sizeof(NormalT));
+#endif
         if (host_staging_) stage_points();
     }
     virtual void setNormals(const PointCloudNConstPtr &normals) {

@@ -58,7 +58,7 @@ struct DevBuf {
     hipError_t ensure(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
         release();
-        size_t want = bytes + bytes / 4 + 256;
+        size_t want = (bytes + bytes / 4 + 256 + 3) & ~(size_t)3;
         hipError_t e = hipMalloc(&p, want);
         if (e == hipSuccess) cap = want;
         return e;
@@ -69,12 +69,15 @@ struct DevBuf {
     // array that came from hipMalloc is parked and freed with the handle.
     hipError_t ensure(size_t bytes, hipStream_t st, std::vector<void *> &parked, bool zero = false) {
         if (bytes <= cap) return hipSuccess;
-        const size_t want = bytes + bytes / 4 + 256;
+        const size_t want = (bytes + bytes / 4 + 256 + 3) & ~(size_t)3;
         void *np = nullptr;
         hipError_t e = hipMallocAsync(&np, want, st);
         if (e != hipSuccess) return e;
         if (zero) {
-            e = hipMemsetAsync(np, 0, want, st);
+            // cleared by a kernel of this library, in the order of the stream like every other kernel of the call -- not by
+            // hipMemsetAsync (see setup_host_path: the one unexplained event of round 6 had a runtime clear of pool memory in it)
+            kpl::launch_zero(np, want & ~(size_t)3, st);
+            e = hipGetLastError();
             if (e != hipSuccess) {
                 (void)hipFreeAsync(np, st);
                 return e;
@@ -168,12 +171,12 @@ struct kpl_detector {
     void *h_res = nullptr;        // pinned landing zone of the keypoint lists (host-buffer entry points)
     size_t h_res_cap = 0;
     // What the HOST entry points need and the device entry points do not -- the handle's two streams (8-9 ms each to create
-    // on this runtime: a hardware queue), the pinned landing buffer, and the first use of the copy paths (the first 128 KiB
-    // device-to-pinned copy of a process takes 7-8 ms, so does its first copy out of pageable memory;
-    // tools/probes/host_cost_probe.cpp, profiles/r06_first_call.jsonl) -- is set up by a thread that kpl_create starts and the
+    // on this runtime: a hardware queue), the pinned landing buffer, and the first use of the device-to-pinned copy path (the
+    // first 128 KiB copy of a handle's stream into pinned memory took 7-8 ms; tools/probes/host_cost_probe.cpp,
+    // profiles/r06_first_call.jsonl) -- is set up by a thread that kpl_create starts and the
     // first host entry point joins (streams_ready): a drop-in TestDetector run loads its forest and reads its cloud in the
     // meantime, and its ONE compute() no longer pays 17 of its 18 ms for set-up.  Until the join the thread owns
-    // stream / copy_stream / ev_xyz / ev_nrm / h_res*, nothing else.
+    // stream / copy_stream / ev_xyz / ev_nrm / h_res* / out_kp, nothing else.
     // the stream of the handle's last enqueuing call: the scratch -- and its stream-ordered growth -- belongs to the handle, so a
     // call that arrives on ANOTHER stream first makes that stream wait for what the earlier one has queued (enter_stream)
     hipStream_t last_st = nullptr;
@@ -828,18 +831,15 @@ void setup_host_path(kpl_detector *h) {
     const size_t landing = kLandingEntries * (sizeof(int) + sizeof(float));
     if (e == hipSuccess) e = hipHostMalloc(&h->h_res, landing + landing / 2 + 4096, hipHostMallocDefault);
     if (e == hipSuccess) h->h_res_cap = landing + landing / 2 + 4096;
-    // first use of the copy paths, on the stream that will use them (results are thrown away)
-    void *tmp = nullptr;
-    const size_t warm = kLandingEntries * sizeof(int);
-    if (e == hipSuccess) e = hipMallocAsync(&tmp, 2 * warm, h->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(tmp, 0, 2 * warm, h->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(h->h_res, tmp, warm, hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess) {
-        std::vector<char> pageable(2 * warm, 0);
-        e = hipMemcpyAsync(tmp, pageable.data(), 2 * warm, hipMemcpyHostToDevice, h->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);       // (the vector must outlive the copy)
-    }
-    if (tmp) (void)hipFreeAsync(tmp, h->stream);
+    // first use of the device-to-pinned copy path, on the stream that will use it: the first 128 KiB copy into pinned memory
+    // took 7-8 ms inside the first compute().  The source is the handle's own keypoint array (plain hipMalloc, kept), the
+    // result is thrown away.  NOT through a stream-ordered scratch block: a block from hipMallocAsync that was cleared with
+    // hipMemsetAsync and freed again here made the first compute() of every second handle of a process count no keypoints
+    // (flags all zero at the compaction; scores right; the second call right) -- reproduced with the C API alone, not
+    // reproduced outside libkpl (tools/probes/memset_order_probe.cpp), gone without the clear or without the pool
+    // (profiles/r06_notes.md).  No copy out of pageable memory either: this thread runs next to the caller's loadForest.
+    if (e == hipSuccess) e = h->out_kp.ensure(kLandingEntries * sizeof(int));
+    if (e == hipSuccess) e = hipMemcpyAsync(h->h_res, h->out_kp.p, kLandingEntries * sizeof(int), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     h->setup_err = e;
 }

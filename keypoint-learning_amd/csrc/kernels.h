@@ -171,6 +171,8 @@ struct DevState {
     alignas(128) unsigned long long word_cursor[32];
 };
 void init_dev_state(DevState *host_copy);
+// clears bytes (a multiple of 4) at p with a kernel on `st`
+void launch_zero(void *p, size_t bytes, hipStream_t st);
 // loads the code objects of both kernel files now (kpl_create) instead of under the first launch of a compute()
 void preload_code();
 

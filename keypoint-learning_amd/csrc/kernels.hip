@@ -4365,6 +4365,18 @@ void preload_code() {
     (void)hipGetLastError();
 }
 
+// clears `bytes` (a multiple of 4) at p, as a kernel of this library on the caller's stream (DevBuf::ensure)
+__global__ __launch_bounds__(256) void zero_words_kernel(uint32_t *p, size_t words) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+void launch_zero(void *p, size_t bytes, hipStream_t st) {
+    const size_t words = bytes / 4;
+    if (words == 0) return;
+    size_t blocks = (words + 1023) / 1024;
+    if (blocks > 4096) blocks = 4096;
+    zero_words_kernel<<<dim3((unsigned)blocks), 256, 0, st>>>(static_cast<uint32_t *>(p), words);
+}
+
 void init_dev_state(DevState *host_copy) {
     memset(host_copy, 0, sizeof(*host_copy));
     host_copy->scan_epoch = 1u;         // 0 = "never written" in the words of the compaction's scan

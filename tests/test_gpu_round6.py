@@ -119,3 +119,35 @@ def test_a_handle_that_moves_between_streams_is_ordered_without_a_host_wait(kpl,
         k = int(dk[0].item())
         assert k == len(w_small[1]) and np.array_equal(dk[1:1 + k].cpu().numpy(), w_small[1]), rep
         assert cases.same_bits(sc.cpu().numpy(), w_small[0]), rep
+
+
+def test_every_fresh_handle_of_a_process_counts_its_keypoints(kpl, oracle, cases):
+    """The one unexplained event of round 6 (profiles/r06_notes.md): with a stream-ordered scratch block cleared and freed in a
+    handle's set-up, the FIRST compute() of every second handle of a process returned no keypoints (scores right, second
+    call right).  Handles are created, used once through the keypoints-only entry point and destroyed, in the order that
+    failed (sorted, sorted, canonical without NMS, canonical with NMS, ...)."""
+    A, B = 5, 6
+    xyz, nrm = cases.cloud(40, 40, seed=7, nan_points=5, nan_normals=7)
+    mr = oracle.cloud_resolution(xyz)
+    r, rn = float(np.float32(6 * mr)), float(np.float32(4 * mr))
+    of = cases.oracle_forest(cases.trained_forest(A, B))
+    want = {}
+    for srt in (False, True):
+        for thr in (0.0, 0.5):
+            want[(srt, thr)] = oracle.detect(xyz, nrm, A, B, r, rn, float(np.float32(thr)), of,
+                                             order=oracle.ORDER_SORTED if srt else oracle.ORDER_CANONICAL)
+    scoreable = int(np.isfinite(want[(False, 0.0)][0]).sum())
+    for rep in range(3):
+        for srt, thr, nms in [(True, 0.5, False), (True, 0.5, True), (False, 0.0, False), (False, 0.0, True),
+                              (False, 0.5, True), (False, 0.5, False)]:
+            det = _det(kpl, cases, A, B, r, rn, float(np.float32(thr)), srt)
+            det.setNonMaxima(nms)
+            det.setInputCloud(xyz)
+            det.setNormals(nrm)
+            kp, _ = det.compute(with_scores=False)
+            idx = det.getKeypointsIndices()
+            if nms:
+                assert np.array_equal(idx, want[(srt, thr)][1]), (rep, srt, thr, nms, len(idx))
+            else:
+                assert len(idx) == scoreable, (rep, srt, thr, nms, len(idx))
+            del det
