@@ -141,10 +141,11 @@ struct kpl_detector {
     int lcap_hint = 0;            // sorted-search mode: keys per point the lists of the register-sort kernel need (0: not known = 128),
     double lcap_hint_radius = 0.0;    // ... for this feature radius
     bool all_large_hint = false;  // sorted-search mode: the last call at that radius listed a quarter of the view's points or more for the collect / add kernels
+    bool all_huge_hint = false;   // ... and stored more than 1 024 keys per listed point: all of them for the workgroup-per-point kernel
     int all_large_n = 0;
     double launched_radius = 0.0; // feature radius / points of the last scoring launch (what the next read-back describes)
     int launched_n = 0;
-    bool launched_all_large = false;   // ... and whether it ran with FeatDesc::all_large
+    int launched_all_large = 0;        // ... and FeatDesc::all_large it ran with
     int last_lcap = 0;            // sorted-search mode: list capacity / all_large of the last launch (kpl_get_last_launch)
     float origin[3] = {0.0f, 0.0f, 0.0f};
 
@@ -527,7 +528,10 @@ int sync_status(kpl_detector *h, hipStream_t st) {
         h->all_large_hint = h->launched_n > 0 && (long long)h->h_state->large_seen * 4 >= (long long)h->launched_n;
         h->all_large_n = h->launched_n;
         KPL_HIP(h, hipMemsetAsync((char *)h->dstate.p + offsetof(DevState, kf_max), 0, sizeof(int), st));
-    } else if (h->launched_all_large && h->h_state->status == kStatusOk) {
+    }
+    if (h->h_state->status == kStatusOk && h->h_state->large_seen > 0)     // (a view whose points mostly hold thousands of neighbors: see FeatDesc::all_large == 2)
+        h->all_huge_hint = (double)h->h_state->keys_needed > 1024.0 * (double)h->h_state->large_seen;
+    if (h->h_state->kf_max <= 0 && h->launched_all_large && h->h_state->status == kStatusOk) {
         // A launch with all_large sends every point to the collect / add kernels, so the register-sort kernel measures nothing
         // (kf_max stays 0) and the hint would never be looked at again: a stream of views of one size at one radius that went
         // from dense to sparse would stay on the slow path for good.  What such a launch does measure is the number of keys it
@@ -599,6 +603,7 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
     if (feat.sorted && h->lcap_hint > 0 && h->lcap_hint_radius == h->prm.radius_search) {
         feat.lcap = h->lcap_hint;
         feat.all_large = h->all_large_hint && (long long)n * 4 >= (long long)h->all_large_n * 3 && (long long)n * 3 <= (long long)h->all_large_n * 4 ? 1 : 0;
+        if (feat.all_large && h->all_huge_hint) feat.all_large = 2;
     }
     if (!feat.sorted && feat.walk == 1) {
         // two-pass walk: the accept words of every point's whole walk (8-byte entries in the array the sorted mode keeps its
@@ -632,7 +637,7 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
     h->last_lanes = feat.sorted ? 0 : feat.lanes;
     h->last_words = (!feat.sorted && feat.walk == 0) ? (feat.words > 0 ? feat.words : 24) : 0;
     h->last_lcap = feat.sorted ? (feat.lcap > 0 ? feat.lcap : 128) : 0;
-    h->launched_all_large = feat.sorted && feat.all_large;
+    h->launched_all_large = feat.sorted ? feat.all_large : 0;
     if (!feat.sorted && feat.walk == 1) {
         KPL_HIP(h, h->seg_start.ensure(sizeof(unsigned) * nn, st, h->parked));
         KPL_HIP(h, h->seg_len.ensure(sizeof(int) * nn, st, h->parked));
@@ -1148,7 +1153,7 @@ int kpl_get_last_launch(const kpl_detector *h, kpl_launch_info *out) {
     out->lanes_per_point = h->last_lanes;
     out->accept_words = h->last_words;
     out->sorted_list_keys = h->last_lcap;
-    out->sorted_all_large = h->launched_all_large ? 1 : 0;
+    out->sorted_all_large = h->launched_all_large;
     return KPL_OK;
 }
 

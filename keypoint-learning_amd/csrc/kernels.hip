@@ -2463,7 +2463,9 @@ __global__ __launch_bounds__(kLanes) void feature_sorted_kernel(Batch b, int max
     const int own_cell = own_cell_population(v.ds->grid, v.cell_start, w);
     // (all_large: the handle's last call ended up listing nearly every point, most of them after a search that filled their
     // register lists for nothing -- 1.5 of 7.6 ms for 8 x 200 k points at 10 mesh resolutions)
-    const bool large = own_cell > kLargeCell || (v.f.all_large && w.scoreable), huge = own_cell > kHugeCell;
+    // (all_large == 2: the handle's last call stored more than a thousand keys per listed point -- the reference's default radius:
+    // 2 300 --: every point is for the workgroup kernel, the wave-per-point kernel is not even launched)
+    const bool large = own_cell > kLargeCell || (v.f.all_large && w.scoreable), huge = own_cell > kHugeCell || (v.f.all_large == 2 && w.scoreable);
     uint2 *ent = reinterpret_cast<uint2 *>(H + maxF * kPts);
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(ent + ecap * kPts);
     bool deferred = false;
@@ -4615,7 +4617,9 @@ void launch_feature_stage(const Batch &b, hipStream_t st) {
         }
         int wwgs = div_up(cu_count() * wave_wgs_per_cu, b.nviews);
         if (wwgs > div_up(n, kWaveCollectWaves)) wwgs = div_up(n, kWaveCollectWaves);
-        sorted_collect_wave_kernel<<<dim3(wwgs, b.nviews), kWaveCollectWaves * kWave, 0, st>>>(b, by_xcd);
+        bool all_huge = true;               // every sorted view lists all of its points for the workgroup kernel: nothing for this one
+        for (int v = 0; v < b.nviews; ++v) all_huge = all_huge && (!b.view[v].f.sorted || b.view[v].f.all_large == 2);
+        if (!all_huge) sorted_collect_wave_kernel<<<dim3(wwgs, b.nviews), kWaveCollectWaves * kWave, 0, st>>>(b, by_xcd);
         int wgs = div_up(cu_count() * 4, b.nviews);             // persistent: four workgroups per CU (37 KB of LDS each)
         if (wgs > n) wgs = n;
         sorted_collect_kernel<<<dim3(wgs, b.nviews), kCollectThreads, 0, st>>>(b);
