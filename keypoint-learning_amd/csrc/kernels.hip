@@ -179,12 +179,19 @@ __global__ void grid_setup_kernel(Batch b) {
 // ---------------------------------------------------------------------------------------------
 // exclusive scan (3 launches): chunk sums -> scan of sums -> per-chunk scan with carry
 // ---------------------------------------------------------------------------------------------
+// One wave per workgroup: in the pipelined mode (two batches in flight) these kernels queue behind the other batch's feature
+// kernel, which fills the register files; a 256-thread workgroup needs four free wave slots on ONE CU at once, a 64-thread one
+// fits any slot that comes free.  compact_scan_kernel under the bench: avg 39.6 -> 20.5 us, max 520 -> 50 (profiles/r06_notes.md).
+// (compact_scan_kernel<64>, the NMS kernel and, for a batch, bucket_total / bucket_offsets; the three-kernel scan of the draws
+// pass keeps 256.)
 constexpr int kScanBlock = 256;
+constexpr int kCompactBatchBlock = 64;        // threads of compact_scan_kernel for a batch; kScanBlock for one view alone (fewer, longer blocks: the shorter look-back chain)
 constexpr int kScanPerThread = 16;
 constexpr int kScanChunk = kScanBlock * kScanPerThread;
 
+template <int BLOCK = kScanBlock>
 __device__ __forceinline__ int block_exclusive_scan(int v, int *total) {
-    __shared__ int wave_sum[kScanBlock / kWave];
+    __shared__ int wave_sum[BLOCK / kWave];
     const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
     int incl = v;
     for (int off = 1; off < kWave; off <<= 1) {
@@ -194,7 +201,7 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *total) {
     if (lane == kWave - 1) wave_sum[wid] = incl;
     __syncthreads();
     int base = 0, tot = 0;
-    for (int w = 0; w < kScanBlock / kWave; ++w) {
+    for (int w = 0; w < BLOCK / kWave; ++w) {
         int s = wave_sum[w];
         if (w < wid) base += s;
         tot += s;
@@ -454,14 +461,16 @@ __global__ __launch_bounds__(256) void bucket_total_kernel(Batch b, int chunk_pt
 // scans the kBins totals for itself (they are few); then one wave per bin scans the bin's chunks.
 // (Totals and starts are separate arrays: the blocks of this launch read ALL totals and finish at
 // different times.)
-__global__ __launch_bounds__(256) void bucket_offsets_kernel(Batch b, int chunk_pts) {
+// T threads per workgroup: 256 for one view alone (the shortest chain), 64 for a batch (see kScanBlock)
+template <int T>
+__global__ __launch_bounds__(T) void bucket_offsets_kernel(Batch b, int chunk_pts) {
     const ViewDev &v = b.view[blockIdx.y];
     __shared__ int tot[kBins];
-    __shared__ int wsum[256 / kWave];
+    __shared__ int wsum[T / kWave];
     for (int k = threadIdx.x; k < kBins; k += blockDim.x) tot[k] = v.btotal[k];
     __syncthreads();
-    // exclusive scan of tot[] by the block: 256 threads x ceil(kBins / 256) consecutive bins each
-    constexpr int kPer = (kBins + 255) / 256;
+    // exclusive scan of tot[] by the block: T threads x ceil(kBins / T) consecutive bins each
+    constexpr int kPer = (kBins + T - 1) / T;
     const int first = threadIdx.x * kPer;
     int mine = 0;
     for (int k = 0; k < kPer; ++k) mine += first + k < kBins ? tot[first + k] : 0;
@@ -4211,11 +4220,13 @@ __device__ __forceinline__ void scan_publish(unsigned long long *word, unsigned 
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ __launch_bounds__(kScanBlock) void compact_scan_kernel(Batch b) {
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void compact_scan_kernel(Batch b) {
+    constexpr int kChunk = BLOCK * kScanPerThread;            // flags per block
     const ViewDev &v = b.view[blockIdx.y];
     const int poll_limit = v.nd.scan_poll_limit;       // (of the view's handle: kpl_debug_set_scan_poll_limit)
     const int n = v.n, kp_cap = v.kp_cap;
-    const int nb = n > 0 ? (n + kScanChunk - 1) / kScanChunk : 1;      // blocks of this view (block 0 exists for an empty view too)
+    const int nb = n > 0 ? (n + kChunk - 1) / kChunk : 1;      // blocks of this view (block 0 exists for an empty view too)
     if ((int)blockIdx.x >= nb) return;
     int *flags = v.flags;
     int *skip = v.nd.draws_remove ? v.skip : nullptr;
@@ -4224,7 +4235,7 @@ __global__ __launch_bounds__(kScanBlock) void compact_scan_kernel(Batch b) {
     // captured hipGraph gets a fresh tag every time, which a tag passed as a kernel argument would not.  Read ONCE, as an
     // atomic load: the last block rewrites the field while earlier blocks may still be in their look-back
     const unsigned epoch = __hip_atomic_load(&v.ds->scan_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int base = blockIdx.x * kScanChunk + threadIdx.x * kScanPerThread;
+    const int base = blockIdx.x * kChunk + threadIdx.x * kScanPerThread;
     int f[kScanPerThread];
     int s = 0;
     const bool whole = base + kScanPerThread <= n;
@@ -4249,7 +4260,7 @@ __global__ __launch_bounds__(kScanBlock) void compact_scan_kernel(Batch b) {
 #pragma unroll
     for (int k = 0; k < kScanPerThread; ++k) s += f[k] != 0 ? 1 : 0;
     int total;
-    const int excl = block_exclusive_scan(s, &total);
+    const int excl = block_exclusive_scan<BLOCK>(s, &total);
     __shared__ int carry;
     if (threadIdx.x < kWave) {                               // the first wave: publish, look back, publish
         const int lane = threadIdx.x;
@@ -4431,8 +4442,13 @@ void launch_index_points(const Batch &b, hipStream_t st) {
     grid_setup_kernel<<<dim3(1, nv), 64, 0, st>>>(b);
     const int chunk_pts = sort_chunk_points(b);
     if (n > 0) bucket_hist_kernel<<<dim3(sort_chunks(n, chunk_pts), nv), kWave, 0, st>>>(b, chunk_pts);
-    bucket_total_kernel<<<dim3(div_up(kBins, 256 / kWave), nv), 256, 0, st>>>(b, chunk_pts);
-    bucket_offsets_kernel<<<dim3(div_up(kBins, 256 / kWave), nv), 256, 0, st>>>(b, chunk_pts);
+    if (nv >= 2) {          // a batch: one wave per workgroup (see kScanBlock)
+        bucket_total_kernel<<<dim3(kBins, nv), kWave, 0, st>>>(b, chunk_pts);
+        bucket_offsets_kernel<kWave><<<dim3(kBins, nv), kWave, 0, st>>>(b, chunk_pts);
+    } else {                // one view alone on the GPU: the shortest chain (0.046 against 0.049 ms of index build on 62 k points)
+        bucket_total_kernel<<<dim3(div_up(kBins, 256 / kWave), nv), 256, 0, st>>>(b, chunk_pts);
+        bucket_offsets_kernel<256><<<dim3(div_up(kBins, 256 / kWave), nv), 256, 0, st>>>(b, chunk_pts);
+    }
 }
 
 // second half: from the scatter on the NORMALS are read too (the 32-byte record travels with the key)
@@ -4748,12 +4764,13 @@ void launch_post(const Batch &b, hipStream_t st) {
         int blocks = div_up(n, 256 / L);                // at most one group per point ...
         const int most = nv >= 2 ? 128 : 2048;          // ... but a few waves per SIMD are plenty
         if (blocks > most) blocks = most;
-        const dim3 grid(blocks, nv);
         const int many = 5 * blocks * (256 / 16) / 4;   // more candidates than the groups of 16 take in about one round
-        if (nv >= 2) {
-            if (stats) nms_kernel<true, 4, 0><<<grid, 256, 0, st>>>(b, 0);
-            else nms_kernel<false, 4, 0><<<grid, 256, 0, st>>>(b, 0);
+        if (nv >= 2) {      // a batch: workgroups of ONE wave (see kScanBlock): nms_kernel avg 118 -> 101 us, max 641 -> 186 under the bench
+            const dim3 grid(blocks * 4, nv);
+            if (stats) nms_kernel<true, 4, 0><<<grid, kWave, 0, st>>>(b, 0);
+            else nms_kernel<false, 4, 0><<<grid, kWave, 0, st>>>(b, 0);
         } else {
+            const dim3 grid(blocks, nv);
             if (stats) nms_kernel<true, 16, 8><<<grid, 256, 0, st>>>(b, many);
             else nms_kernel<false, 16, 8><<<grid, 256, 0, st>>>(b, many);
         }
@@ -4775,10 +4792,11 @@ void launch_post(const Batch &b, hipStream_t st) {
                                 sizeof(uint32_t) * (size_t)lds_words + sizeof(int) * (size_t)kRestWaves * kWave * kDrawAdj, st>>>(b, lds_words);
         }
     }
-    compact_scan_kernel<<<dim3(n > 0 ? div_up(n, kScanChunk) : 1, nv), kScanBlock, 0, st>>>(b);
+    if (nv >= 2) compact_scan_kernel<kCompactBatchBlock><<<dim3(n > 0 ? div_up(n, kCompactBatchBlock * kScanPerThread) : 1, nv), kCompactBatchBlock, 0, st>>>(b);
+    else compact_scan_kernel<kScanBlock><<<dim3(n > 0 ? div_up(n, kScanChunk) : 1, nv), kScanBlock, 0, st>>>(b);
 }
 
-size_t scan_state_bytes(int n) { return sizeof(unsigned long long) * ((size_t)(n > 0 ? n : 1) / kScanChunk + 2); }
+size_t scan_state_bytes(int n) { return sizeof(unsigned long long) * ((size_t)(n > 0 ? n : 1) / (kCompactBatchBlock * kScanPerThread) + 2); }      // (the smaller blocks' count)
 
 void launch_resolution(const float4 *pts, const int *cell_start, const int *pos_of, const DevState *ds,
                        int n, float *val, double *out, void *scratch, hipStream_t st) {
