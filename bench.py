@@ -101,6 +101,98 @@ def iso_ms_val(t):
     return t["feature_ms"] / max(t["calls"], 1)
 
 
+def reference_defaults(kpl, torch, dev, local_rank):
+    """TestDetector with no options: tests/golden/cheff001.npz (the reference's data file + k = 10 normals), the 50-variable
+    fixture forest.  Device-resident compute() in both neighbor orders (keypoint lists against the committed fixture), the
+    class's host-array call warm and on a FRESH handle, and -- the true one-shot figure -- the TestDetector binary as a child
+    process."""
+    import ctypes as C
+    import subprocess
+    import tempfile
+    z = np.load(os.path.join(ROOT, "tests", "golden", "cheff001.npz"))
+    forest = os.path.join(ROOT, "data", "forests", "cheff_a5b10_t10.yaml.gz")
+    xyz, nrm = np.ascontiguousarray(z["xyz"], np.float32), np.ascontiguousarray(z["nrm"], np.float32)
+    n = len(xyz)
+    r, rn, thr = float(z["r_feat"]), float(z["r_nms"]), float(z["thr"])
+
+    def make(sorted_search):
+        d = kpl.KeypointLearningDetector(device=local_rank)
+        d.setNAnnulus(5); d.setNBins(10); d.setNonMaxima(True); d.setNonMaximaDrawsRemove(False)
+        d.setNonMaxRadius(rn); d.setPredictionThreshold(thr); d.setRadiusSearch(r); d.setSortedSearch(sorted_search)
+        if not d.loadForest(forest):
+            raise RuntimeError(d.lastError())
+        return d
+    out = {"what": "the reference main's defaults: cheff001 (%d points), radiusFeatures 20, radiusNMS 4, threshold 0.85, 5 x 10" % n}
+    # the real thing first: one TestDetector process, one detector, one compute() (a CHILD process; exit code checked), on the
+    # cloud as the reference ships it (data/point_cloud_test/cheff001.pcd is DATA ascii)
+    exe = os.path.join(ROOT, "keypoint-learning_amd", "TestDetector")
+    if os.path.exists(exe):
+        with tempfile.TemporaryDirectory() as tmp:
+            cloud = os.path.join(tmp, "cheff001.pcd")
+            with open(cloud, "w") as f:
+                f.write("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\n"
+                        "WIDTH %d\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS %d\nDATA ascii\n" % (n, n))
+                f.write("\n".join("%.9g %.9g %.9g" % (p[0], p[1], p[2]) for p in xyz) + "\n")
+            rows = []
+            for extra in ([], ["--sortedSearch"]):
+                res = subprocess.run([exe, "--pathCloud", cloud, "--pathRF", forest, "--json"] + extra, capture_output=True, text=True, timeout=300)
+                if res.returncode == 0 and res.stdout.strip():
+                    j = json.loads(res.stdout.strip().splitlines()[-1])
+                    rows.append({"options": " ".join(extra) or "(none)", "first_compute_ms": round(j["compute_first_s"] * 1e3, 3),
+                                 "warm_compute_ms": round(j["compute_s"] * 1e3, 3), "prepare_ms": round(j["prepare_s"] * 1e3, 3),
+                                 "keypoints": j["keypoints"], "walk": j["walk"]})
+            out["test_detector_process"] = rows
+    dx, dn = torch.from_numpy(xyz).to(dev), torch.from_numpy(nrm).to(dev)
+    dk = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+    st = torch.cuda.Stream()
+    for name, srt, want in (("canonical", False, z["kp_canonical"]), ("sorted", True, z["kp_sorted"])):
+        d = make(srt)
+        d.bindCloudDevice(dx.data_ptr(), 12, dn.data_ptr(), 12, n)
+        for _ in range(6):                 # (tables / key array / word list grow, the handle measures the neighborhood)
+            d.computeDevice(None, dk[1:].data_ptr(), n, dk[0:1].data_ptr(), st.cuda_stream)
+            st.synchronize()
+            d.syncStatus(st.cuda_stream)
+        d.enableTiming(True)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            d.computeDevice(None, dk[1:].data_ptr(), n, dk[0:1].data_ptr(), st.cuda_stream)
+        st.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3 / 20
+        assert d.syncStatus(st.cuda_stream) == kpl.OK
+        t = d.getTiming()
+        k = int(dk[0].item())
+        out[name] = {"compute_ms": round(ms, 4), "Mpoints_per_s": round(n / ms / 1e3, 2),
+                     "phases_ms": {q: round(t[q] / max(t["calls"], 1), 4) for q in ("index_ms", "feature_ms", "forest_ms", "nms_ms")},
+                     "launch": d.getLastLaunch(), "keypoints": k,
+                     "keypoints_equal_fixture": bool(k == len(want) and np.array_equal(dk[1:1 + k].cpu().numpy(), want))}
+    # the class's own call: host arrays in PCL's layouts, kpl_detect_keypoints (PCIe inclusive)
+    pcl_xyz, pcl_nrm = np.zeros((n, 4), np.float32), np.zeros((n, 8), np.float32)
+    pcl_xyz[:, :3], pcl_nrm[:, :3] = xyz, nrm
+    h_kp, h_kps, h_cnt = np.empty(n, np.int32), np.empty(n, np.float32), C.c_int()
+
+    def host_call(d):
+        d._push()
+        c0 = time.perf_counter()
+        rc = d._lib.kpl_detect_keypoints(d._h, pcl_xyz.ctypes.data, 16, pcl_nrm.ctypes.data, 32, n, h_kp.ctypes.data,
+                                         h_kps.ctypes.data, n, C.byref(h_cnt))
+        ms = (time.perf_counter() - c0) * 1e3
+        if rc != 0:
+            raise RuntimeError(d.lastError())
+        return ms
+    fresh = make(False)
+    fresh._lib.kpl_reserve(fresh._h, n, 16, 32)        # (what the class does in setInputCloud)
+    time.sleep(0.05)                                   # (a caller reads its cloud here; the handle's set-up thread runs meanwhile)
+    first_ms = host_call(fresh)
+    warm = sorted(host_call(fresh) for _ in range(12))
+    # (the first call of a fresh handle INSIDE this long-lived process also meets whatever the earlier phases of the bench left in the
+    # device's memory pool; the one-shot figure is test_detector_process above)
+    out["host_arrays"] = {"first_call_ms_fresh_handle_same_process": round(first_ms, 4), "warm_call_ms": round(warm[len(warm) // 2], 4),
+                          "warm_Mpoints_per_s": round(n / warm[len(warm) // 2] / 1e3, 2),
+                          "keypoints_equal_fixture": bool(h_cnt.value == len(z["kp_canonical"]) and
+                                                          np.array_equal(h_kp[:h_cnt.value], z["kp_canonical"]))}
+    return out
+
+
 def visible_devices():
     """GPUs this process would see, WITHOUT initialising HIP (torch.cuda.device_count() only counts)."""
     import torch
@@ -320,6 +412,7 @@ def main():
         kd = importlib.import_module("keypoint-learning_amd.dist")
 
         comm_stream = torch.cuda.Stream()
+        comm_spans = []                  # (start, end) events on the comm stream around every gather: collective.ms_per_step
 
         def full_step():
             g = step()
@@ -329,11 +422,14 @@ def main():
             batch_done.record(tstreams[g])
             with torch.cuda.stream(comm_stream):
                 comm_stream.wait_event(batch_done)
+                c_start = torch.cuda.Event(enable_timing=True)
+                c_start.record(comm_stream)
                 send = d_packed[g * nb:(g + 1) * nb, :gather_cap + 1].contiguous().view(-1)
                 # the one exchange step of the path: all-gather of the packed keypoint lists (RCCL)
                 gathered[0] = kd.gather_keypoints(send if args.backend == "nccl" else send.cpu())
-                gather_done[g] = torch.cuda.Event()
+                gather_done[g] = torch.cuda.Event(enable_timing=True)
                 gather_done[g].record(comm_stream)
+                comm_spans.append((c_start, gather_done[g]))
     else:
         full_step = step
 
@@ -352,6 +448,8 @@ def main():
     barrier()
     dets[0].enableTiming(True)
     rep_s, rep_enq = [], []
+    if use_dist:
+        del comm_spans[:]                # (the warm-up's gathers are not part of the figure)
     for _ in range(repeats):
         barrier()
         t0 = time.perf_counter()
@@ -364,6 +462,27 @@ def main():
         rep_enq.append(t_enq - t0)
     timing = dets[0].getTiming()
     dets[0].enableTiming(False)
+    # N > 1 (or --force-dist): what the exchange step itself takes on its stream, from the events around every gather of the
+    # timed repetitions (pack + all-gather; it runs beside the other group's scoring, so this is not added to a step)
+    collective_ms = None
+    if use_dist and comm_spans:
+        torch.cuda.synchronize()
+        collective_ms = float(np.mean([a.elapsed_time(b) for a, b in comm_spans]))
+    # the same loop at the OTHER customary step count (the driver runs --steps 20 --warmup 5, the tables of earlier rounds quoted
+    # 200-step runs): a short run pays the fill of the two-deep pipeline and the clock ramp once per K steps
+    sensitivity = None
+    if world == 1 and not use_dist and not args.lean:
+        other = 200 if args.steps != 200 else 20
+        runs = []
+        for _ in range(3):
+            barrier()
+            s0 = time.perf_counter()
+            for _ in range(other):
+                full_step()
+            barrier()
+            runs.append((time.perf_counter() - s0) * 1e3 / other)
+        sensitivity = {"steps": other, "ms_per_step": round(sorted(runs)[1], 5),
+                       "Mpoints_per_s": round(n * nb / sorted(runs)[1] / 1e3, 1)}
     # a status raised DURING the timed loop (a table that had to grow, a failed scan) would otherwise go unseen: every
     # detector must report OK now (the barrier above has drained every stream), else the numbers are not those of the path
     rcs = [d.syncStatus(None) for d in dets]
@@ -565,6 +684,14 @@ def main():
                                           "phases_ms": {k: round(t1v[k] / max(t1v["calls"], 1), 5)
                                                         for k in ("index_ms", "feature_ms", "forest_ms", "nms_ms")}}
 
+    # ---- the reference's OWN default operating point (src/main_test_detector.cpp:62-67,105-106: cheff001, radiusFeatures 20,
+    # radiusNMS 4, threshold 0.85, 5 x 10), both neighbor orders, and what the drop-in's ONE compute() costs
+    if not args.lean and rank == 0 and world == 1:
+        try:
+            extras["reference_defaults"] = reference_defaults(kpl, torch, dev, local_rank)
+        except Exception as e:               # (a missing fixture must not cost the headline)
+            extras["reference_defaults"] = {"error": repr(e)}
+
     # ---- algorithmic bytes from the engine's own counters -------------------------
     # B_alg(i) = 24 (1 + K_f) + 16 K_n [s >= thr] + 8 sum depth + 8.  The scoring stage is two kernels:
     # the feature kernel (the dominant one) gathers xyz + normal of the point and of each feature
@@ -578,7 +705,12 @@ def main():
         b_alg_feat += 24 * (st["n_scored"] + st["sum_kf"])
         b_alg_forest += 8 * st["sum_depth"] + 4 * st["n_scored"]
     calls = max(timing["calls"], 1)
-    feat_ms = timing["feature_ms"] / calls          # HIP events on the launching stream, over the timed region
+    # HIP events on the launching stream around the launch, over the timed region.  With two batches in flight that span is the
+    # kernel's duration PLUS the time its dispatch waits for the other batch's kernels (round 6: the small kernels of a batch are
+    # one-wave workgroups that now run inside this span instead of queueing behind it: span 0.59 -> 0.78 ms while a step got
+    # SHORTER, 0.825 -> 0.80 ms, and rocprofv3's begin-to-end duration of the dispatch moved 0.574 -> 0.597); events given to
+    # hipExtLaunchKernelGGL measure the same span (tried).  frac_rocprof / alone_on_gpu below are the kernel by itself.
+    feat_ms = timing["feature_ms"] / calls
     forest_ms = timing["forest_ms"] / calls
     achieved = b_alg_feat / (feat_ms * 1e-3) if feat_ms > 0 else 0.0
     iso_ms = max(t_iso["feature_ms"] / max(t_iso["calls"], 1), 1e-9) if t_iso else None
@@ -662,11 +794,16 @@ def main():
                        "parallelism": "views sharded, %d rank(s)" % world,
                        "exchange": ("one all-gather of the packed keypoint lists per step (%s)" %
                                     ("RCCL" if args.backend == "nccl" else args.backend)) if use_dist else "none (one rank)"},
-            "repeats": {"n": repeats, "reported": "median", "ms_per_step": [round(x * 1e3 / args.steps, 5) for x in rep_s]},
+            "repeats": {"n": repeats, "reported": "median", "ms_per_step": [round(x * 1e3 / args.steps, 5) for x in rep_s],
+                        "steps_sensitivity": sensitivity},
             # N > 1: the median repetition's ms per step of EVERY rank (the reported one is their maximum), the size of the
             # RCCL communicator the gathers ran in, and where rank 0's process was pinned before its first HIP call
             "per_rank_ms_per_step": [round(r[med] * 1e3 / args.steps, 5) for r in per_rank] if per_rank else None,
-            "collective": {"backend": "RCCL" if args.backend == "nccl" else args.backend, "world_size": dist.get_world_size()}
+            "collective": {"backend": "RCCL" if args.backend == "nccl" else args.backend, "world_size": dist.get_world_size(),
+                           "ms_per_step": round(collective_ms, 5) if collective_ms is not None else None,
+                           "what": "pack + all-gather of the keypoint lists, HIP events on the comm stream (it runs beside the "
+                                   "other batch's scoring: not a part of ms_per_step unless it is longer than a step)",
+                           "bytes_per_rank_per_step": int(nb * (gather_cap + 1) * 4)}
             if use_dist else None,
             "devices_shared": devices_shared,       # true only in tests that run more ranks than the box has GPUs
             "cpu_affinity": affinity,
@@ -680,6 +817,7 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 5), "traffic": traffic,
                          "kernel": "feature_kernel (histogram features, %d view(s) per launch)" % nb,
                          "kernel_ms": round(feat_ms, 5), "alg_bytes_per_launch": int(b_alg_feat),
+                         "kernel_ms_is": "HIP events around the launch on its stream: the dispatch's duration + its wait behind the other batch",
                          # measured IN THIS RUN: achieved / frac / kernel_ms (HIP events on the launching stream) and
                          # alg_bytes_per_launch (the engine's own counters).  NOT measured in this run: everything that needs
                          # rocprofv3 -- traffic, valu_*, ta_busy, waves_per_simd, hbm_counter_frac's numerator and the forest
