@@ -130,3 +130,12 @@ def test_bench_refuses_more_ranks_than_devices():
                          env=env_clean, capture_output=True, text=True, timeout=300)
     assert out.returncode != 0
     assert "visible" in out.stderr and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_scale_report_arithmetic():
+    """tools/scale_report.py: efficiency / rank spread / collective share from the N = 1, 2, 4, 8 bench lines"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "scale_report.py"), "--self-test"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
