@@ -211,6 +211,10 @@ public:
         if (lanes_per_point) *lanes_per_point = li.lanes_per_point;
         return li.walk;
     }
+    // the engine's handle behind this detector (no reference counterpart): for callers that also want the preparation steps of
+    // the reference's main on the device -- kpl_cloud_resolution, kpl_estimate_normals -- without a second handle (a handle
+    // sets up two HIP streams: 8-9 ms each).  Null when no HIP device was found.
+    kpl_detector *nativeHandle() const { return handle_; }
     bool getSortedSearch() const { return sorted_search_ >= 0 ? sorted_search_ != 0 : (this->tree_ && this->tree_->getSortedResults()); }
     const char *lastError() const { return handle_ ? kpl_last_error(handle_) : kpl_status_string(create_status_); }
 

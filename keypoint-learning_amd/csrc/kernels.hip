@@ -4442,7 +4442,9 @@ void launch_index_points(const Batch &b, hipStream_t st) {
     grid_setup_kernel<<<dim3(1, nv), 64, 0, st>>>(b);
     const int chunk_pts = sort_chunk_points(b);
     if (n > 0) bucket_hist_kernel<<<dim3(sort_chunks(n, chunk_pts), nv), kWave, 0, st>>>(b, chunk_pts);
-    if (nv >= 2) {          // a batch: one wave per workgroup (see kScanBlock)
+    if (nv >= 2 && n >= 128 * 1024) {   // a batch of LARGE views: one wave per workgroup (see kScanBlock): bench 1 969 -> 1 980 Mpoints/s; for
+                                        // batches of small views the 1 025 one-wave blocks per view cost more than they free: 64 views
+                                        // of 63 k points 1 490 against 1 553-1 602 (profiles/r06_notes.md)
         bucket_total_kernel<<<dim3(kBins, nv), kWave, 0, st>>>(b, chunk_pts);
         bucket_offsets_kernel<kWave><<<dim3(kBins, nv), kWave, 0, st>>>(b, chunk_pts);
     } else {                // one view alone on the GPU: the shortest chain (0.046 against 0.049 ms of index build on 62 k points)

@@ -99,13 +99,12 @@ long long voxel_key(long long x, long long y, long long z) {
     return (((x + o) & m) << 42) | (((y + o) & m) << 21) | ((z + o) & m);
 }
 
-// owns a plain libkpl handle for the preparation steps that run on the device
+// the preparation steps that run on the device, on the DETECTOR's own handle (nativeHandle(): one handle, one set-up, per process)
 struct Prep {
     kpl_detector *h = nullptr;
-    explicit Prep(int device) {
-        if (kpl_create(&h, device) != KPL_OK) { fprintf(stderr, "no HIP device %d\n", device); h = nullptr; }
+    explicit Prep(kpl_detector *handle) : h(handle) {
+        if (!h) fprintf(stderr, "no HIP device\n");
     }
-    ~Prep() { if (h) kpl_destroy(h); }
     // computeCloudResolution, /root/reference/include/impl/point_cloud_utilities.hpp:120-151
     bool resolution(const pcl::PointCloud<PointInT> &cloud, double &mr) const {
         const int n = (int)cloud.size();
@@ -203,7 +202,11 @@ int main(int argc, char **argv) {
     const bool json = vm.has("json");
 
     const int device = (int)vm.num("device", 0);
-    Prep prep(device);
+
+    // create detector (:123-130)
+    pcl::keypoints::KeypointLearningDetector<PointInT, KeypointT>::Ptr detector(
+        new pcl::keypoints::KeypointLearningDetector<PointInT, KeypointT>(0.5, true, true, 0.0, 5, 10, device));
+    Prep prep(detector->nativeHandle());
     if (!prep.h) return -1;
     if (vm.has("printResolution")) {
         pcl::PointCloud<PointInT> c;
@@ -214,9 +217,6 @@ int main(int argc, char **argv) {
         return 0;
     }
 
-    // create detector (:123-130)
-    pcl::keypoints::KeypointLearningDetector<PointInT, KeypointT>::Ptr detector(
-        new pcl::keypoints::KeypointLearningDetector<PointInT, KeypointT>(0.5, true, true, 0.0, 5, 10, device));
     detector->setNAnnulus(annuli);
     detector->setNBins(bins);
     detector->setNonMaxima(true);
