@@ -115,10 +115,12 @@ int kpl_get_feature_walk(const kpl_detector *h, int *walk, int *lanes_per_point,
 /* What the handle's LAST scoring launch took -- a plain read of the handle, no wait, nothing cleared (kpl_get_timing, which
  * carries the same three walk fields, waits for its events and clears the recorded times). */
 typedef struct kpl_launch_info {
-    int walk;               /* KPL_WALK_LANES / KPL_WALK_TWO_PASS; -1: sorted order, or no call yet                       */
+    int walk;               /* KPL_WALK_LANES / KPL_WALK_TWO_PASS; -1: sorted order (register lists / wave / workgroup kernels), or no
+                               call yet; sorted order with KPL_WALK_TWO_PASS: through the word lists, eight lanes per point   */
     int lanes_per_point;
     int accept_words;       /* KPL_WALK_LANES: accept words a point collected between two drains (24 / 20 / 16 / 12)      */
-    int sorted_list_keys;   /* sorted order: keys per point of the register-sort lists (128, or what the handle measured) */
+    int sorted_list_keys;   /* sorted order: keys per point of the register-sort lists (128, or what the handle measured; 256
+                               through the word lists)                                                                  */
     int sorted_all_large;   /* sorted order: 1 = every point went straight to the wave / workgroup-per-point kernels      */
 } kpl_launch_info;
 int kpl_get_last_launch(const kpl_detector *h, kpl_launch_info *out);

@@ -154,6 +154,9 @@ struct kpl_detector {
     DevBuf score_sorted, flags, prefix, stats, out_scores, out_kp, out_count, cand_list, cand_count;
     DevBuf draw_list, draw_count, skip, feat, scan_state;
     DevBuf large_list, seg_start, seg_len, sort_keys;      // sorted-search mode, large neighborhoods (kernels.hip)
+    DevBuf words, wseg_start, wseg_len;                    // sorted order through the word lists (sorted_words_kernel): accept words of every point
+    bool launched_words = false;  // the last scoring launch was such a one
+    double words_mean_keys = -1.0;    // sorted order: keys per listed point of the last call that listed (nearly) every point; < 0: not known
     DevBuf org_scratch;           // kpl_estimate_normals_organized: change map, distance map, integral image
     int cells_cap = 0;            // capacity (cells) of cell_start
     DevState *h_state = nullptr;  // pinned copy of the device state (status read-back)
@@ -529,8 +532,12 @@ int sync_status(kpl_detector *h, hipStream_t st) {
         h->all_large_n = h->launched_n;
         KPL_HIP(h, hipMemsetAsync((char *)h->dstate.p + offsetof(DevState, kf_max), 0, sizeof(int), st));
     }
-    if (h->h_state->status == kStatusOk && h->h_state->large_seen > 0)     // (a view whose points mostly hold thousands of neighbors: see FeatDesc::all_large == 2)
+    if (h->h_state->status == kStatusOk && h->h_state->large_seen > 0 && !h->launched_words)     // (a view whose points mostly hold thousands of neighbors: see FeatDesc::all_large == 2)
         h->all_huge_hint = (double)h->h_state->keys_needed > 1024.0 * (double)h->h_state->large_seen;
+    // sorted order, what a launch that listed every point (all_large) stored per point: between what the register lists hold and
+    // ~200 keys the next launch goes through the word lists (sorted_words_kernel), which from then on measures the mean itself
+    if (h->h_state->status == kStatusOk && h->launched_all_large && h->h_state->large_seen > 0)
+        h->words_mean_keys = (double)(h->h_state->keys_needed - h->h_state->words_needed) / (double)h->h_state->large_seen;
     if (h->h_state->kf_max <= 0 && h->launched_all_large && h->h_state->status == kStatusOk) {
         // A launch with all_large sends every point to the collect / add kernels, so the register-sort kernel measures nothing
         // (kf_max stays 0) and the hint would never be looked at again: a stream of views of one size at one radius that went
@@ -563,7 +570,13 @@ int sync_status(kpl_detector *h, hipStream_t st) {
             return fail(h, KPL_ERR_CAPACITY, "%llu neighbor keys / accept words in one view (limit 2^32)", need);
         }
         h->index_valid = false;
-        KPL_HIP(h, h->sort_keys.ensure(sizeof(unsigned long long) * (size_t)(need + need / 16 + 4096), st, h->parked));
+        if (h->launched_words) {        // sorted order through the word lists: two arrays, each grown to what the call asked of it
+            const unsigned long long wneed = h->h_state->words_needed, kneed = need - wneed;
+            KPL_HIP(h, h->words.ensure(sizeof(uint2) * (size_t)(wneed + wneed / 16 + 4096), st, h->parked));
+            KPL_HIP(h, h->sort_keys.ensure(sizeof(unsigned long long) * (size_t)(kneed + kneed / 16 + 4096), st, h->parked));
+        } else {
+            KPL_HIP(h, h->sort_keys.ensure(sizeof(unsigned long long) * (size_t)(need + need / 16 + 4096), st, h->parked));
+        }
         return fail(h, KPL_ERR_RETRY, "the view needs room for %llu neighbor keys / accept words: array grown, call again", need);
     }
     if (h->h_state->status == kStatusCellCapacity) {
@@ -600,6 +613,11 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
     v.key_cap = 0;
     FeatDesc feat = make_feat(h->prm);
     choose_walk(h, feat);
+    if (feat.sorted) {                  // (the walks of the canonical order are not the sorted order's: see words_mode below)
+        feat.walk = 0;
+        feat.lanes = 2;
+        feat.words = 0;
+    }
     if (feat.sorted && h->lcap_hint > 0 && h->lcap_hint_radius == h->prm.radius_search) {
         feat.lcap = h->lcap_hint;
         feat.all_large = h->all_large_hint && (long long)n * 4 >= (long long)h->all_large_n * 3 && (long long)n * 3 <= (long long)h->all_large_n * 4 ? 1 : 0;
@@ -633,10 +651,47 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
             feat.words = words_for(h);
         }
     }
-    h->last_walk = feat.sorted ? -1 : feat.walk;
-    h->last_lanes = feat.sorted ? 0 : feat.lanes;
+    // sorted order, 125 .. ~200 neighbors per point on average: through the word lists (sorted_words_kernel: 256 keys per point in
+    // the registers of eight lanes; points beyond are listed for the wave / workgroup kernels).  Entered from what an all_large
+    // launch stored per point, kept while the kernel's own sample of the mean stays in range
+    bool words_mode = false;
+    if (feat.sorted) {
+        const bool sized_alike = h->all_large_n > 0 && (long long)n * 4 >= (long long)h->all_large_n * 3 && (long long)n * 3 <= (long long)h->all_large_n * 4;
+        const bool stay = h->launched_words && h->lcap_hint_radius == h->prm.radius_search && sized_alike && kf_hint_fits(h, n) &&
+                          h->kf_hint >= 95.0 && h->kf_hint <= 215.0;
+        if (h->launched_words && !stay && kf_hint_fits(h, n)) h->words_mean_keys = h->kf_hint;      // (the fresher figure decides about coming back)
+        const bool enter = feat.all_large == 1 && h->words_mean_keys >= 100.0 && h->words_mean_keys <= 205.0;
+        words_mode = enter || stay;
+    }
+    if (words_mode) {
+        const double mean = h->launched_words && kf_hint_fits(h, n) ? h->kf_hint : h->words_mean_keys;
+        const double entries = (double)nn * (mean * 0.3 + 96.0);
+        if (entries * 8.0 <= 8.0 * 1073741824.0 && entries <= 4.0e9) {
+            const size_t want = sizeof(uint2) * (size_t)entries;
+            if (h->words.cap < want && h->words.ensure(want, st, h->parked) != hipSuccess) {
+                (void)hipGetLastError();
+                words_mode = false;
+            }
+        } else {
+            words_mode = false;
+        }
+    }
+    if (words_mode) {
+        feat.walk = 1;
+        feat.all_large = 0;
+        KPL_HIP(h, h->wseg_start.ensure(sizeof(unsigned) * nn, st, h->parked));
+        KPL_HIP(h, h->wseg_len.ensure(sizeof(int) * nn, st, h->parked));
+    }
+    h->launched_words = words_mode;
+    v.words = words_mode ? h->words.as<uint2>() : nullptr;
+    v.word_cap = words_mode ? h->words.cap / sizeof(uint2) : 0;
+    if (v.word_cap > 0xfffffff0ull) v.word_cap = 0xfffffff0ull;
+    v.wseg_start = h->wseg_start.as<unsigned>();
+    v.wseg_len = h->wseg_len.as<int>();
+    h->last_walk = feat.sorted ? (words_mode ? 1 : -1) : feat.walk;
+    h->last_lanes = feat.sorted ? (words_mode ? 8 : 0) : feat.lanes;
     h->last_words = (!feat.sorted && feat.walk == 0) ? (feat.words > 0 ? feat.words : 24) : 0;
-    h->last_lcap = feat.sorted ? (feat.lcap > 0 ? feat.lcap : 128) : 0;
+    h->last_lcap = feat.sorted ? (words_mode ? 256 : feat.lcap > 0 ? feat.lcap : 128) : 0;
     h->launched_all_large = feat.sorted ? feat.all_large : 0;
     if (!feat.sorted && feat.walk == 1) {
         KPL_HIP(h, h->seg_start.ensure(sizeof(unsigned) * nn, st, h->parked));
@@ -1091,7 +1146,7 @@ void kpl_destroy(kpl_detector *h) {
                       &h->pts, &h->nrm, &h->pos_of, &h->score_sorted, &h->flags, &h->prefix, &h->stats,
                       &h->out_scores, &h->out_kp, &h->out_count, &h->cand_list, &h->cand_count,
                       &h->draw_list, &h->draw_count, &h->skip, &h->feat, &h->scan_state,
-                      &h->large_list, &h->seg_start, &h->seg_len, &h->sort_keys};
+                      &h->large_list, &h->seg_start, &h->seg_len, &h->sort_keys, &h->words, &h->wseg_start, &h->wseg_len};
     for (DevBuf *b : bufs) b->release();
     for (void *q : h->parked) (void)hipFree(q);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);

@@ -40,7 +40,9 @@ struct FeatDesc {
     float rr;        // (float)(r*(1+2^-10)): half width of the cell box that is searched
     int sorted;      // neighbor order of the feature loop: 0 = canonical (cell id, index), 1 = ascending (d2, index)
     // how the canonical order is walked -- never WHAT is computed: every combination gives the same bits (kernels.hip)
-    int walk;        // 0: search and drain alternate, accept words in LDS (point_features); 1: two passes, the accept words of the whole walk through global memory (large neighborhoods)
+    int walk;        // 0: search and drain alternate, accept words in LDS (point_features); 1: two passes, the accept words of the whole walk through global memory (large neighborhoods).
+                     // sorted order with walk = 1 ("sorted words", 125 .. ~250 neighbors per point): the same search pass (no neighbor dropped), then
+                     // sorted_words_kernel -- eight lanes per point collect the keys out of the point's word list, sort 256 of them in registers and add
     int lanes;       // lanes per point: 2 or 4
     int words;       // one-kernel walk: accept words a point collects between two drains (0 = 24; fewer for small neighborhoods, kernels.hip accept_words)
     int lcap;        // sorted-search mode: keys per point of the register-sort kernel's lists in LDS (<= 128; 0 = 128)
@@ -126,6 +128,12 @@ struct ViewDev {
     unsigned *seg_start;             // [n] by storage position: first key of the point's segment
     int *seg_len;                    // [n] its length (0: none, or the keys did not fit -> DevState::status)
     unsigned long long key_cap;
+    // sorted order through the word lists (FeatDesc::sorted && walk == 1): a view then needs BOTH arrays -- the accept words of
+    // every point here, the key segments of the points that overflow 256 keys in sort_keys -- and the words' own per-point tables
+    uint2 *words;                    // [word_cap] the blocks of the search pass
+    unsigned long long word_cap;
+    unsigned *wseg_start;            // [n] first entry of the point's word list
+    int *wseg_len;                   // [n] its entries
 };
 
 constexpr int kMaxBatch = 8;     // views per batched launch (bounded by the 4 KB kernel argument block)
@@ -157,6 +165,7 @@ struct DevState {
     int huge_count;                    // of them, points left to the workgroup kernel (second half of large_list)
     unsigned long long key_cursor;     // keys handed out of ViewDev::sort_keys so far (counts on past key_cap)
     unsigned long long keys_needed;    // key_cursor of the last call
+    unsigned long long words_needed;   // ... and the accept-word entries it asked for (32 x the fullest cursor), already part of keys_needed
     // neighborhood size of the view, for the handle's NEXT call: sum of K_f and number of points over a sample of the waves of
     // the feature kernels (one in 64); cumulative, the host takes differences (api.cpp).  On a cache line of their own:
     // every wave of every kernel reads the grid descriptor at the top of this struct, and atomics on its line queue those

@@ -1178,7 +1178,7 @@ __device__ __forceinline__ int wave_max_of(int v, bool in) {
 template <int G, class Block>
 __device__ __forceinline__ int search_point_words_staged(const float4 *__restrict__ pts, const int *__restrict__ cell_start,
                                                          const GridDesc &g, const FeatDesc &fin, float4 p, bool active,
-                                                         float4 *sp, int W, Block block, int &entries) {
+                                                         float4 *sp, int W, Block block, int &entries, bool drop_first = true) {
     static_assert(G == 2 || G == 4 || G == 8, "lanes per point");
     constexpr int kPts = kLanes / G, kStepBits = kStepW * G, kSteps = 32 / kStepBits;
     const int tid = threadIdx.x, pi = tid / G, gq = tid % G;
@@ -1252,7 +1252,7 @@ __device__ __forceinline__ int search_point_words_staged(const float4 *__restric
     list += pi;
     const int mine = kStepW * gq;                 // this lane's 4 candidates of a step start here
     const int nib_shift = 4 * (G - 1 - gq);
-    bool first_pending = true;
+    bool first_pending = drop_first;               // (the sorted order drops element 0 of ITS order, after the sort)
     int kf = 0, ecnt = 0;
     unsigned long long todo = __ballot(active);
     while (todo != 0ull) {
@@ -1583,10 +1583,82 @@ __device__ __forceinline__ unsigned long long quad_fetch(unsigned long long x) {
     return ((unsigned long long)hi << 32) | lo;
 }
 
+// the element of lane g ^ MASK of a group of 8 consecutive lanes (a quad, or two quads of one DPP row): 4 = row_shl / row_shr by 4
+// under bank masks (lane_xor32<4> further down), 7 = 4 after 3
+__device__ __forceinline__ unsigned lane_xor4_u32(unsigned x) {
+    const int t = __builtin_amdgcn_update_dpp(0, (int)x, 0x104, 0xf, 0x5, false);
+    return (unsigned)__builtin_amdgcn_update_dpp(t, (int)x, 0x114, 0xf, 0xa, false);
+}
+template <int MASK>
+__device__ __forceinline__ unsigned long long group_fetch(unsigned long long x) {
+    static_assert(MASK == 1 || MASK == 2 || MASK == 3 || MASK == 4 || MASK == 7, "partner inside a group of 8 lanes");
+    if (MASK <= 3) return quad_fetch<MASK <= 3 ? MASK : 1>(x);
+    if (MASK == 7) x = quad_fetch<3>(x);
+    return ((unsigned long long)lane_xor4_u32((unsigned)(x >> 32)) << 32) | lane_xor4_u32((unsigned)x);
+}
+
+// (the levels of the network are template instantiations, not iterations of a loop over k: with the partner lanes chosen by
+// `if constexpr` the compiler sees straight-line code per level -- as one loop with run-time-looking branches the body exceeded
+// the unroll threshold once groups of 8 lanes were added, the loop stayed rolled and the 32 keys of a lane went to scratch)
+template <int G, int E>
+struct KeySort {
+    using U = unsigned long long;
+    // (the empty asm statements pin every comparator's results in place, in program order: left alone the scheduler
+    // overlaps dozens of comparators and needs 250-300 registers for a network that lives in 64)
+    static __device__ __forceinline__ void inside(U &a, U &b) {          // a <- min, b <- max
+        const bool sw = b < a;
+        const U lo = sw ? b : a, hi = sw ? a : b;
+        a = lo;
+        b = hi;
+        asm volatile("" : "+v"(a), "+v"(b));
+    }
+    static __device__ __forceinline__ U across(U mine, U other, bool upper) {   // the lower lane keeps the minimum
+        const bool lt = other < mine;
+        U res = (lt != upper) ? other : mine;
+        asm volatile("" : "+v"(res));
+        return res;
+    }
+    // the compare-exchange steps of a merge at distances J, J / 2, ... 1 (elements)
+    template <int J>
+    static __device__ __forceinline__ void steps(U (&r)[E], int gq) {
+        if constexpr (J < E) {
+#pragma unroll
+            for (int a = 0; a < E; ++a)
+                if ((a & J) == 0) inside(r[a], r[a + J]);
+        } else {                                    // partner lane g ^ (J / E), the same element
+            const bool upper = (gq & (J / E)) != 0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) r[e] = across(r[e], group_fetch<J / E>(r[e]), upper);
+        }
+        if constexpr (J > 1) steps<J / 2>(r, gq);
+    }
+    // merges sorted blocks of K / 2 into sorted blocks of K: the first step pairs an element with its mirror image in the
+    // block (all comparators ascending), then the half-cleaners
+    template <int K>
+    static __device__ __forceinline__ void level(U (&r)[E], int gq) {
+        if constexpr (K <= E) {                     // inside the lane
+#pragma unroll
+            for (int blk = 0; blk < E; blk += K)
+#pragma unroll
+                for (int off = 0; off < K / 2; ++off) inside(r[blk + off], r[blk + K - 1 - off]);
+        } else {                                    // partner lane g ^ (K / E - 1), its element E - 1 - e
+            const bool upper = (gq & (K / E / 2)) != 0;
+#pragma unroll
+            for (int e = 0; e < E / 2; ++e) {
+                const U o1 = group_fetch<K / E - 1>(r[E - 1 - e]), o2 = group_fetch<K / E - 1>(r[e]);
+                r[e] = across(r[e], o1, upper);
+                r[E - 1 - e] = across(r[E - 1 - e], o2, upper);
+            }
+        }
+        if constexpr (K >= 4) steps<K / 4>(r, gq);
+        if constexpr (2 * K <= G * E) level<2 * K>(r, gq);
+    }
+};
+
 template <int G, int E>
 __device__ __forceinline__ void sort_key_lists(unsigned long long *keys, int pi, int gq, int cnt) {
-    static_assert(G == 4, "the lanes of a group are a DPP quad");
-    constexpr int kPts = kLanes / G, N = G * E;
+    static_assert(G == 4 || G == 8, "the lanes of a group are a DPP quad, or two quads of a row");
+    constexpr int kPts = kLanes / G;
     unsigned long long r[E];
     wave_lds_fence();
 #pragma unroll
@@ -1594,60 +1666,7 @@ __device__ __forceinline__ void sort_key_lists(unsigned long long *keys, int pi,
         const int idx = gq * E + e;
         r[e] = idx < cnt ? keys[idx * kPts + pi] : ~0ull;
     }
-    // (the empty asm statements pin every comparator's results in place, in program order: left alone the scheduler
-    // overlaps dozens of comparators and needs 250-300 registers for a network that lives in 64)
-    auto inside = [](unsigned long long &a, unsigned long long &b) {          // a <- min, b <- max
-        const bool sw = b < a;
-        const unsigned long long lo = sw ? b : a, hi = sw ? a : b;
-        a = lo;
-        b = hi;
-        asm volatile("" : "+v"(a), "+v"(b));
-    };
-    auto across = [](unsigned long long mine, unsigned long long other, bool upper) {   // the lower lane keeps the minimum
-        const bool lt = other < mine;
-        unsigned long long res = (lt != upper) ? other : mine;
-        asm volatile("" : "+v"(res));
-        return res;
-    };
-#pragma unroll
-    for (int k = 2; k <= N; k <<= 1) {
-        if (k <= E) {                                   // merge step 1 inside the lane: i against its mirror image
-#pragma unroll
-            for (int blk = 0; blk < E; blk += k)
-#pragma unroll
-                for (int off = 0; off < k / 2; ++off) inside(r[blk + off], r[blk + k - 1 - off]);
-        } else {                                        // ... across lanes: partner lane g ^ (k / E - 1), its element E - 1 - e
-            const bool upper = (gq & (k / E / 2)) != 0;
-#pragma unroll
-            for (int e = 0; e < E / 2; ++e) {
-                unsigned long long o1, o2;
-                if (k / E - 1 == 1) {
-                    o1 = quad_fetch<1>(r[E - 1 - e]);
-                    o2 = quad_fetch<1>(r[e]);
-                } else {
-                    o1 = quad_fetch<3>(r[E - 1 - e]);
-                    o2 = quad_fetch<3>(r[e]);
-                }
-                r[e] = across(r[e], o1, upper);
-                r[E - 1 - e] = across(r[E - 1 - e], o2, upper);
-            }
-        }
-#pragma unroll
-        for (int j = k / 4; j > 0; j >>= 1) {
-            if (j < E) {
-#pragma unroll
-                for (int a = 0; a < E; ++a)
-                    if ((a & j) == 0) inside(r[a], r[a + j]);
-            } else {                                    // partner lane g ^ (j / E), the same element
-                const bool upper = (gq & (j / E)) != 0;
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    const unsigned long long o = j / E == 1 ? quad_fetch<1>(r[e]) : quad_fetch<2>(r[e]);
-                    r[e] = across(r[e], o, upper);
-                }
-            }
-        }
-    }
+    KeySort<G, E>::template level<2>(r, gq);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int idx = gq * E + e;
@@ -1864,6 +1883,187 @@ __device__ __forceinline__ int point_features_sorted(const float4 *__restrict__ 
         const float nr = sqrtf(s);
         if (nr > 0)
             for (int k = 0; k < f.B; ++k) h[k * kPts] = h[k * kPts] / nr;
+    }
+    wave_lds_fence();
+    return kf;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Sorted order through the word lists ("sorted words": FeatDesc::sorted && walk == 1), for views whose points hold more
+// neighbors than the register lists of point_features_sorted (124) and up to ~250: round 5 gave such a point a whole wave
+// (sorted_collect_wave_kernel: its own search of the box, a 256 .. 512-key network, the keys through HBM to sorted_add_kernel
+// -- ~1 100 + ~800 wave-instructions per point).  Here the search is the two-pass walk's (feature_search_kernel: the candidates
+// of a wave's points staged in LDS once, accept words to a list in global memory; no neighbor dropped), and EIGHT lanes per
+// point -- 8 points per wave -- do the rest in one kernel:
+//   collect  the point's word list: lane g takes the g-th set bit of the current word, loads that candidate (16 bytes:
+//            xyz + original index) and appends its key (d2 bits << 32 | index) to the point's list in LDS (kWordsKeys keys)
+//   sort     the bitonic network of sort_key_lists over 8 lanes x 32 keys, in registers (partners across lanes: DPP)
+//   add      the keys in order, 8 per round, as in point_features_sorted (hpp:334-359; element 0 dropped, hpp:336)
+// A point with more keys than the list holds is listed for the wave / workgroup kernels like the deferred points of
+// feature_sorted_kernel.  Same keys, same order, same arithmetic: the same bits.
+//   LDS: [H: maxF x 8 floats][key lists: kWordsKeys x 8 keys of 8 bytes]
+constexpr int kWordsGroup = 8, kWordsKeys = 32 * kWordsGroup;
+
+template <int G>
+__device__ __forceinline__ int point_features_sorted_words(const float4 *__restrict__ pts, const char *__restrict__ nrmsrc, unsigned ns,
+                                                           const FeatDesc &fin, float4 p, float4 np, float *H,
+                                                           unsigned long long *keys, const uint2 *__restrict__ list, int stride,
+                                                           int ecnt, bool &deferred) {
+    static_assert(G == 8, "eight lanes per point");
+    constexpr int kPts = kLanes / G, lcap = 32 * G;
+    const int tid = threadIdx.x, pi = tid / G, gq = tid % G;
+    FeatDesc f;
+    f.A = pin_i(fin.A);
+    f.B = pin_i(fin.B);
+    f.F = pin_i(fin.F);
+    f.A1f = pin_f(fin.A1f);
+    f.B1f = pin_f(fin.B1f);
+    f.support = fin.support;
+    f.ann_dim = pin_f(fin.ann_dim);
+    f.ann_half = pin_f(fin.ann_half);
+    f.ann_rdim = pin_f(fin.ann_rdim);
+    f.bin_dim = pin_f(fin.bin_dim);
+    f.bin_half = pin_f(fin.bin_half);
+    f.bin_rdim = pin_f(fin.bin_rdim);
+    f.r2 = pin_f(fin.r2);
+    f.rr = fin.rr;
+    for (int c = gq; c < f.F; c += G) H[c * kPts + pi] = 0.0f;                     // hpp:325
+    const int col_address = lds_address(H + pi);
+    const unsigned group_shift = (unsigned)(tid & ~(G - 1));
+    deferred = false;
+    int cnt = 0, kf = 0;
+    // ---- collect: G accepted neighbors of the point per round -> keys
+    if (__any(ecnt > 0)) {
+        const int last = max(ecnt - 1, 0);
+        int e = 0;
+        unsigned w = 0u;
+        int wbase = 0;
+        uint2 nw = ecnt > 0 ? list[0] : make_uint2(0u, 0u);
+        struct Taken {
+            bool valid;
+            float4 q;
+        };
+        auto take = [&](Taken &slot) {
+            const bool refill = (w == 0u) & (e < ecnt);
+            w = refill ? nw.y : w;
+            wbase = refill ? (int)nw.x : wbase;
+            e += refill ? 1 : 0;
+            if (refill) nw = list[min(e, last) * stride];
+            // lane g: the g-th set bit of what is left of the word (a round never spans two words)
+            const unsigned c1 = drop_lowest_bit(w), c2 = drop_lowest_bit(c1), c3 = drop_lowest_bit(c2), c4 = drop_lowest_bit(c3),
+                           c5 = drop_lowest_bit(c4), c6 = drop_lowest_bit(c5), c7 = drop_lowest_bit(c6);
+            const unsigned m = gq == 0 ? w : gq == 1 ? c1 : gq == 2 ? c2 : gq == 3 ? c3 : gq == 4 ? c4 : gq == 5 ? c5 : gq == 6 ? c6 : c7;
+            w = drop_lowest_bit(c7);
+            slot.valid = m != 0u;
+            const int tt = slot.valid ? wbase + lowest_bit_index(m) : 0;
+            slot.q = pts[tt];
+        };
+        auto collect = [&](Taken &now) {
+            if (cnt > lcap - G) {          // no room for the keys of this round: the point leaves for the wave / workgroup kernels
+                deferred = true;
+                cnt = 0;
+                e = ecnt;
+                w = 0u;
+            }
+            const unsigned long long key = ((unsigned long long)__float_as_uint(dist2(p.x, p.y, p.z, now.q)) << 32) |
+                                           (unsigned long long)(unsigned)__float_as_int(now.q.w);
+            const bool app = now.valid & !deferred;
+            const unsigned gb = (unsigned)(__ballot(app) >> group_shift) & ((1u << G) - 1u);
+            if (app) keys[(cnt + __popc(gb & ((1u << gq) - 1u))) * kPts + pi] = key;
+            cnt += __popc(gb);
+            kf += __popc(gb);
+            now.valid = false;
+        };
+        // (the candidates of THREE rounds are on their way while a round's keys are appended: with ~2 waves per SIMD -- the key
+        // lists take 16 KB of LDS per wave -- one round ahead left every round waiting for its loads: 4.8 ms per 8 x 200 k points
+        // at 190 keys, against 3.x with three)
+        constexpr int kAhead = 3;
+        Taken sl[kAhead + 1];
+#pragma unroll
+        for (int q = 0; q <= kAhead; ++q) {
+            sl[q].valid = false;
+            sl[q].q = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < kAhead; ++q) take(sl[q]);
+        bool more = true;
+        while (more) {
+#pragma unroll
+            for (int q = 0; q <= kAhead; ++q) {
+                take(sl[(q + kAhead) % (kAhead + 1)]);
+                collect(sl[q]);
+            }
+            bool pending = false;
+#pragma unroll
+            for (int q = 0; q <= kAhead; ++q) pending |= sl[q].valid;
+            more = __any((w != 0u) | (e < ecnt) | pending);
+        }
+    }
+    // ---- sort: 256 keys, or 128 when no list of the wave holds more
+    if (__all(cnt <= 16 * G)) sort_key_lists<G, 16>(keys, pi, gq, cnt);
+    else sort_key_lists<G, 32>(keys, pi, gq, cnt);
+    // ---- add the neighbors in order, G per round; hpp:336: element 0 of the order is dropped
+    {
+        struct Next {
+            bool valid;
+            float d2;
+            f32x3 n;
+        };
+        int k = cnt > 0 ? 1 : 0;
+        const int key_last = (lcap - 1) * kPts + pi;
+        auto take = [&](Next &slot) {
+            const int idx = k + gq;
+            slot.valid = idx < cnt;
+            const unsigned long long key = keys[min(idx * kPts + pi, key_last)];
+            k += G;
+            slot.d2 = __uint_as_float((unsigned)(key >> 32));
+            const unsigned orig = slot.valid ? (unsigned)key : 0u;
+            slot.n = *reinterpret_cast<const f32x3 *>(nrmsrc + (size_t)orig * ns);
+        };
+        constexpr int kAhead = 3;              // normals requested three rounds ahead of their use (see the collect phase)
+        Next sl[kAhead + 1];
+#pragma unroll
+        for (int q = 0; q <= kAhead; ++q) {
+            sl[q].valid = false;
+            sl[q].d2 = 0.f;
+            sl[q].n = f32x3{0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int q = 0; q < kAhead; ++q) take(sl[q]);
+        bool more = true;
+        while (more) {
+#pragma unroll
+            for (int q = 0; q <= kAhead; ++q) {
+                Next &now = sl[q];
+                take(sl[(q + kAhead) % (kAhead + 1)]);
+                const bool has_ = now.valid & finite3(now.n.x, now.n.y, now.n.z);          /* hpp:338 */
+                Contribution c_;
+                if (has_) c_ = neighbor_contribution<kPts>(f, now.d2, np, now.n, col_address);
+#pragma unroll
+                for (int sub_ = 0; sub_ < G; ++sub_) {
+                    if (has_ & (gq == sub_)) apply_contribution(c_, request_cells(c_));
+                    wave_lds_fence();
+                }
+                now.valid = false;
+            }
+            bool pending = false;
+#pragma unroll
+            for (int q = 0; q <= kAhead; ++q) pending |= sl[q].valid;
+            more = __any((k - G * kAhead < cnt) | pending);
+        }
+    }
+    wave_lds_fence();
+    for (int a = gq; a < f.A; a += G) {                                            // hpp:360-370, one row per lane
+        float *h = H + (a * f.B) * kPts + pi;
+        float sq = 0.0f;
+        for (int kk = 0; kk < f.B; ++kk) {
+            float v = h[kk * kPts];
+            sq += v * v;
+        }
+        const float nr = sqrtf(sq);
+        if (nr > 0)
+            for (int kk = 0; kk < f.B; ++kk) h[kk * kPts] = h[kk * kPts] / nr;
     }
     wave_lds_fence();
     return kf;
@@ -2396,12 +2596,19 @@ __global__ __launch_bounds__(kLanes) void feature_kernel(Batch b, int maxF, int 
 constexpr int kSearchGroup = 8;        // lanes per point of the search pass: a word of 32 candidates is ONE step of the 8 lanes; 8 points per wave --
                                        // the waves of the densest cells walk 2.7 x the words of the average wave, the launch lasts as long as they do
 constexpr int kSearchWindow = 128;     // candidates per staged window (two windows of 2 KB of LDS per wave: the ~31 waves per CU of a 63 k-point view are resident together)
+// for_sorted: the launch of the sorted branch takes the views in sorted order (their lists feed sorted_words_kernel), the other
+// one the views in canonical order (feature_drain_kernel)
 template <bool STATS>
-__global__ __launch_bounds__(kLanes) void feature_search_kernel(Batch b) {
+__global__ __launch_bounds__(kLanes) void feature_search_kernel(Batch b, int for_sorted) {
     __shared__ float4 sp[2 * kSearchWindow];        // two windows: one searched, the next on its way
     constexpr int G = kSearchGroup, kPts = kLanes / G;
     const ViewDev &v = b.view[blockIdx.y];
-    if (v.f.sorted || v.f.walk != kWalkTwoPass) return;
+    if (v.f.walk != kWalkTwoPass || (v.f.sorted != 0) != (for_sorted != 0)) return;
+    // (a view in sorted order keeps its key segments in sort_keys: its word lists have an array and tables of their own)
+    uint2 *const wbase = v.f.sorted ? v.words : reinterpret_cast<uint2 *>(v.sort_keys);
+    const unsigned long long wcap = v.f.sorted ? v.word_cap : v.key_cap;
+    unsigned *const wstart = v.f.sorted ? v.wseg_start : v.seg_start;
+    int *const wlen = v.f.sorted ? v.wseg_len : v.seg_len;
     const int chunk = blockIdx.x / G, pi = threadIdx.x / G, gq = threadIdx.x % G;
     const int col = (blockIdx.x % G) * kPts + pi;
     if (chunk * kLanes + col - pi >= v.n) return;
@@ -2410,7 +2617,7 @@ __global__ __launch_bounds__(kLanes) void feature_search_kernel(Batch b) {
     bool fits = true;
     auto block = [&](int steps) -> uint2 * {
         // a 32nd of the array per cursor; the cursor of a wave = its number mod 32 (waves go to the XCDs round robin: four cursors per XCD)
-        const unsigned long long share = v.key_cap / kWordShards, need = (unsigned long long)steps * kPts;
+        const unsigned long long share = wcap / kWordShards, need = (unsigned long long)steps * kPts;
         const int shard = blockIdx.x % kWordShards;
         unsigned long long off = 0ull;
         if (threadIdx.x == 0 && need > 0) off = atomicAdd(&v.ds->word_cursor[shard], need);
@@ -2422,15 +2629,16 @@ __global__ __launch_bounds__(kLanes) void feature_search_kernel(Batch b) {
             return nullptr;
         }
         first = (unsigned)(share * shard + off);
-        return reinterpret_cast<uint2 *>(v.sort_keys) + first;
+        return wbase + first;
     };
     int entries = 0;
-    const int kf = search_point_words_staged<G>(v.pts, v.cell_start, v.ds->grid, v.f, w.p, w.scoreable, sp, kSearchWindow, block, entries);
+    const int kf = search_point_words_staged<G>(v.pts, v.cell_start, v.ds->grid, v.f, w.p, w.scoreable, sp, kSearchWindow, block, entries,
+                                                !v.f.sorted);
     if (w.in_range && gq == 0) {
-        v.seg_start[w.s] = first + (unsigned)pi;
-        v.seg_len[w.s] = fits ? entries : 0;
+        wstart[w.s] = first + (unsigned)pi;
+        wlen[w.s] = fits ? entries : 0;
     }
-    if (STATS && w.scoreable && gq == 0) atomicAdd(&v.stats->sum_kf, (unsigned long long)kf);
+    if (STATS && !v.f.sorted && w.scoreable && gq == 0) atomicAdd(&v.stats->sum_kf, (unsigned long long)kf);     // (sorted: the kernels behind count)
     if (kf_sampled(blockIdx.x)) note_kf(v, w.scoreable && gq == 0 ? (float)kf : 0.0f, w.scoreable && gq == 0 ? 1 : 0);
 }
 
@@ -2462,7 +2670,7 @@ __global__ __launch_bounds__(kLanes) void feature_sorted_kernel(Batch b, int max
     constexpr int G = kSortGroup, kPts = kLanes / G;
     const ViewBlock vb = view_block(by_xcd);
     const ViewDev &v = b.view[vb.view];
-    if (!v.f.sorted) return;
+    if (!v.f.sorted || v.f.walk == kWalkTwoPass) return;          // (walk 1: sorted_words_kernel)
     const int chunk = vb.bx / G, pi = threadIdx.x / G, gq = threadIdx.x % G;
     const int col = (vb.bx % G) * kPts + pi;
     if (chunk * kLanes + col - pi >= v.n) return;
@@ -2512,6 +2720,39 @@ __global__ __launch_bounds__(kLanes) void feature_sorted_kernel(Batch b, int max
         }
     }
     if (listed) return;
+    if (STATS && w.scoreable && gq == 0) atomicAdd(&v.stats->sum_kf, (unsigned long long)kf);
+    float *o = v.feat + (size_t)chunk * v.f.F * kLanes + col;
+    for (int c = gq; c < v.f.F; c += G) o[c * kLanes] = H[c * kPts + pi];
+}
+
+// sorted order through the word lists (point_features_sorted_words): kWordsGroup lanes per point, 8 points per wave
+//   LDS: [H: maxF x 8 floats][key lists: kWordsKeys x 8 keys]
+template <bool STATS>
+__global__ __launch_bounds__(kLanes) void sorted_words_kernel(Batch b, int maxF, int by_xcd) {
+    extern __shared__ float H[];
+    constexpr int G = kWordsGroup, kPts = kLanes / G;
+    const ViewBlock vb = view_block(by_xcd);
+    const ViewDev &v = b.view[vb.view];
+    if (!v.f.sorted || v.f.walk != kWalkTwoPass) return;
+    const int chunk = vb.bx / G, pi = threadIdx.x / G, gq = threadIdx.x % G;
+    const int col = (vb.bx % G) * kPts + pi;
+    if (chunk * kLanes + col - pi >= v.n) return;
+    const WavePoint w = wave_point(v, chunk, col, true);
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(H + maxF * kPts);
+    const int ecnt = w.scoreable ? v.wseg_len[w.s] : 0;
+    const uint2 *list = v.words + (w.scoreable ? v.wseg_start[w.s] : 0u);
+    bool deferred = false;
+    const int kf = point_features_sorted_words<G>(v.pts, v.nrmsrc, v.ns, v.f, w.p, w.np, H, keys, list, kLanes / kSearchGroup, ecnt, deferred);
+    // a point whose list ran full: for the wave-per-point kernel (and the workgroup kernel behind it), as in feature_sorted_kernel
+    const unsigned long long lbal = __ballot(deferred && gq == 0);
+    if (lbal != 0ull) {
+        const int lane = threadIdx.x;
+        int base = 0;
+        if (lane == __builtin_ctzll(lbal)) base = atomicAdd(&v.ds->large_count, __popcll(lbal));
+        base = __builtin_amdgcn_readlane(base, __builtin_ctzll(lbal));
+        if (deferred && gq == 0) v.large_list[base + __popcll(lbal & ((1ull << lane) - 1ull))] = w.s;
+    }
+    if (deferred) return;              // (the mean neighborhood of the view is sampled by the search pass, deferred points included)
     if (STATS && w.scoreable && gq == 0) atomicAdd(&v.stats->sum_kf, (unsigned long long)kf);
     float *o = v.feat + (size_t)chunk * v.f.F * kLanes + col;
     for (int c = gq; c < v.f.F; c += G) o[c * kLanes] = H[c * kPts + pi];
@@ -4318,6 +4559,7 @@ __global__ __launch_bounds__(BLOCK) void compact_scan_kernel(Batch b) {
                     v.ds->word_cursor[k] = 0ull;
                 }
                 v.ds->keys_needed = v.ds->key_cursor + wmax * kWordShards;
+                v.ds->words_needed = wmax * kWordShards;
                 v.ds->key_cursor = 0ull;
                 v.ds->large_seen = v.ds->large_count;
                 v.ds->large_count = 0;
@@ -4563,7 +4805,7 @@ void launch_feature_stage(const Batch &b, hipStream_t st) {
     bool sorted = false, lanes2 = false, lanes4 = false, two2 = false, two4 = false;
     for (int v = 0; v < b.nviews; ++v) {
         const FeatDesc &f = b.view[v].f;
-        if (f.sorted) sorted = true;
+        if (f.sorted) sorted = true;                 // (walk == 1 there: the sorted-words kernels, launched in the sorted branch)
         else if (f.walk == kWalkTwoPass) (f.lanes == 4 ? two4 : two2) = true;
         else (f.lanes == 4 ? lanes4 : lanes2) = true;
     }
@@ -4600,8 +4842,8 @@ void launch_feature_stage(const Batch &b, hipStream_t st) {
     // points are interleaved), then the drain with the lanes per point of the view
     if (two2 || two4) {
         const dim3 sgrid(div_up(n, kLanes) * kSearchGroup, b.nviews);
-        if (stats) feature_search_kernel<true><<<sgrid, kLanes, 0, st>>>(b);
-        else feature_search_kernel<false><<<sgrid, kLanes, 0, st>>>(b);
+        if (stats) feature_search_kernel<true><<<sgrid, kLanes, 0, st>>>(b, 0);
+        else feature_search_kernel<false><<<sgrid, kLanes, 0, st>>>(b, 0);
         const int stride = kLanes / kSearchGroup;
         if (two2)
             feature_drain_kernel<2><<<dim3(div_up(n, kLanes) * 2, b.nviews), kLanes, sizeof(float) * (size_t)maxF * (kLanes / 2), st>>>(b, maxF, stride);
@@ -4623,8 +4865,22 @@ void launch_feature_stage(const Batch &b, hipStream_t st) {
         int min_n = n;
         for (int k = 0; k < b.nviews; ++k) min_n = b.view[k].n < min_n ? b.view[k].n : min_n;
         const int by_xcd = (b.nviews >= 2 && (long long)min_n * 10 >= (long long)n * 9) ? 1 : 0;
-        if (stats) feature_sorted_kernel<true><<<grid, kLanes, lds, st>>>(b, maxF, kSortWords, lcap, by_xcd);
-        else feature_sorted_kernel<false><<<grid, kLanes, lds, st>>>(b, maxF, kSortWords, lcap, by_xcd);
+        bool reg_views = false, word_views = false;     // which of the two front kernels the sorted views of the batch take
+        for (int v = 0; v < b.nviews; ++v)
+            if (b.view[v].f.sorted) (b.view[v].f.walk == kWalkTwoPass ? word_views : reg_views) = true;
+        if (reg_views) {
+            if (stats) feature_sorted_kernel<true><<<grid, kLanes, lds, st>>>(b, maxF, kSortWords, lcap, by_xcd);
+            else feature_sorted_kernel<false><<<grid, kLanes, lds, st>>>(b, maxF, kSortWords, lcap, by_xcd);
+        }
+        if (word_views) {       // 125 .. ~250 neighbors per point: the search pass of the two-pass walk, then eight lanes per point
+            const dim3 sgrid(div_up(n, kLanes) * kSearchGroup, b.nviews);
+            if (stats) feature_search_kernel<true><<<sgrid, kLanes, 0, st>>>(b, 1);
+            else feature_search_kernel<false><<<sgrid, kLanes, 0, st>>>(b, 1);
+            const size_t wlds = (sizeof(float) * (size_t)maxF + sizeof(unsigned long long) * (size_t)kWordsKeys) * (size_t)(kLanes / kWordsGroup);
+            const dim3 wgrid(div_up(n, kLanes) * kWordsGroup, b.nviews);
+            if (stats) sorted_words_kernel<true><<<wgrid, kLanes, wlds, st>>>(b, maxF, by_xcd);
+            else sorted_words_kernel<false><<<wgrid, kLanes, wlds, st>>>(b, maxF, by_xcd);
+        }
         // persistent: as many workgroups of four waves as are resident at once (every wave takes the same share of the list:
         // workgroups that start when others have finished would double the kernel's time)
         static int wave_wgs_per_cu = 0;         // (every thread that gets here computes the same value)

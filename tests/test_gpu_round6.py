@@ -151,3 +151,55 @@ def test_every_fresh_handle_of_a_process_counts_its_keypoints(kpl, oracle, cases
             else:
                 assert len(idx) == scoreable, (rep, srt, thr, nms, len(idx))
             del det
+
+
+@pytest.mark.parametrize("rmul,nan", [(8.5, False), (10.0, True)])
+def test_sorted_order_through_the_word_lists(kpl, oracle, cases, rmul, nan):
+    """125 .. ~250 neighbors per point in sorted order: once a handle has seen that its points overflow the register lists and
+    hold ~100-200 keys each, it searches with the two-pass walk's search kernel and sorts 256 keys per point in the registers
+    of eight lanes (sorted_words_kernel).  Every call -- before, at and after the switch -- gives the oracle's bits."""
+    A, B = 5, 6
+    xyz, nrm = cases.cloud(150, 120, seed=11, nan_points=6 if nan else 0, nan_normals=9 if nan else 0)
+    mr = oracle.cloud_resolution(xyz)
+    r, rn, thr = float(np.float32(rmul * mr)), float(np.float32(4 * mr)), float(np.float32(0.5))
+    of = cases.oracle_forest(cases.trained_forest(A, B))
+    want = oracle.detect(xyz, nrm, A, B, r, rn, thr, of, order=oracle.ORDER_SORTED, threads=cases.usable_cores())
+    det = _det(kpl, cases, A, B, r, rn, thr, True)
+    det.setInputCloud(xyz)
+    det.setNormals(nrm)
+    launches = []
+    for rep in range(6):
+        _, scores = det.compute()
+        assert cases.same_bits(scores, want[0]), rep
+        assert np.array_equal(det.getKeypointsIndices(), want[1]), rep
+        launches.append(det.getLastLaunch())
+    assert launches[0]["walk"] == -1                                  # the first call knows nothing
+    assert launches[-1]["walk"] == kpl.WALK_TWO_PASS and launches[-1]["lanes_per_point"] == 8 and launches[-1]["sorted_list_keys"] == 256, launches
+    # the query entry point (training features) is untouched by the handle's mode
+    q = np.flatnonzero(np.isfinite(nrm).all(axis=1)).astype(np.int32)[::37]
+    g = oracle.Grid(xyz, r)
+    assert cases.same_bits(det.computePointsForTrainingFeatures(q), g.features(nrm, A, B, r, q, order=oracle.ORDER_SORTED))
+
+
+def test_sorted_word_lists_with_exact_ties_and_points_beyond_the_list(kpl, oracle, cases):
+    """a lattice with duplicates (hundreds of equal distances, broken by index) whose denser half overflows the 256 keys of a
+    point's list: those points go on to the wave / workgroup kernels, the others are sorted in the eight lanes"""
+    from tests.test_oracle_sorted import lattice
+    A, B = 5, 6
+    xyz, nrm = lattice(48, 40, dup=60)
+    dense = xyz[: len(xyz) // 3] * np.float32([0.55, 0.55, 1.0]) + np.float32([100.0, 0.0, 0.0])     # a denser patch beside it
+    xyz = np.ascontiguousarray(np.concatenate([xyz, dense]), np.float32)
+    nrm = np.ascontiguousarray(np.concatenate([nrm, nrm[: len(dense)]]), np.float32)
+    r, rn, thr = 7.3, 3.1, float(np.float32(0.5))
+    of = cases.oracle_forest(cases.trained_forest(A, B))
+    want = oracle.detect(xyz, nrm, A, B, r, rn, thr, of, order=oracle.ORDER_SORTED, threads=cases.usable_cores())
+    det = _det(kpl, cases, A, B, r, rn, thr, True)
+    det.setInputCloud(xyz)
+    det.setNormals(nrm)
+    seen = set()
+    for rep in range(6):
+        _, scores = det.compute()
+        assert cases.same_bits(scores, want[0]), rep
+        assert np.array_equal(det.getKeypointsIndices(), want[1]), rep
+        seen.add(det.getLastLaunch()["walk"])
+    assert kpl.WALK_TWO_PASS in seen, seen
