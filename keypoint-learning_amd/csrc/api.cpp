@@ -156,6 +156,9 @@ struct kpl_detector {
     DevBuf large_list, seg_start, seg_len, sort_keys;      // sorted-search mode, large neighborhoods (kernels.hip)
     DevBuf words, wseg_start, wseg_len;                    // sorted order through the word lists (sorted_words_kernel): accept words of every point
     bool launched_words = false;  // the last scoring launch was such a one
+    double kf_estimate = -1.0;    // sorted order, first host call: neighbors per point estimated off the bounding box (estimate_neighborhood)
+    double kf_estimate_radius = 0.0;
+    int kf_estimate_n = 0;
     double words_mean_keys = -1.0;    // sorted order: keys per listed point of the last call that listed (nearly) every point; < 0: not known
     DevBuf org_scratch;           // kpl_estimate_normals_organized: change map, distance map, integral image
     int cells_cap = 0;            // capacity (cells) of cell_start
@@ -546,11 +549,20 @@ int sync_status(kpl_detector *h, hipStream_t st) {
         // the mean is back within what the register lists hold, the next launch tries them again (and measures again).
         const long long listed = h->h_state->large_seen;
         const double mean_keys = listed > 0 ? (double)h->h_state->keys_needed / (double)listed : 0.0;
+        if (!(h->lcap_hint > 0 && h->lcap_hint_radius == h->launched_radius)) {
+            // the launch listed everything on an ESTIMATE (a first host call, estimate_neighborhood): from here on the handle has
+            // measurements like any other -- "every point is listed" for views of this size at this radius, lists of 128 keys
+            h->lcap_hint = 128;
+            h->lcap_hint_radius = h->launched_radius;
+            h->all_large_hint = true;
+            h->all_large_n = h->launched_n;
+        }
         if (mean_keys < 100.0) {
             h->all_large_hint = false;
             h->lcap_hint = 0;               // (not known: 128 keys per point until the next launch has measured)
         }
     }
+    if (h->h_state->status == kStatusOk) h->kf_estimate = -1.0;       // (an estimate serves ONE call: the read above has measured)
     if (h->h_state->status == kStatusGridTooLarge)
         return fail(h, KPL_ERR_GRID_TOO_LARGE, "bounding box / radius needs more than 2^28 grid cells");
     if (h->h_state->status == kStatusBadOrigin)
@@ -618,6 +630,9 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
         feat.lanes = 2;
         feat.words = 0;
     }
+    const bool estimated = feat.sorted && !(h->lcap_hint > 0 && h->lcap_hint_radius == h->prm.radius_search) && h->kf_estimate > 0.0 &&
+                           h->kf_estimate_radius == h->prm.radius_search && h->kf_estimate_n == n;
+    if (estimated) feat.all_large = h->kf_estimate > 1100.0 ? 2 : 1;       // (a first host call, sorted order: estimate_neighborhood)
     if (feat.sorted && h->lcap_hint > 0 && h->lcap_hint_radius == h->prm.radius_search) {
         feat.lcap = h->lcap_hint;
         feat.all_large = h->all_large_hint && (long long)n * 4 >= (long long)h->all_large_n * 3 && (long long)n * 3 <= (long long)h->all_large_n * 4 ? 1 : 0;
@@ -708,7 +723,9 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
         KPL_HIP(h, h->large_list.ensure(sizeof(int) * 2 * nn, st, h->parked));         // all large points + the ones for the workgroup kernel
         KPL_HIP(h, h->seg_start.ensure(sizeof(unsigned) * nn, st, h->parked));
         KPL_HIP(h, h->seg_len.ensure(sizeof(int) * nn, st, h->parked));
-        if (h->sort_keys.cap < sizeof(unsigned long long) * 64 * nn) KPL_HIP(h, h->sort_keys.ensure(sizeof(unsigned long long) * 64 * nn, st, h->parked));
+        size_t key_bytes = sizeof(unsigned long long) * 64 * nn;
+        if (estimated) key_bytes = sizeof(unsigned long long) * (size_t)((double)nn * h->kf_estimate * 1.25);
+        if (h->sort_keys.cap < key_bytes) KPL_HIP(h, h->sort_keys.ensure(key_bytes, st, h->parked));
         v.large_list = h->large_list.as<int>();
         v.sort_keys = h->sort_keys.as<unsigned long long>();
         v.seg_start = h->seg_start.as<unsigned>();
@@ -851,7 +868,9 @@ void estimate_neighborhood(kpl_detector *h, const void *xyz, size_t xs, int n) {
     const double r = h->prm.radius_search;
     const bool hint_fits = h->kf_hint >= 0.0 && h->kf_hint_radius == r && h->kf_hint_n > 0 &&
                            (long long)n * 4 >= (long long)h->kf_hint_n * 3 && (long long)n * 3 <= (long long)h->kf_hint_n * 4;
-    if (hint_fits || n < 1024 || !(r > 0.0) || h->prm.neighbor_order != KPL_NEIGHBORS_CANONICAL || h->walk_forced != KPL_WALK_AUTO) return;
+    const bool sorted = h->prm.neighbor_order == KPL_NEIGHBORS_SORTED;
+    if (sorted && h->lcap_hint > 0 && h->lcap_hint_radius == r) return;           // (the sorted order's own hints exist already)
+    if ((!sorted && hint_fits) || n < 1024 || !(r > 0.0) || (!sorted && h->walk_forced != KPL_WALK_AUTO)) return;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     long long finite = 0;
     const char *base = static_cast<const char *>(xyz);
@@ -871,6 +890,18 @@ void estimate_neighborhood(kpl_detector *h, const void *xyz, size_t xs, int n) {
     const double area = e[2] * e[1];
     if (!(area > 0.0)) return;
     const double estimate = 3.14159265358979 * r * r * (double)finite / area;
+    if (sorted) {
+        // the sorted order's first call: with hundreds of neighbors per point the register-sort kernel would search every box only
+        // to find its lists full, and the key array (64 keys per point to begin with) would send the call back with RETRY after a
+        // whole run -- a one-shot TestDetector --sortedSearch at the reference's default radius paid 15-50 ms for that.  A clear
+        // estimate sizes the key array and lists every point at once (prepare_detect); the first status read replaces it
+        if (estimate >= 300.0 && (double)n * estimate * 1.25 * 8.0 <= 4.0 * 1073741824.0) {
+            h->kf_estimate = estimate;
+            h->kf_estimate_radius = r;
+            h->kf_estimate_n = n;
+        }
+        return;
+    }
     if (estimate < 1.5 * kTwoPassFromKf) return;   // a rough figure: only a clear case leaves the default before a measurement
     // ... and a VOLUME of points is not a surface (a million points in a cube, r = 1/50 of its edge: 1 260 estimated, 33 real):
     // the two-pass walk sizes its word lists by the hint, so an estimate is not allowed to ask for more than 1 GiB of them
