@@ -1,5 +1,8 @@
 """Round 6: the hints a handle carries from call to call must follow the views (advisor findings of round 5), kpl_reserve,
 the side-effect-free launch record, and a handle that changes streams."""
+import json
+import os
+
 import numpy as np
 import pytest
 
@@ -203,3 +206,15 @@ def test_sorted_word_lists_with_exact_ties_and_points_beyond_the_list(kpl, oracl
         assert np.array_equal(det.getKeypointsIndices(), want[1]), rep
         seen.add(det.getLastLaunch()["walk"])
     assert kpl.WALK_TWO_PASS in seen, seen
+
+
+def test_a_handle_lives_through_a_random_stream_of_views():
+    """tools/fuzz_streams.py for a few seconds: one handle, views whose density / size / radius / order change, every call
+    against the oracle (the hints a handle carries are choices of speed, never of result)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_streams.py"), "25", "4242"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["all_bit_exact"] and line["calls"] >= 20, line
