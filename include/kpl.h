@@ -88,9 +88,10 @@ typedef struct kpl_params {
  *              pcl::search::KdTree constructed with sorted = true to setSearchMethod (FLANN sorts its radius
  *              result set by (distance, index)).  Element 0 is then the query itself (or a duplicate of it with a
  *              lower index).  This is the order in which results can be compared bit for bit with a PCL build of
- *              the reference.  Cost against CANONICAL: ~3.3x at 70 neighbors per point (per-point sort in the registers
- *              of four lanes), ~6x between 125 and 512 (a wave per point collects and sorts the keys), ~1.6x at the
- *              ~2 300 of the reference's default radius (a workgroup per point). */
+ *              the reference.  Cost against CANONICAL (round 6): ~3.1x at 70 neighbors per point
+ *              (per-point sort in the registers of four lanes), 3.9-4.7x between 125 and 512 (word lists + eight lanes
+ *              per point up to ~250 keys, a wave per point beyond), ~2.5x at the ~2 300 of the reference's default radius
+ *              (a workgroup per point). */
 enum { KPL_NEIGHBORS_CANONICAL = 0, KPL_NEIGHBORS_SORTED = 1 };
 
 /* How the feature kernels WALK the canonical order (never what they compute: every choice gives the same bits --
