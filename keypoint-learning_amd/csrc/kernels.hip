@@ -1655,12 +1655,116 @@ struct KeySort {
     }
 };
 
+// The same network on 32-bit keys: two instructions per comparator inside a lane (v_min_u32 / v_max_u32) against five on the
+// 64-bit keys, two against six across lanes (one DPP move + v_med3_u32 with the bound 0 in the lower lane = the minimum,
+// ~0 in the upper lane = the maximum).
+template <int MASK>
+__device__ __forceinline__ unsigned group_fetch32(unsigned x) {
+    static_assert(MASK == 1 || MASK == 2 || MASK == 3 || MASK == 4 || MASK == 7, "partner inside a group of 8 lanes");
+    if (MASK <= 3) {
+        constexpr int ctrl = MASK == 1 ? 0xB1 : MASK == 2 ? 0x4E : 0x1B;
+        return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, ctrl, 0xf, 0xf, true);
+    }
+    if (MASK == 7) x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x1B, 0xf, 0xf, true);
+    return lane_xor4_u32(x);
+}
+
 template <int G, int E>
-__device__ __forceinline__ void sort_key_lists(unsigned long long *keys, int pi, int gq, int cnt) {
+struct KeySort32 {
+    using U = unsigned;
+    static __device__ __forceinline__ void inside(U &a, U &b) {          // a <- min, b <- max
+        const U lo = min(a, b), hi = max(a, b);
+        a = lo;
+        b = hi;
+        asm volatile("" : "+v"(a), "+v"(b));
+    }
+    static __device__ __forceinline__ U across(U mine, U other, U bound) {
+        U res;
+        asm volatile("v_med3_u32 %0, %1, %2, %3" : "=v"(res) : "v"(mine), "v"(other), "v"(bound));
+        return res;
+    }
+    template <int J>
+    static __device__ __forceinline__ void steps(U (&r)[E], int gq) {
+        if constexpr (J < E) {
+#pragma unroll
+            for (int a = 0; a < E; ++a)
+                if ((a & J) == 0) inside(r[a], r[a + J]);
+        } else {
+            const U bound = (gq & (J / E)) != 0 ? ~0u : 0u;
+#pragma unroll
+            for (int e = 0; e < E; ++e) r[e] = across(r[e], group_fetch32<J / E>(r[e]), bound);
+        }
+        if constexpr (J > 1) steps<J / 2>(r, gq);
+    }
+    template <int K>
+    static __device__ __forceinline__ void level(U (&r)[E], int gq) {
+        if constexpr (K <= E) {
+#pragma unroll
+            for (int blk = 0; blk < E; blk += K)
+#pragma unroll
+                for (int off = 0; off < K / 2; ++off) inside(r[blk + off], r[blk + K - 1 - off]);
+        } else {
+            const U bound = (gq & (K / E / 2)) != 0 ? ~0u : 0u;
+#pragma unroll
+            for (int e = 0; e < E / 2; ++e) {
+                const U o1 = group_fetch32<K / E - 1>(r[E - 1 - e]), o2 = group_fetch32<K / E - 1>(r[e]);
+                r[e] = across(r[e], o1, bound);
+                r[E - 1 - e] = across(r[E - 1 - e], o2, bound);
+            }
+        }
+        if constexpr (K >= 4) steps<K / 4>(r, gq);
+        if constexpr (2 * K <= G * E) level<2 * K>(r, gq);
+    }
+};
+
+// The lists are sorted through 32-bit STAND-INS of their keys where that decides the order: a key (d2, index) in slot i of its
+// list is represented by  q(d2) << SB | i,  q(d2) = (unsigned)(d2 * scale)  with scale ~ 2^(31 - SB) / r2 -- float multiply
+// and truncation are monotonic, so d2_a < d2_b gives q_a <= q_b, and wherever the q of neighbours in the sorted stand-ins
+// DIFFER their order is the order of the keys.  On a surface d2 is spread evenly over [0, r2): two of 70 keys share one of 2^24
+// values of q once in 7 000 points.  The network runs on the stand-ins (KeySort32), the 64-bit keys are fetched through the slot
+// numbers and written back in order.  If ANY two neighbours of ANY list of the wave share a q (equal or almost equal distances:
+// a lattice, duplicates) the wave sorts the 64-bit keys themselves (KeySort) -- the exact order either way.
+// Padding: slot i >= cnt stands for q = 2^(31 - SB) + 1 + i -- above every key's, all different.
+template <int G, int E>
+__device__ __forceinline__ void sort_key_lists(unsigned long long *keys, int pi, int gq, int cnt, float r2) {
     static_assert(G == 4 || G == 8, "the lanes of a group are a DPP quad, or two quads of a row");
     constexpr int kPts = kLanes / G;
-    unsigned long long r[E];
+    constexpr int SB = G * E == 64 ? 6 : G * E == 128 ? 7 : 8;
+    static_assert((1 << SB) == G * E, "slot bits");
+    constexpr unsigned kQEnd = 1u << (31 - SB);
+    const float scale = pin_f((float)kQEnd * 0.999f / r2);           // q < kQEnd for every d2 < r2
     wave_lds_fence();
+    if (scale < 3.0e38f) {                                           // (uniform; a radius so small that the scale overflows: below)
+        unsigned r[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const unsigned idx = (unsigned)(gq * E + e);
+            const float d2 = __uint_as_float(reinterpret_cast<const unsigned *>(keys)[2 * (min((int)idx, cnt - 1 < 0 ? 0 : cnt - 1) * kPts + pi) + 1]);
+            const unsigned q = (unsigned)(d2 * scale);
+            r[e] = (((int)idx < cnt ? q : kQEnd + 1u + idx) << SB) | idx;
+        }
+        KeySort32<G, E>::template level<2>(r, gq);
+        unsigned near = ~0u;                                         // smallest difference pattern of two neighbours
+#pragma unroll
+        for (int e = 0; e + 1 < E; ++e) near = min(near, r[e] ^ r[e + 1]);
+        const unsigned nxt = (unsigned)__shfl_down((int)r[0], 1);
+        if (gq != G - 1) near = min(near, r[E - 1] ^ nxt);
+        if (!__any((near >> SB) == 0u)) {
+            unsigned long long k64[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                if (gq * E + e < cnt) k64[e] = keys[(int)(r[e] & (unsigned)(G * E - 1)) * kPts + pi];
+                if (e % 8 == 7) __builtin_amdgcn_sched_barrier(0);      // (a stand-in's register is free once its key is requested)
+            }
+            wave_lds_fence();                                        // every lane has read its keys
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                if (gq * E + e < cnt) keys[(gq * E + e) * kPts + pi] = k64[e];
+            wave_lds_fence();
+            return;
+        }
+    }
+    unsigned long long r[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int idx = gq * E + e;
@@ -1804,7 +1908,8 @@ __device__ __forceinline__ int point_features_sorted(const float4 *__restrict__ 
                     }
                     const unsigned long long key = ((unsigned long long)__float_as_uint(dist2(p.x, p.y, p.z, now.q)) << 32) |
                                                    (unsigned long long)(unsigned)__float_as_int(now.q.w);
-                    const bool app = now.valid & (key >= lo) & (key < hi) & !(DEFER && deferred);
+                    // (DEFER: one pass over the whole window [0, key_end), and every accepted key is inside it)
+                    const bool app = DEFER ? now.valid & !deferred : now.valid & (key >= lo) & (key < hi);
                     const unsigned gb = (unsigned)(__ballot(app) >> group_shift) & ((1u << G) - 1u);
                     if (app) keys[(cnt + __popc(gb & ((1u << gq) - 1u))) * kPts + pi] = key;
                     cnt += __popc(gb);
@@ -1824,7 +1929,8 @@ __device__ __forceinline__ int point_features_sorted(const float4 *__restrict__ 
             if (DEFER && !__any(active && !deferred)) break;           // every point of the wave has left for the large path
         }
         // ---- sort the lists (the one place where the network is instantiated)
-        sort_key_lists<G, kSortedListKeys / G>(keys, pi, gq, cnt);
+        if (lcap <= kSortedListKeys / 2) sort_key_lists<G, kSortedListKeys / G / 2>(keys, pi, gq, cnt, f.r2);     // (uniform)
+        else sort_key_lists<G, kSortedListKeys / G>(keys, pi, gq, cnt, f.r2);
         // ---- add the neighbors in order, G per round; hpp:336: element 0 of the whole order is dropped
         {
             struct Next {
@@ -1866,7 +1972,7 @@ __device__ __forceinline__ int point_features_sorted(const float4 *__restrict__ 
             } while (__any((k - G < cnt) | pa.valid | pb.valid));
 #undef KPL_SORTED_ROUND
         }
-        if (!__any(hi != key_end)) break;
+        if (DEFER || !__any(hi != key_end)) break;
         // the next pass: the keys from the pivot on; a point whose window was never cut is done (an empty window)
         lo = hi != key_end ? hi : key_end;
         hi = key_end;
@@ -2001,8 +2107,8 @@ __device__ __forceinline__ int point_features_sorted_words(const float4 *__restr
         }
     }
     // ---- sort: 256 keys, or 128 when no list of the wave holds more
-    if (__all(cnt <= 16 * G)) sort_key_lists<G, 16>(keys, pi, gq, cnt);
-    else sort_key_lists<G, 32>(keys, pi, gq, cnt);
+    if (__all(cnt <= 16 * G)) sort_key_lists<G, 16>(keys, pi, gq, cnt, f.r2);
+    else sort_key_lists<G, 32>(keys, pi, gq, cnt, f.r2);
     // ---- add the neighbors in order, G per round; hpp:336: element 0 of the order is dropped
     {
         struct Next {
@@ -2665,7 +2771,7 @@ __global__ __launch_bounds__(kLanes) void feature_drain_kernel(Batch b, int maxF
 // the same for the views in sorted-search mode: kSortGroup lanes per point, 64 / kSortGroup points per wave
 //   LDS: [H: maxF x 16 floats][accept words: ecap x 16 uint2][key lists: lcap x 16 keys of 8 bytes]
 template <bool STATS>
-__global__ __launch_bounds__(kLanes) void feature_sorted_kernel(Batch b, int maxF, int ecap, int lcap, int by_xcd) {
+__global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(3))) void feature_sorted_kernel(Batch b, int maxF, int ecap, int lcap, int by_xcd) {
     extern __shared__ float H[];
     constexpr int G = kSortGroup, kPts = kLanes / G;
     const ViewBlock vb = view_block(by_xcd);
@@ -3089,8 +3195,75 @@ __device__ __forceinline__ unsigned long long lane_xor64(unsigned long long x, i
     }
 }
 
+// (as sort_key_lists: the network runs on 32-bit stand-ins  q(d2) << SB | slot  of the keys -- min / max / median-of-three
+// instead of 64-bit compares and selects, one lane exchange per comparator instead of two -- and the keys are fetched through
+// the slot numbers; a list in which two neighbours of the sorted stand-ins share a q is sorted by its 64-bit keys)
 template <int E>
-__device__ __forceinline__ void wave_sort_store(const unsigned long long *list, int n, int lane, unsigned long long *__restrict__ out) {
+__device__ __forceinline__ void wave_sort_store(const unsigned long long *list, int n, int lane, float r2,
+                                                unsigned long long *__restrict__ out) {
+    constexpr int SB = E == 1 ? 6 : E == 2 ? 7 : E == 4 ? 8 : 9;
+    static_assert((1 << SB) == kWave * E, "slot bits");
+    constexpr unsigned kQEnd = 1u << (31 - SB);
+    const float scale = pin_f((float)kQEnd * 0.999f / r2);
+    if (scale < 3.0e38f) {
+        unsigned r[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const unsigned i = (unsigned)(lane * E + e);
+            const float d2 = __uint_as_float(reinterpret_cast<const unsigned *>(list)[2 * max(min((int)i, n - 1), 0) + 1]);
+            const unsigned q = (unsigned)(d2 * scale);
+            r[e] = (((int)i < n ? q : kQEnd + 1u + i) << SB) | i;
+        }
+#pragma unroll
+        for (int k = 2; k <= kWave * E; k <<= 1) {
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                if (j < E) {
+                    const bool lane_up = (lane & (k / E)) == 0;        // (k >= E)
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        if ((e & j) != 0) continue;
+                        const unsigned a = r[e], c = r[e | j];
+                        const unsigned lo = min(a, c), hi = max(a, c);
+                        const bool up = k < E ? (e & k) == 0 : lane_up;
+                        r[e] = up ? lo : hi;
+                        r[e | j] = up ? hi : lo;
+                    }
+                } else {
+                    const bool keep_min = ((lane & (j / E)) == 0) == ((lane & (k / E)) == 0);
+                    const unsigned bound = keep_min ? 0u : ~0u;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        unsigned o;
+                        switch (j / E) {
+                        case 1: o = lane_xor32<1>(r[e]); break;
+                        case 2: o = lane_xor32<2>(r[e]); break;
+                        case 4: o = lane_xor32<4>(r[e]); break;
+                        case 8: o = lane_xor32<8>(r[e]); break;
+                        case 16: o = lane_xor32<16>(r[e]); break;
+                        default: o = lane_xor32<32>(r[e]); break;
+                        }
+                        unsigned res;
+                        asm volatile("v_med3_u32 %0, %1, %2, %3" : "=v"(res) : "v"(r[e]), "v"(o), "v"(bound));
+                        r[e] = res;
+                    }
+                }
+            }
+        }
+        unsigned near = ~0u;
+#pragma unroll
+        for (int e = 0; e + 1 < E; ++e) near = min(near, r[e] ^ r[e + 1]);
+        const unsigned nxt = (unsigned)__shfl_down((int)r[0], 1);
+        if (lane != kWave - 1) near = min(near, r[E - 1] ^ nxt);
+        if (!__any((near >> SB) == 0u)) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int i = lane * E + e;
+                if (i < n) out[i] = list[r[e] & (unsigned)(kWave * E - 1)];
+            }
+            return;
+        }
+    }
     unsigned long long r[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -3258,10 +3431,10 @@ __global__ __launch_bounds__(kWaveCollectWaves *kWave) void sorted_collect_wave_
             if (off != ~0ull) {                 // (no room: this call fails, the next one has it -- kpl_sync_status)
                 unsigned long long *out = v.sort_keys + off;
                 wave_lds_fence();               // the list is complete
-                if (cnt <= kWave) wave_sort_store<1>(list, cnt, lane, out);
-                else if (cnt <= 2 * kWave) wave_sort_store<2>(list, cnt, lane, out);
-                else if (cnt <= 4 * kWave) wave_sort_store<4>(list, cnt, lane, out);
-                else wave_sort_store<8>(list, cnt, lane, out);
+                if (cnt <= kWave) wave_sort_store<1>(list, cnt, lane, r2, out);
+                else if (cnt <= 2 * kWave) wave_sort_store<2>(list, cnt, lane, r2, out);
+                else if (cnt <= 4 * kWave) wave_sort_store<4>(list, cnt, lane, r2, out);
+                else wave_sort_store<8>(list, cnt, lane, r2, out);
             }
         }
         li += nwaves;
