@@ -677,6 +677,7 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
         if (h->launched_words && !stay && kf_hint_fits(h, n)) h->words_mean_keys = h->kf_hint;      // (the fresher figure decides about coming back)
         const bool enter = feat.all_large == 1 && h->words_mean_keys >= 100.0 && h->words_mean_keys <= 205.0;
         words_mode = enter || stay;
+        if (getenv("KPL_FORCE_WORDS")) { words_mode = true; if (h->words_mean_keys < 0) h->words_mean_keys = atof(getenv("KPL_FORCE_WORDS")); }
     }
     if (words_mode) {
         const double mean = h->launched_words && kf_hint_fits(h, n) ? h->kf_hint : h->words_mean_keys;
@@ -693,6 +694,7 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
     }
     if (words_mode) {
         feat.walk = 1;
+        feat.lanes = getenv("KPL_WORDS_LANES") ? atoi(getenv("KPL_WORDS_LANES")) : 8;
         feat.all_large = 0;
         KPL_HIP(h, h->wseg_start.ensure(sizeof(unsigned) * nn, st, h->parked));
         KPL_HIP(h, h->wseg_len.ensure(sizeof(int) * nn, st, h->parked));
@@ -704,7 +706,7 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
     v.wseg_start = h->wseg_start.as<unsigned>();
     v.wseg_len = h->wseg_len.as<int>();
     h->last_walk = feat.sorted ? (words_mode ? 1 : -1) : feat.walk;
-    h->last_lanes = feat.sorted ? (words_mode ? 8 : 0) : feat.lanes;
+    h->last_lanes = feat.sorted ? (words_mode ? feat.lanes : 0) : feat.lanes;
     h->last_words = (!feat.sorted && feat.walk == 0) ? (feat.words > 0 ? feat.words : 24) : 0;
     h->last_lcap = feat.sorted ? (words_mode ? 256 : feat.lcap > 0 ? feat.lcap : 128) : 0;
     h->launched_all_large = feat.sorted ? feat.all_large : 0;

@@ -1476,8 +1476,12 @@ constexpr int kSortGroup = 4;
 constexpr int kSortWords = 8;        // accept words per point between two collect rounds
 
 template <int G>
-__host__ __device__ inline size_t sorted_lds_bytes(int F, int ecap, int lcap) {
+__host__ __device__ inline size_t sorted_lds_bytes(int F, int ecap, int lcap) {          // the sparse queries: 64-bit keys
     return (sizeof(float) * (size_t)F + sizeof(uint2) * (size_t)ecap + sizeof(unsigned long long) * (size_t)lcap) * (size_t)(kLanes / G);
+}
+template <int G>
+__host__ __device__ inline size_t sorted_view_lds_bytes(int F, int ecap, int lcap) {     // whole views: positions
+    return (sizeof(float) * (size_t)F + sizeof(uint2) * (size_t)ecap + sizeof(unsigned) * (size_t)lcap) * (size_t)(kLanes / G);
 }
 
 // the rows of cells of a point's search box, walked by the G lanes of its group together (the search phase of
@@ -2001,24 +2005,183 @@ __device__ __forceinline__ int point_features_sorted(const float4 *__restrict__ 
 // (sorted_collect_wave_kernel: its own search of the box, a 256 .. 512-key network, the keys through HBM to sorted_add_kernel
 // -- ~1 100 + ~800 wave-instructions per point).  Here the search is the two-pass walk's (feature_search_kernel: the candidates
 // of a wave's points staged in LDS once, accept words to a list in global memory; no neighbor dropped), and EIGHT lanes per
-// point -- 8 points per wave -- do the rest in one kernel:
-//   collect  the point's word list: lane g takes the g-th set bit of the current word, loads that candidate (16 bytes:
-//            xyz + original index) and appends its key (d2 bits << 32 | index) to the point's list in LDS (kWordsKeys keys)
-//   sort     the bitonic network of sort_key_lists over 8 lanes x 32 keys, in registers (partners across lanes: DPP)
-//   add      the keys in order, 8 per round, as in point_features_sorted (hpp:334-359; element 0 dropped, hpp:336)
-// A point with more keys than the list holds is listed for the wave / workgroup kernels like the deferred points of
-// feature_sorted_kernel.  Same keys, same order, same arithmetic: the same bits.
-//   LDS: [H: maxF x 8 floats][key lists: kWordsKeys x 8 keys of 8 bytes]
+// point -- 8 points per wave -- do the rest in one kernel.  The kernel is a chain of dependent steps per wave (the ordered
+// updates), so its throughput is its occupancy: 8 / 5 / 4 / 2 waves per CU took 4.2 / 6.8 / 8.5 / 16.5 ms (profiles/
+// r06_notes.md).  Its LDS therefore holds FOUR bytes per neighbor -- the neighbor's storage position -- not the 8-byte key:
+//   collect  lane g expands the words g, g + 8, ... of the point's list into positions (slot = neighbors before it)
+//   sort     every lane loads the records of its 32 slots (12 bytes: xyz), d2 as everywhere -> the 32-bit stand-in
+//            q(d2) << 8 | slot (see sort_key_lists); the network KeySort32 over 8 lanes x 32 stand-ins in registers; the
+//            positions written back in that order
+//   add      G positions per round: record (xyz + original index) -> d2 again (the same arithmetic, the same bits), the
+//            normal by original index, then as point_features_sorted (hpp:334-359; element 0 dropped, hpp:336)
+// A point with more neighbors than the list holds, or with two neighbours in the sorted stand-ins that share a q (equal or
+// almost equal distances: only the 64-bit keys (d2, index) order those), is listed for the wave / workgroup kernels like the
+// deferred points of feature_sorted_kernel.  Same keys, same order, same arithmetic: the same bits.
+//   LDS: [H: maxF x 8 floats][position lists: kWordsKeys x 8 positions of 4 bytes]
 constexpr int kWordsGroup = 8, kWordsKeys = 32 * kWordsGroup;
 
+// the positions of every point's list (tl[slot * kPts + point], cnt <= G E of them) into ascending (d2, index) order; returns
+// true for a point whose order the stand-ins do not decide
+template <int G, int E>
+__device__ __forceinline__ bool sort_position_lists(unsigned *tl, int lcap, const float4 *__restrict__ pts, const float4 &p, int pi,
+                                                    int gq, int cnt, float r2, unsigned group_shift) {
+    constexpr int kPts = kLanes / G;
+    constexpr int SB = G * E == 64 ? 6 : G * E == 128 ? 7 : 8;
+    static_assert((1 << SB) == G * E, "slot bits");
+    constexpr unsigned kQEnd = 1u << (31 - SB);
+    const float scale = pin_f((float)kQEnd * 0.999f / r2);
+    if (!(scale < 3.0e38f)) return true;                             // (uniform) a radius so small that the scale overflows
+    unsigned r[E];
+    wave_lds_fence();
+    const int last = max(cnt - 1, 0);                                // (slot 0 always holds a valid position)
+#pragma unroll
+    for (int e0 = 0; e0 < E; e0 += 8) {
+        f32x3 c[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c[j] = ld12(pts, (int)tl[min(gq * E + e0 + j, last) * kPts + pi]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned idx = (unsigned)(gq * E + e0 + j);
+            const unsigned q = (unsigned)(dist2(p.x, p.y, p.z, c[j]) * scale);
+            r[e0 + j] = (((int)idx < cnt ? q : kQEnd + 1u + idx) << SB) | idx;
+        }
+    }
+    KeySort32<G, E>::template level<2>(r, gq);
+    unsigned near = ~0u;
+#pragma unroll
+    for (int e = 0; e + 1 < E; ++e) near = min(near, r[e] ^ r[e + 1]);
+    const unsigned nxt = (unsigned)__shfl_down((int)r[0], 1);
+    if (gq != G - 1) near = min(near, r[E - 1] ^ nxt);
+    const bool tie = (((unsigned)(__ballot((near >> SB) == 0u) >> group_shift)) & ((1u << G) - 1u)) != 0u;
+    // (slots and positions from cnt on are never used; the list may be shorter than the network: lcap <= G E)
+#pragma unroll
+    for (int e = 0; e < E; ++e) r[e] = tl[min((int)(r[e] & (unsigned)(G * E - 1)), lcap - 1) * kPts + pi];
+    wave_lds_fence();                                                // every lane has read its positions
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+        if (gq * E + e < lcap) tl[(gq * E + e) * kPts + pi] = r[e];
+    wave_lds_fence();
+    return tie;
+}
+
+// the positions of the neighbors in the words 0 .. ecnt - 1 of a point (fetch(e): first position and bits of word e, zeros
+// beyond the list) appended to its list: lane g of the group expands the words g, g + G, ... (slot = neighbors before it).
+// cnt comes back as the number of neighbors, also where the list (lcap positions) does not hold them all
+template <int G, class Fetch>
+__device__ __forceinline__ void expand_words(unsigned *tl, int lcap, int pi, int gq, unsigned group_shift, int ecnt, int &cnt, Fetch fetch) {
+    constexpr int kPts = kLanes / G;
+    uint2 wd = fetch(gq);
+    for (int eb = 0; __any(eb < ecnt); eb += G) {
+        const uint2 nx = fetch(eb + G + gq);                                   // (the next G words on their way)
+        unsigned bits = wd.y;
+        int incl = __popc(bits);                                               // neighbors in the group's words up to this lane's
+        {
+            const int s1 = __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);          // row_shr:1
+            incl += gq >= 1 ? s1 : 0;
+            const int s2 = __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);          // row_shr:2
+            incl += gq >= 2 ? s2 : 0;
+            if (G == 8) {
+                const int s4 = __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, true);      // row_shr:4
+                incl += gq >= 4 ? s4 : 0;
+            }
+        }
+        int slot = cnt + incl - __popc(bits);
+        cnt += __shfl(incl, (int)group_shift + G - 1);
+        while (__any(bits != 0u)) {
+            if (bits != 0u) {
+                if (slot < lcap) tl[slot * kPts + pi] = wd.x + (unsigned)lowest_bit_index(bits);
+                ++slot;
+                bits = drop_lowest_bit(bits);
+            }
+        }
+        wd = nx;
+    }
+}
+
+// the feature loop (hpp:334-359) over a point's positions in sorted order, G per round; hpp:336: element 0 of the order is
+// dropped.  Position -> the neighbor's record (xyz + original index), requested four rounds ahead of its use -> d2 (the
+// arithmetic the stand-in saw: the same bits) and the normal by original index, requested two rounds ahead
 template <int G>
-__device__ __forceinline__ int point_features_sorted_words(const float4 *__restrict__ pts, const char *__restrict__ nrmsrc, unsigned ns,
-                                                           const FeatDesc &fin, float4 p, float4 np, float *H,
-                                                           unsigned long long *keys, const uint2 *__restrict__ list, int stride,
-                                                           int ecnt, bool &deferred) {
-    static_assert(G == 8, "eight lanes per point");
-    constexpr int kPts = kLanes / G, lcap = 32 * G;
-    const int tid = threadIdx.x, pi = tid / G, gq = tid % G;
+__device__ __forceinline__ void add_sorted_positions(const unsigned *tl, int lcap, int cnt, const float4 *__restrict__ pts,
+                                                     const char *__restrict__ nrmsrc, unsigned ns, const FeatDesc &f, const float4 &p,
+                                                     const float4 &np, int col_address, int pi, int gq) {
+    constexpr int kPts = kLanes / G;
+    struct Next {
+        bool valid;
+        float4 q;
+        float d2;
+        f32x3 n;
+    };
+    int k = cnt > 0 ? 1 : 0;
+    auto request_record = [&](Next &s) {
+        const int idx = k + gq;
+        s.valid = idx < cnt;
+        const unsigned t = tl[min(idx, lcap - 1) * kPts + pi];
+        k += G;
+        s.q = pts[s.valid ? t : 0u];
+    };
+    auto request_normal = [&](Next &s) {
+        s.d2 = dist2(p.x, p.y, p.z, s.q);
+        const unsigned orig = s.valid ? (unsigned)__float_as_int(s.q.w) : 0u;
+        s.n = *reinterpret_cast<const f32x3 *>(nrmsrc + (size_t)orig * ns);
+    };
+    constexpr int kRing = 5;
+    Next sl[kRing];
+#pragma unroll
+    for (int q = 0; q < kRing; ++q) {
+        sl[q].valid = false;
+        sl[q].q = make_float4(0.f, 0.f, 0.f, 0.f);
+        sl[q].d2 = 0.f;
+        sl[q].n = f32x3{0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int q = 0; q < kRing - 1; ++q) request_record(sl[q]);
+    request_normal(sl[0]);
+    request_normal(sl[1]);
+    bool more = true;
+    while (more) {
+#pragma unroll
+        for (int q = 0; q < kRing; ++q) {
+            Next &now = sl[q];
+            request_record(sl[(q + 4) % kRing]);
+            request_normal(sl[(q + 2) % kRing]);
+            const bool has_ = now.valid & finite3(now.n.x, now.n.y, now.n.z);          /* hpp:338 */
+            Contribution c_;
+            if (has_) c_ = neighbor_contribution<kPts>(f, now.d2, np, now.n, col_address);
+#pragma unroll
+            for (int sub_ = 0; sub_ < G; ++sub_) {
+                if (has_ & (gq == sub_)) apply_contribution(c_, request_cells(c_));
+                wave_lds_fence();
+            }
+            now.valid = false;
+        }
+        bool pending = false;
+#pragma unroll
+        for (int q = 0; q < kRing; ++q) pending |= sl[q].valid;
+        more = __any(pending);
+    }
+}
+
+// hpp:360-370: the rows of the histogram normalized, one row per lane of the group
+template <int G>
+__device__ __forceinline__ void normalize_rows(float *H, const FeatDesc &f, int pi, int gq) {
+    constexpr int kPts = kLanes / G;
+    wave_lds_fence();
+    for (int a = gq; a < f.A; a += G) {
+        float *h = H + (a * f.B) * kPts + pi;
+        float sq = 0.0f;
+        for (int kk = 0; kk < f.B; ++kk) {
+            float v = h[kk * kPts];
+            sq += v * v;
+        }
+        const float nr = sqrtf(sq);
+        if (nr > 0)
+            for (int kk = 0; kk < f.B; ++kk) h[kk * kPts] = h[kk * kPts] / nr;
+    }
+    wave_lds_fence();
+}
+
+__device__ __forceinline__ FeatDesc pinned_feat(const FeatDesc &fin) {
     FeatDesc f;
     f.A = pin_i(fin.A);
     f.B = pin_i(fin.B);
@@ -2034,144 +2197,112 @@ __device__ __forceinline__ int point_features_sorted_words(const float4 *__restr
     f.bin_rdim = pin_f(fin.bin_rdim);
     f.r2 = pin_f(fin.r2);
     f.rr = fin.rr;
+    return f;
+}
+
+template <int G>
+__device__ __forceinline__ int point_features_sorted_words(const float4 *__restrict__ pts, const char *__restrict__ nrmsrc, unsigned ns,
+                                                           const FeatDesc &fin, float4 p, float4 np, float *H,
+                                                           unsigned *tl, const uint2 *__restrict__ list, int stride,
+                                                           int ecnt, bool &deferred) {
+    static_assert(G == 8 || G == 4, "eight lanes per point (up to 256 neighbors), or four (up to 128)");
+    constexpr int kPts = kLanes / G, lcap = 32 * G;
+    const int tid = threadIdx.x, pi = tid / G, gq = tid % G;
+    const FeatDesc f = pinned_feat(fin);
     for (int c = gq; c < f.F; c += G) H[c * kPts + pi] = 0.0f;                     // hpp:325
+    if (gq == 0) tl[pi] = 0u;
     const int col_address = lds_address(H + pi);
     const unsigned group_shift = (unsigned)(tid & ~(G - 1));
     deferred = false;
-    int cnt = 0, kf = 0;
-    // ---- collect: G accepted neighbors of the point per round -> keys
-    if (__any(ecnt > 0)) {
-        const int last = max(ecnt - 1, 0);
-        int e = 0;
-        unsigned w = 0u;
-        int wbase = 0;
-        uint2 nw = ecnt > 0 ? list[0] : make_uint2(0u, 0u);
-        struct Taken {
-            bool valid;
-            float4 q;
-        };
-        auto take = [&](Taken &slot) {
-            const bool refill = (w == 0u) & (e < ecnt);
-            w = refill ? nw.y : w;
-            wbase = refill ? (int)nw.x : wbase;
-            e += refill ? 1 : 0;
-            if (refill) nw = list[min(e, last) * stride];
-            // lane g: the g-th set bit of what is left of the word (a round never spans two words)
-            const unsigned c1 = drop_lowest_bit(w), c2 = drop_lowest_bit(c1), c3 = drop_lowest_bit(c2), c4 = drop_lowest_bit(c3),
-                           c5 = drop_lowest_bit(c4), c6 = drop_lowest_bit(c5), c7 = drop_lowest_bit(c6);
-            const unsigned m = gq == 0 ? w : gq == 1 ? c1 : gq == 2 ? c2 : gq == 3 ? c3 : gq == 4 ? c4 : gq == 5 ? c5 : gq == 6 ? c6 : c7;
-            w = drop_lowest_bit(c7);
-            slot.valid = m != 0u;
-            const int tt = slot.valid ? wbase + lowest_bit_index(m) : 0;
-            slot.q = pts[tt];
-        };
-        auto collect = [&](Taken &now) {
-            if (cnt > lcap - G) {          // no room for the keys of this round: the point leaves for the wave / workgroup kernels
-                deferred = true;
-                cnt = 0;
-                e = ecnt;
-                w = 0u;
-            }
-            const unsigned long long key = ((unsigned long long)__float_as_uint(dist2(p.x, p.y, p.z, now.q)) << 32) |
-                                           (unsigned long long)(unsigned)__float_as_int(now.q.w);
-            const bool app = now.valid & !deferred;
-            const unsigned gb = (unsigned)(__ballot(app) >> group_shift) & ((1u << G) - 1u);
-            if (app) keys[(cnt + __popc(gb & ((1u << gq) - 1u))) * kPts + pi] = key;
-            cnt += __popc(gb);
-            kf += __popc(gb);
-            now.valid = false;
-        };
-        // (the candidates of THREE rounds are on their way while a round's keys are appended: with ~2 waves per SIMD -- the key
-        // lists take 16 KB of LDS per wave -- one round ahead left every round waiting for its loads: 4.8 ms per 8 x 200 k points
-        // at 190 keys, against 3.x with three)
-        constexpr int kAhead = 3;
-        Taken sl[kAhead + 1];
-#pragma unroll
-        for (int q = 0; q <= kAhead; ++q) {
-            sl[q].valid = false;
-            sl[q].q = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int q = 0; q < kAhead; ++q) take(sl[q]);
-        bool more = true;
-        while (more) {
-#pragma unroll
-            for (int q = 0; q <= kAhead; ++q) {
-                take(sl[(q + kAhead) % (kAhead + 1)]);
-                collect(sl[q]);
-            }
-            bool pending = false;
-#pragma unroll
-            for (int q = 0; q <= kAhead; ++q) pending |= sl[q].valid;
-            more = __any((w != 0u) | (e < ecnt) | pending);
-        }
+    int cnt = 0;
+    // ---- collect: the words of the list, G at a time, each expanded by its lane
+    expand_words<G>(tl, lcap, pi, gq, group_shift, ecnt, cnt,
+                    [&](int e) { return e < ecnt ? list[e * stride] : make_uint2(0u, 0u); });
+    const int kf = cnt;
+    if (cnt > lcap) {                  // more neighbors than the list holds: the point leaves for the wave / workgroup kernels
+        deferred = true;
+        cnt = 0;
     }
-    // ---- sort: 256 keys, or 128 when no list of the wave holds more
-    if (__all(cnt <= 16 * G)) sort_key_lists<G, 16>(keys, pi, gq, cnt, f.r2);
-    else sort_key_lists<G, 32>(keys, pi, gq, cnt, f.r2);
-    // ---- add the neighbors in order, G per round; hpp:336: element 0 of the order is dropped
+    // ---- sort: 32 G stand-ins, or half of that when no list of the wave holds more
     {
-        struct Next {
-            bool valid;
-            float d2;
-            f32x3 n;
-        };
-        int k = cnt > 0 ? 1 : 0;
-        const int key_last = (lcap - 1) * kPts + pi;
-        auto take = [&](Next &slot) {
-            const int idx = k + gq;
-            slot.valid = idx < cnt;
-            const unsigned long long key = keys[min(idx * kPts + pi, key_last)];
-            k += G;
-            slot.d2 = __uint_as_float((unsigned)(key >> 32));
-            const unsigned orig = slot.valid ? (unsigned)key : 0u;
-            slot.n = *reinterpret_cast<const f32x3 *>(nrmsrc + (size_t)orig * ns);
-        };
-        constexpr int kAhead = 3;              // normals requested three rounds ahead of their use (see the collect phase)
-        Next sl[kAhead + 1];
-#pragma unroll
-        for (int q = 0; q <= kAhead; ++q) {
-            sl[q].valid = false;
-            sl[q].d2 = 0.f;
-            sl[q].n = f32x3{0.f, 0.f, 0.f};
+        const bool tie = __all(cnt <= 16 * G) ? sort_position_lists<G, 16>(tl, lcap, pts, p, pi, gq, cnt, f.r2, group_shift)
+                                              : sort_position_lists<G, 32>(tl, lcap, pts, p, pi, gq, cnt, f.r2, group_shift);
+        if (tie & (cnt > 1)) {         // equal or almost equal distances: the 64-bit keys order them (the wave kernel)
+            deferred = true;
+            cnt = 0;
         }
-#pragma unroll
-        for (int q = 0; q < kAhead; ++q) take(sl[q]);
-        bool more = true;
-        while (more) {
-#pragma unroll
-            for (int q = 0; q <= kAhead; ++q) {
-                Next &now = sl[q];
-                take(sl[(q + kAhead) % (kAhead + 1)]);
-                const bool has_ = now.valid & finite3(now.n.x, now.n.y, now.n.z);          /* hpp:338 */
-                Contribution c_;
-                if (has_) c_ = neighbor_contribution<kPts>(f, now.d2, np, now.n, col_address);
-#pragma unroll
-                for (int sub_ = 0; sub_ < G; ++sub_) {
-                    if (has_ & (gq == sub_)) apply_contribution(c_, request_cells(c_));
-                    wave_lds_fence();
-                }
-                now.valid = false;
+    }
+    add_sorted_positions<G>(tl, lcap, cnt, pts, nrmsrc, ns, f, p, np, col_address, pi, gq);
+    normalize_rows<G>(H, f, pi, gq);
+    return kf;
+}
+
+// The whole-view kernel of the sorted order (feature_sorted_kernel: up to 124 neighbors per point, kSortGroup lanes per point):
+// the search of point_features_sorted (RowSearch: accept words of the point's box, `ecap` of them in LDS at a time), then as
+// point_features_sorted_words -- positions, stand-ins, ordered adds; 4 bytes of LDS per neighbor and ~90 registers keep
+// ~16 waves per CU where the 64-bit key lists kept 8-10.  overflow: the list ran full (the search stops: kf is not the
+// neighborhood's size then); deferred: overflow, or an order the stand-ins do not decide -- a point for the wave / workgroup kernels.
+template <int G>
+__device__ __forceinline__ int point_features_sorted_view(const float4 *__restrict__ pts, const char *__restrict__ nrmsrc, unsigned ns,
+                                                          const int *__restrict__ cell_start, const GridDesc &g, const FeatDesc &fin,
+                                                          float4 p, float4 np, float *H, uint2 *ent, int ecap, unsigned *tl, int lcap,
+                                                          bool active, bool &deferred, bool &overflow) {
+    constexpr int kPts = kLanes / G;
+    const int tid = threadIdx.x, pi = tid / G, gq = tid % G;
+    const FeatDesc f = pinned_feat(fin);
+    for (int c = gq; c < f.F; c += G) H[c * kPts + pi] = 0.0f;                     // hpp:325
+    if (gq == 0) tl[pi] = 0u;
+    RowSearch<G> rs;
+    rs.init(pts, cell_start, g, p, f.rr, f.r2, active, gq);
+    const int col_address = lds_address(H + pi);
+    const unsigned group_shift = (unsigned)(tid & ~(G - 1));
+    deferred = overflow = false;
+    int cnt = 0, kf = 0;
+    rs.restart();
+    for (;;) {
+        // ---- search: accept words of the point
+        int ecnt = 0;
+        bool full = false;
+        while (!full) {
+            int wbase;
+            unsigned w;
+            if (!rs.next_word(wbase, w)) break;
+            kf += __popc(w);
+            if (w != 0u) {
+                if (gq == 0) ent[ecnt * kPts + pi] = make_uint2((unsigned)wbase, __brev(w));     // first candidate = bit 0
+                ++ecnt;
             }
-            bool pending = false;
-#pragma unroll
-            for (int q = 0; q <= kAhead; ++q) pending |= sl[q].valid;
-            more = __any((k - G * kAhead < cnt) | pending);
+            full = __any(ecnt == ecap);
+        }
+        // ---- collect: their neighbors' positions
+        if (__any(ecnt > 0)) {
+            wave_lds_fence();
+            int c2 = cnt;
+            expand_words<G>(tl, lcap, pi, gq, group_shift, ecnt, c2,
+                            [&](int e) { return e < ecnt ? ent[e * kPts + pi] : make_uint2(0u, 0u); });
+            wave_lds_fence();
+            if (!overflow) cnt = c2;
+            if (cnt > lcap) {          // the list is full: the point leaves (its rows are over: it does not hold up the others' walk)
+                overflow = true;
+                cnt = 0;
+                rs.ny = 0;
+                rs.t1 = rs.t;
+            }
+        }
+        if (rs.exhausted()) break;
+        if (!__any(active && !overflow)) break;           // every point of the wave has left for the large path
+    }
+    deferred = overflow;
+    {
+        const bool tie = (lcap <= 16 * G || __all(cnt <= 16 * G)) ? sort_position_lists<G, 16>(tl, lcap, pts, p, pi, gq, cnt, f.r2, group_shift)
+                                                                  : sort_position_lists<G, 32>(tl, lcap, pts, p, pi, gq, cnt, f.r2, group_shift);
+        if (tie & (cnt > 1)) {
+            deferred = true;
+            cnt = 0;
         }
     }
-    wave_lds_fence();
-    for (int a = gq; a < f.A; a += G) {                                            // hpp:360-370, one row per lane
-        float *h = H + (a * f.B) * kPts + pi;
-        float sq = 0.0f;
-        for (int kk = 0; kk < f.B; ++kk) {
-            float v = h[kk * kPts];
-            sq += v * v;
-        }
-        const float nr = sqrtf(sq);
-        if (nr > 0)
-            for (int kk = 0; kk < f.B; ++kk) h[kk * kPts] = h[kk * kPts] / nr;
-    }
-    wave_lds_fence();
+    add_sorted_positions<G>(tl, lcap, cnt, pts, nrmsrc, ns, f, p, np, col_address, pi, gq);
+    normalize_rows<G>(H, f, pi, gq);
     return kf;
 }
 
@@ -2769,9 +2900,9 @@ __global__ __launch_bounds__(kLanes) void feature_drain_kernel(Batch b, int maxF
 }
 
 // the same for the views in sorted-search mode: kSortGroup lanes per point, 64 / kSortGroup points per wave
-//   LDS: [H: maxF x 16 floats][accept words: ecap x 16 uint2][key lists: lcap x 16 keys of 8 bytes]
+//   LDS: [H: maxF x 16 floats][accept words: ecap x 16 uint2][position lists: lcap x 16 positions of 4 bytes]
 template <bool STATS>
-__global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(3))) void feature_sorted_kernel(Batch b, int maxF, int ecap, int lcap, int by_xcd) {
+__global__ __launch_bounds__(kLanes) void feature_sorted_kernel(Batch b, int maxF, int ecap, int lcap, int by_xcd) {
     extern __shared__ float H[];
     constexpr int G = kSortGroup, kPts = kLanes / G;
     const ViewBlock vb = view_block(by_xcd);
@@ -2790,18 +2921,18 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(3))) voi
     // 2 300 --: every point is for the workgroup kernel, the wave-per-point kernel is not even launched)
     const bool large = own_cell > kLargeCell || (v.f.all_large && w.scoreable), huge = own_cell > kHugeCell || (v.f.all_large == 2 && w.scoreable);
     uint2 *ent = reinterpret_cast<uint2 *>(H + maxF * kPts);
-    unsigned long long *keys = reinterpret_cast<unsigned long long *>(ent + ecap * kPts);
-    bool deferred = false;
+    unsigned *tl = reinterpret_cast<unsigned *>(ent + ecap * kPts);
+    bool deferred = false, overflow = false;
     int kf = 0;
     if (__any(w.scoreable && !large))           // (a wave whose points are all large only lists them)
-        kf = point_features_sorted<G, true>(v.pts, v.nrmsrc, v.ns, v.cell_start, v.ds->grid, v.f, w.p, w.np, H, ent, ecap,
-                                            keys, lcap, w.scoreable && !large, deferred);
+        kf = point_features_sorted_view<G>(v.pts, v.nrmsrc, v.ns, v.cell_start, v.ds->grid, v.f, w.p, w.np, H, ent, ecap,
+                                           tl, lcap, w.scoreable && !large, deferred, overflow);
     else
         for (int c = gq; c < v.f.F; c += G) H[c * kPts + pi] = 0.0f;      // (what a point that is not scored leaves in its column)
     // the longest neighborhood of the wave (a deferred point: "longer than the list") for the list capacity of the handle's
     // next launch: a plain read of the running maximum first, the atomic only when the wave raises it (a handful per launch)
     {
-        int m = (w.scoreable && !large) ? (deferred ? kSortedListKeys + 1 : kf) : 0;
+        int m = (w.scoreable && !large) ? (overflow ? kSortedListKeys + 1 : kf) : 0;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) m = max(m, __shfl_xor(m, d));
         if (threadIdx.x == 0 && m > __hip_atomic_load(&v.ds->kf_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&v.ds->kf_max, m);
@@ -2832,23 +2963,23 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(3))) voi
 }
 
 // sorted order through the word lists (point_features_sorted_words): kWordsGroup lanes per point, 8 points per wave
-//   LDS: [H: maxF x 8 floats][key lists: kWordsKeys x 8 keys]
-template <bool STATS>
+//   LDS: [H: maxF x 8 floats][position lists: kWordsKeys x 8 positions]
+template <bool STATS, int G>
 __global__ __launch_bounds__(kLanes) void sorted_words_kernel(Batch b, int maxF, int by_xcd) {
     extern __shared__ float H[];
-    constexpr int G = kWordsGroup, kPts = kLanes / G;
+    constexpr int kPts = kLanes / G;
     const ViewBlock vb = view_block(by_xcd);
     const ViewDev &v = b.view[vb.view];
-    if (!v.f.sorted || v.f.walk != kWalkTwoPass) return;
+    if (!v.f.sorted || v.f.walk != kWalkTwoPass || v.f.lanes != G) return;
     const int chunk = vb.bx / G, pi = threadIdx.x / G, gq = threadIdx.x % G;
     const int col = (vb.bx % G) * kPts + pi;
     if (chunk * kLanes + col - pi >= v.n) return;
     const WavePoint w = wave_point(v, chunk, col, true);
-    unsigned long long *keys = reinterpret_cast<unsigned long long *>(H + maxF * kPts);
+    unsigned *tl = reinterpret_cast<unsigned *>(H + maxF * kPts);
     const int ecnt = w.scoreable ? v.wseg_len[w.s] : 0;
     const uint2 *list = v.words + (w.scoreable ? v.wseg_start[w.s] : 0u);
     bool deferred = false;
-    const int kf = point_features_sorted_words<G>(v.pts, v.nrmsrc, v.ns, v.f, w.p, w.np, H, keys, list, kLanes / kSearchGroup, ecnt, deferred);
+    const int kf = point_features_sorted_words<G>(v.pts, v.nrmsrc, v.ns, v.f, w.p, w.np, H, tl, list, kLanes / kSearchGroup, ecnt, deferred);
     // a point whose list ran full: for the wave-per-point kernel (and the workgroup kernel behind it), as in feature_sorted_kernel
     const unsigned long long lbal = __ballot(deferred && gq == 0);
     if (lbal != 0ull) {
@@ -5032,7 +5163,7 @@ void launch_feature_stage(const Batch &b, hipStream_t st) {
         int lcap = 8;
         for (int v = 0; v < b.nviews; ++v)
             if (b.view[v].f.sorted) lcap = std::max(lcap, b.view[v].f.lcap > 0 && b.view[v].f.lcap <= kSortedListKeys ? b.view[v].f.lcap : kSortedListKeys);
-        const size_t lds = sorted_lds_bytes<kSortGroup>(maxF, kSortWords, lcap);
+        const size_t lds = sorted_view_lds_bytes<kSortGroup>(maxF, kSortWords, lcap);
         const dim3 grid(div_up(n, kLanes) * kSortGroup, b.nviews);
         // views of about the same size are dealt to the XCDs (view_block): what a view reads at random then stays in one L2
         int min_n = n;
@@ -5049,10 +5180,22 @@ void launch_feature_stage(const Batch &b, hipStream_t st) {
             const dim3 sgrid(div_up(n, kLanes) * kSearchGroup, b.nviews);
             if (stats) feature_search_kernel<true><<<sgrid, kLanes, 0, st>>>(b, 1);
             else feature_search_kernel<false><<<sgrid, kLanes, 0, st>>>(b, 1);
-            const size_t wlds = (sizeof(float) * (size_t)maxF + sizeof(unsigned long long) * (size_t)kWordsKeys) * (size_t)(kLanes / kWordsGroup);
-            const dim3 wgrid(div_up(n, kLanes) * kWordsGroup, b.nviews);
-            if (stats) sorted_words_kernel<true><<<wgrid, kLanes, wlds, st>>>(b, maxF, by_xcd);
-            else sorted_words_kernel<false><<<wgrid, kLanes, wlds, st>>>(b, maxF, by_xcd);
+            // (positions and histograms of a wave's points take the same LDS with eight and with four lanes per point)
+            const size_t wlds = (sizeof(float) * (size_t)maxF + sizeof(unsigned) * (size_t)kWordsKeys) * (size_t)(kLanes / kWordsGroup);
+            const size_t wlds4 = (sizeof(float) * (size_t)maxF + sizeof(unsigned) * (size_t)(kWordsKeys / 2)) * (size_t)(kLanes / 4);
+            bool w8 = false, w4 = false;
+            for (int v = 0; v < b.nviews; ++v)
+                if (b.view[v].f.sorted && b.view[v].f.walk == kWalkTwoPass) (b.view[v].f.lanes == 4 ? w4 : w8) = true;
+            if (w8) {
+                const dim3 wgrid(div_up(n, kLanes) * kWordsGroup, b.nviews);
+                if (stats) sorted_words_kernel<true, kWordsGroup><<<wgrid, kLanes, wlds, st>>>(b, maxF, by_xcd);
+                else sorted_words_kernel<false, kWordsGroup><<<wgrid, kLanes, wlds, st>>>(b, maxF, by_xcd);
+            }
+            if (w4) {
+                const dim3 wgrid(div_up(n, kLanes) * 4, b.nviews);
+                if (stats) sorted_words_kernel<true, 4><<<wgrid, kLanes, wlds4, st>>>(b, maxF, by_xcd);
+                else sorted_words_kernel<false, 4><<<wgrid, kLanes, wlds4, st>>>(b, maxF, by_xcd);
+            }
         }
         // persistent: as many workgroups of four waves as are resident at once (every wave takes the same share of the list:
         // workgroups that start when others have finished would double the kernel's time)
