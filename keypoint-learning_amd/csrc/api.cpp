@@ -156,6 +156,11 @@ struct kpl_detector {
     DevBuf large_list, seg_start, seg_len, sort_keys;      // sorted-search mode, large neighborhoods (kernels.hip)
     DevBuf words, wseg_start, wseg_len;                    // sorted order through the word lists (sorted_words_kernel): accept words of every point
     bool launched_words = false;  // the last scoring launch was such a one
+    int launched_words_lcap = 0;  // ... with lists of so many positions per point (256 / 512)
+    bool launched_sorted = false; // the last scoring launch was in sorted order
+    int tie_ban = 0;              // sorted order: launches left that list every point without trying the register / word kernels -- the
+                                  // last launch that tried them handed most points on although their lists held them (equal distances:
+                                  // the stand-ins of sort_position_lists do not order those, the wave / workgroup kernels' 64-bit keys do)
     double kf_estimate = -1.0;    // sorted order, first host call: neighbors per point estimated off the bounding box (estimate_neighborhood)
     double kf_estimate_radius = 0.0;
     int kf_estimate_n = 0;
@@ -325,6 +330,9 @@ void choose_walk(const kpl_detector *h, FeatDesc &f) {
     }
     if (f.walk == 0) f.words = words_for(h);        // (thresholds: kWords12BelowKf / 16 / 20 above)
 }
+// sorted order through the word lists: mean neighbors per point up to which a view enters / stays, and up to which 256 positions
+// per point are the better choice (beyond: 512)
+constexpr double kWordsEnterBelow = 410.0, kWordsStayBelow = 430.0, kWords256BelowKf = 225.0;
 static_assert(kWords12BelowKf == 80.0 && kWords16BelowKf == 140.0 && kWords20BelowKf == 175.0, "words_for() spells these out");
 
 NmsDesc make_nms(const kpl_params &p) {
@@ -535,6 +543,12 @@ int sync_status(kpl_detector *h, hipStream_t st) {
         h->all_large_n = h->launched_n;
         KPL_HIP(h, hipMemsetAsync((char *)h->dstate.p + offsetof(DevState, kf_max), 0, sizeof(int), st));
     }
+    if (h->h_state->status == kStatusOk && h->launched_sorted && !h->launched_all_large && h->launched_n > 0 &&
+        (long long)h->h_state->large_seen * 2 >= (long long)h->launched_n) {
+        const bool lists_held = h->launched_words ? (h->kf_hint > 0.0 && h->kf_hint <= 0.8 * (double)h->launched_words_lcap)
+                                                  : (h->h_state->kf_max > 0 && h->h_state->kf_max <= 124);
+        if (lists_held) h->tie_ban = 16;
+    }
     if (h->h_state->status == kStatusOk && h->h_state->large_seen > 0 && !h->launched_words)     // (a view whose points mostly hold thousands of neighbors: see FeatDesc::all_large == 2)
         h->all_huge_hint = (double)h->h_state->keys_needed > 1024.0 * (double)h->h_state->large_seen;
     // sorted order, what a launch that listed every point (all_large) stored per point: between what the register lists hold and
@@ -666,18 +680,23 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
             feat.words = words_for(h);
         }
     }
-    // sorted order, 125 .. ~200 neighbors per point on average: through the word lists (sorted_words_kernel: 256 keys per point in
-    // the registers of eight lanes; points beyond are listed for the wave / workgroup kernels).  Entered from what an all_large
-    // launch stored per point, kept while the kernel's own sample of the mean stays in range
+    // sorted order, 100 .. ~420 neighbors per point on average: through the word lists (sorted_words_kernel: 256 or 512 positions
+    // per point, eight lanes each; points beyond, and points with equal distances, are listed for the wave / workgroup kernels).
+    // Entered from what an all_large launch stored per point, kept while the kernel's own sample of the mean stays in range.
+    // 8 x 200 k points, feature stage: K_f 190 -> 3.5 ms with 256 positions / 4.6 with 512; 230 -> 5.4 / 5.5; 275 -> 10.2 / 6.6
+    // (wave kernel: 9.1); 375 -> 8.3 (11.3); 490 -> 23.4 (21.5)
     bool words_mode = false;
     if (feat.sorted) {
         const bool sized_alike = h->all_large_n > 0 && (long long)n * 4 >= (long long)h->all_large_n * 3 && (long long)n * 3 <= (long long)h->all_large_n * 4;
         const bool stay = h->launched_words && h->lcap_hint_radius == h->prm.radius_search && sized_alike && kf_hint_fits(h, n) &&
-                          h->kf_hint >= 95.0 && h->kf_hint <= 215.0;
+                          h->kf_hint >= 95.0 && h->kf_hint <= kWordsStayBelow;
         if (h->launched_words && !stay && kf_hint_fits(h, n)) h->words_mean_keys = h->kf_hint;      // (the fresher figure decides about coming back)
-        const bool enter = feat.all_large == 1 && h->words_mean_keys >= 100.0 && h->words_mean_keys <= 205.0;
-        words_mode = enter || stay;
-        if (getenv("KPL_FORCE_WORDS")) { words_mode = true; if (h->words_mean_keys < 0) h->words_mean_keys = atof(getenv("KPL_FORCE_WORDS")); }
+        const bool enter = feat.all_large == 1 && h->words_mean_keys >= 100.0 && h->words_mean_keys <= kWordsEnterBelow;
+        words_mode = (enter || stay) && h->tie_ban == 0;
+        if (h->tie_ban > 0) {
+            feat.all_large = feat.all_large == 2 ? 2 : 1;
+            --h->tie_ban;
+        }
     }
     if (words_mode) {
         const double mean = h->launched_words && kf_hint_fits(h, n) ? h->kf_hint : h->words_mean_keys;
@@ -693,13 +712,16 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
         }
     }
     if (words_mode) {
+        const double mean = h->launched_words && kf_hint_fits(h, n) ? h->kf_hint : h->words_mean_keys;
         feat.walk = 1;
-        feat.lanes = getenv("KPL_WORDS_LANES") ? atoi(getenv("KPL_WORDS_LANES")) : 8;
+        feat.lanes = 8;
+        feat.lcap = mean <= kWords256BelowKf ? 256 : 512;
         feat.all_large = 0;
         KPL_HIP(h, h->wseg_start.ensure(sizeof(unsigned) * nn, st, h->parked));
         KPL_HIP(h, h->wseg_len.ensure(sizeof(int) * nn, st, h->parked));
     }
     h->launched_words = words_mode;
+    h->launched_words_lcap = words_mode ? feat.lcap : 0;
     v.words = words_mode ? h->words.as<uint2>() : nullptr;
     v.word_cap = words_mode ? h->words.cap / sizeof(uint2) : 0;
     if (v.word_cap > 0xfffffff0ull) v.word_cap = 0xfffffff0ull;
@@ -708,8 +730,9 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
     h->last_walk = feat.sorted ? (words_mode ? 1 : -1) : feat.walk;
     h->last_lanes = feat.sorted ? (words_mode ? feat.lanes : 0) : feat.lanes;
     h->last_words = (!feat.sorted && feat.walk == 0) ? (feat.words > 0 ? feat.words : 24) : 0;
-    h->last_lcap = feat.sorted ? (words_mode ? 256 : feat.lcap > 0 ? feat.lcap : 128) : 0;
+    h->last_lcap = feat.sorted ? (feat.lcap > 0 ? feat.lcap : 128) : 0;
     h->launched_all_large = feat.sorted ? feat.all_large : 0;
+    h->launched_sorted = feat.sorted != 0;
     if (!feat.sorted && feat.walk == 1) {
         KPL_HIP(h, h->seg_start.ensure(sizeof(unsigned) * nn, st, h->parked));
         KPL_HIP(h, h->seg_len.ensure(sizeof(int) * nn, st, h->parked));

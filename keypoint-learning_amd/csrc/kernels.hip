@@ -2026,7 +2026,7 @@ template <int G, int E>
 __device__ __forceinline__ bool sort_position_lists(unsigned *tl, int lcap, const float4 *__restrict__ pts, const float4 &p, int pi,
                                                     int gq, int cnt, float r2, unsigned group_shift) {
     constexpr int kPts = kLanes / G;
-    constexpr int SB = G * E == 64 ? 6 : G * E == 128 ? 7 : 8;
+    constexpr int SB = G * E == 64 ? 6 : G * E == 128 ? 7 : G * E == 256 ? 8 : 9;
     static_assert((1 << SB) == G * E, "slot bits");
     constexpr unsigned kQEnd = 1u << (31 - SB);
     const float scale = pin_f((float)kQEnd * 0.999f / r2);
@@ -2200,13 +2200,13 @@ __device__ __forceinline__ FeatDesc pinned_feat(const FeatDesc &fin) {
     return f;
 }
 
-template <int G>
+template <int G, int EMAX>
 __device__ __forceinline__ int point_features_sorted_words(const float4 *__restrict__ pts, const char *__restrict__ nrmsrc, unsigned ns,
                                                            const FeatDesc &fin, float4 p, float4 np, float *H,
                                                            unsigned *tl, const uint2 *__restrict__ list, int stride,
                                                            int ecnt, bool &deferred) {
-    static_assert(G == 8 || G == 4, "eight lanes per point (up to 256 neighbors), or four (up to 128)");
-    constexpr int kPts = kLanes / G, lcap = 32 * G;
+    static_assert(G == 8 && (EMAX == 32 || EMAX == 64), "eight lanes per point: up to 256 neighbors, or 512");
+    constexpr int kPts = kLanes / G, lcap = EMAX * G;
     const int tid = threadIdx.x, pi = tid / G, gq = tid % G;
     const FeatDesc f = pinned_feat(fin);
     for (int c = gq; c < f.F; c += G) H[c * kPts + pi] = 0.0f;                     // hpp:325
@@ -2225,8 +2225,10 @@ __device__ __forceinline__ int point_features_sorted_words(const float4 *__restr
     }
     // ---- sort: 32 G stand-ins, or half of that when no list of the wave holds more
     {
-        const bool tie = __all(cnt <= 16 * G) ? sort_position_lists<G, 16>(tl, lcap, pts, p, pi, gq, cnt, f.r2, group_shift)
-                                              : sort_position_lists<G, 32>(tl, lcap, pts, p, pi, gq, cnt, f.r2, group_shift);
+        bool tie;
+        if (__all(cnt <= 16 * G)) tie = sort_position_lists<G, 16>(tl, lcap, pts, p, pi, gq, cnt, f.r2, group_shift);
+        else if (EMAX == 32 || __all(cnt <= 32 * G)) tie = sort_position_lists<G, 32>(tl, lcap, pts, p, pi, gq, cnt, f.r2, group_shift);
+        else tie = sort_position_lists<G, EMAX>(tl, lcap, pts, p, pi, gq, cnt, f.r2, group_shift);
         if (tie & (cnt > 1)) {         // equal or almost equal distances: the 64-bit keys order them (the wave kernel)
             deferred = true;
             cnt = 0;
@@ -2964,13 +2966,13 @@ __global__ __launch_bounds__(kLanes) void feature_sorted_kernel(Batch b, int max
 
 // sorted order through the word lists (point_features_sorted_words): kWordsGroup lanes per point, 8 points per wave
 //   LDS: [H: maxF x 8 floats][position lists: kWordsKeys x 8 positions]
-template <bool STATS, int G>
+template <bool STATS, int EMAX>
 __global__ __launch_bounds__(kLanes) void sorted_words_kernel(Batch b, int maxF, int by_xcd) {
     extern __shared__ float H[];
-    constexpr int kPts = kLanes / G;
+    constexpr int G = kWordsGroup, kPts = kLanes / G;
     const ViewBlock vb = view_block(by_xcd);
     const ViewDev &v = b.view[vb.view];
-    if (!v.f.sorted || v.f.walk != kWalkTwoPass || v.f.lanes != G) return;
+    if (!v.f.sorted || v.f.walk != kWalkTwoPass || (v.f.lcap > 32 * G ? 64 : 32) != EMAX) return;
     const int chunk = vb.bx / G, pi = threadIdx.x / G, gq = threadIdx.x % G;
     const int col = (vb.bx % G) * kPts + pi;
     if (chunk * kLanes + col - pi >= v.n) return;
@@ -2979,7 +2981,7 @@ __global__ __launch_bounds__(kLanes) void sorted_words_kernel(Batch b, int maxF,
     const int ecnt = w.scoreable ? v.wseg_len[w.s] : 0;
     const uint2 *list = v.words + (w.scoreable ? v.wseg_start[w.s] : 0u);
     bool deferred = false;
-    const int kf = point_features_sorted_words<G>(v.pts, v.nrmsrc, v.ns, v.f, w.p, w.np, H, tl, list, kLanes / kSearchGroup, ecnt, deferred);
+    const int kf = point_features_sorted_words<G, EMAX>(v.pts, v.nrmsrc, v.ns, v.f, w.p, w.np, H, tl, list, kLanes / kSearchGroup, ecnt, deferred);
     // a point whose list ran full: for the wave-per-point kernel (and the workgroup kernel behind it), as in feature_sorted_kernel
     const unsigned long long lbal = __ballot(deferred && gq == 0);
     if (lbal != 0ull) {
@@ -5180,21 +5182,20 @@ void launch_feature_stage(const Batch &b, hipStream_t st) {
             const dim3 sgrid(div_up(n, kLanes) * kSearchGroup, b.nviews);
             if (stats) feature_search_kernel<true><<<sgrid, kLanes, 0, st>>>(b, 1);
             else feature_search_kernel<false><<<sgrid, kLanes, 0, st>>>(b, 1);
-            // (positions and histograms of a wave's points take the same LDS with eight and with four lanes per point)
-            const size_t wlds = (sizeof(float) * (size_t)maxF + sizeof(unsigned) * (size_t)kWordsKeys) * (size_t)(kLanes / kWordsGroup);
-            const size_t wlds4 = (sizeof(float) * (size_t)maxF + sizeof(unsigned) * (size_t)(kWordsKeys / 2)) * (size_t)(kLanes / 4);
-            bool w8 = false, w4 = false;
+            // (FeatDesc::lcap of such a view: 256 positions per point, or 512 -- twice the LDS, half the waves per CU)
+            bool w256 = false, w512 = false;
             for (int v = 0; v < b.nviews; ++v)
-                if (b.view[v].f.sorted && b.view[v].f.walk == kWalkTwoPass) (b.view[v].f.lanes == 4 ? w4 : w8) = true;
-            if (w8) {
-                const dim3 wgrid(div_up(n, kLanes) * kWordsGroup, b.nviews);
-                if (stats) sorted_words_kernel<true, kWordsGroup><<<wgrid, kLanes, wlds, st>>>(b, maxF, by_xcd);
-                else sorted_words_kernel<false, kWordsGroup><<<wgrid, kLanes, wlds, st>>>(b, maxF, by_xcd);
+                if (b.view[v].f.sorted && b.view[v].f.walk == kWalkTwoPass) (b.view[v].f.lcap > kWordsKeys ? w512 : w256) = true;
+            const dim3 wgrid(div_up(n, kLanes) * kWordsGroup, b.nviews);
+            if (w256) {
+                const size_t wlds = (sizeof(float) * (size_t)maxF + sizeof(unsigned) * (size_t)kWordsKeys) * (size_t)(kLanes / kWordsGroup);
+                if (stats) sorted_words_kernel<true, 32><<<wgrid, kLanes, wlds, st>>>(b, maxF, by_xcd);
+                else sorted_words_kernel<false, 32><<<wgrid, kLanes, wlds, st>>>(b, maxF, by_xcd);
             }
-            if (w4) {
-                const dim3 wgrid(div_up(n, kLanes) * 4, b.nviews);
-                if (stats) sorted_words_kernel<true, 4><<<wgrid, kLanes, wlds4, st>>>(b, maxF, by_xcd);
-                else sorted_words_kernel<false, 4><<<wgrid, kLanes, wlds4, st>>>(b, maxF, by_xcd);
+            if (w512) {
+                const size_t wlds = (sizeof(float) * (size_t)maxF + sizeof(unsigned) * (size_t)(2 * kWordsKeys)) * (size_t)(kLanes / kWordsGroup);
+                if (stats) sorted_words_kernel<true, 64><<<wgrid, kLanes, wlds, st>>>(b, maxF, by_xcd);
+                else sorted_words_kernel<false, 64><<<wgrid, kLanes, wlds, st>>>(b, maxF, by_xcd);
             }
         }
         // persistent: as many workgroups of four waves as are resident at once (every wave takes the same share of the list:

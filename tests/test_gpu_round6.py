@@ -25,7 +25,8 @@ def test_sorted_mode_hints_follow_a_stream_that_goes_from_dense_to_sparse(kpl, o
     A, B = 5, 6
     dense, nrm = cases.cloud(120, 100, seed=3)
     mr = oracle.cloud_resolution(dense)
-    r, rn, thr = float(np.float32(10.5 * mr)), float(np.float32(4 * mr)), float(np.float32(0.5))
+    # (dense: ~500 neighbors per point -- beyond what the word lists take, see the next test)
+    r, rn, thr = float(np.float32(17.0 * mr)), float(np.float32(4 * mr)), float(np.float32(0.5))
     sparse = np.ascontiguousarray(dense * np.float32([3.0, 3.0, 1.0]))       # the same points, a ninth of the density
     det = _det(kpl, cases, A, B, r, rn, thr, True)
     of = cases.oracle_forest(cases.trained_forest(A, B))
@@ -45,6 +46,33 @@ def test_sorted_mode_hints_follow_a_stream_that_goes_from_dense_to_sparse(kpl, o
     assert record[5][1] == 0 and record[6][1] == 0, record   # ... the later ones do not
     assert record[6][2] < 128, record                    # and the list capacity follows what the register sort measured again
     assert record[9][1] == 1, record                     # dense again: back to the wave / workgroup kernels
+
+
+def test_sorted_mode_takes_the_kernel_that_fits_the_neighborhoods(kpl, oracle, cases):
+    """one handle, three radii: ~60 neighbors per point -> the register / position lists of feature_sorted_kernel; ~150 -> the word
+    lists with 256 positions per point; ~300 -> with 512.  Every call bit-exact, the third call at a radius in its mode."""
+    A, B = 5, 6
+    xyz, nrm = cases.cloud(120, 100, seed=4)
+    mr = oracle.cloud_resolution(xyz)
+    det = _det(kpl, cases, A, B, 1.0, 0.0, 0.5, True)
+    det.setNonMaxima(False)
+    of = cases.oracle_forest(cases.trained_forest(A, B))
+    seen = {}
+    for rmul in (5.5, 9.0, 12.5, 5.5):
+        r = float(np.float32(rmul * mr))
+        det.setRadiusSearch(r)
+        want = oracle.detect(xyz, nrm, A, B, r, 0.0, float(np.float32(0.5)), of, non_maxima=False, order=oracle.ORDER_SORTED,
+                             threads=cases.usable_cores())[0]
+        for k in range(3):
+            det.setInputCloud(xyz)
+            det.setNormals(nrm)
+            _, scores = det.compute()
+            assert cases.same_bits(scores, want), (rmul, k)
+        ll = det.getLastLaunch()
+        seen[rmul] = (ll["walk"], ll["sorted_list_keys"], ll["sorted_all_large"])
+    assert seen[5.5][0] == -1 and seen[5.5][1] <= 128 and seen[5.5][2] == 0, seen
+    assert seen[9.0] == (1, 256, 0), seen
+    assert seen[12.5] == (1, 512, 0), seen
 
 
 def test_reserve_sizes_a_handle_before_its_first_call(kpl, oracle, cases):

@@ -51,3 +51,25 @@ def test_a_radius_whose_scale_overflows(kpl, oracle, cases):
     assert cases.same_bits(det.computePointsForTrainingFeatures(q), want)
     kf = _score_both_ways(kpl, oracle, cases, xyz, nrm, 5, 6, r, 22)
     assert kf > 30, kf
+
+
+def test_a_stream_of_lattice_views_goes_straight_to_the_exact_kernels(kpl, oracle, cases):
+    """every neighborhood of a lattice holds equal distances: the kernels that sort by stand-ins hand every point on.  The
+    handle notices (most points listed although their lists held them) and lists every point at once for the next launches."""
+    from tests.test_oracle_sorted import lattice
+    from tools import synth
+    xyz, nrm = lattice(40, 36, dup=40)
+    r = 3.3
+    fa = synth.random_forest(30, ntrees=6, max_depth=8, seed=5, target_nodes_per_tree=120)
+    det = make_det(kpl, 5, 6, r, 0.0, 0.0, fa)
+    det.setNonMaxima(False)
+    want, _ = oracle.detect(xyz, nrm, 5, 6, r, 0.0, 0.0, cases.oracle_forest(fa), non_maxima=False, order=oracle.ORDER_SORTED,
+                            threads=cases.usable_cores())
+    record = []
+    for k in range(5):
+        det.setInputCloud(xyz)
+        det.setNormals(nrm)
+        _, scores = det.compute()
+        assert cases.same_bits(scores, want), k
+        record.append(det.getLastLaunch()["sorted_all_large"])
+    assert 0 in record[:2] and record[2:] == [1, 1, 1], record
