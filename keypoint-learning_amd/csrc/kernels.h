@@ -41,11 +41,12 @@ struct FeatDesc {
     int sorted;      // neighbor order of the feature loop: 0 = canonical (cell id, index), 1 = ascending (d2, index)
     // how the canonical order is walked -- never WHAT is computed: every combination gives the same bits (kernels.hip)
     int walk;        // 0: search and drain alternate, accept words in LDS (point_features); 1: two passes, the accept words of the whole walk through global memory (large neighborhoods).
-                     // sorted order with walk = 1 ("sorted words", 125 .. ~250 neighbors per point): the same search pass (no neighbor dropped), then
-                     // sorted_words_kernel -- eight lanes per point collect the keys out of the point's word list, sort 256 of them in registers and add
-    int lanes;       // lanes per point: 2 or 4
+                     // sorted order with walk = 1 ("sorted words", ~100 .. ~420 neighbors per point): the same search pass (no neighbor dropped), then
+                     // sorted_words_kernel -- eight lanes per point expand the point's word list into positions, sort them through 32-bit
+                     // stand-ins in registers and add in order
+    int lanes;       // lanes per point: 2 or 4 (sorted words: 8)
     int words;       // one-kernel walk: accept words a point collects between two drains (0 = 24; fewer for small neighborhoods, kernels.hip accept_words)
-    int lcap;        // sorted-search mode: keys per point of the register-sort kernel's lists in LDS (<= 128; 0 = 128)
+    int lcap;        // sorted-search mode: positions per point of feature_sorted_kernel's lists in LDS (<= 128; 0 = 128); sorted words: 256 or 512
     int all_large;   // sorted-search mode: every point goes to the collect / add kernels without trying the register sort first
                      // (the handle's last call listed nearly all of them anyway -- after searching for most)
 };

@@ -1460,12 +1460,21 @@ __device__ __forceinline__ void drain_point_words(const float4 *__restrict__ pts
 // that is defined without FLANN's tree layout, i.e. the one order in which this engine can be compared bit for
 // bit with a PCL run.  The neighbor SET is the canonical mode's; only the order of the float additions differs.
 //
-// kSortGroup = 4 lanes per point, 16 points per wave.  Per wave and pass:
+// Who scores a point (the handle picks per view from what its last launches measured, api.cpp: prepare_detect):
+//   up to ~124 neighbors      feature_sorted_kernel (point_features_sorted_view): kSortGroup = 4 lanes per point, 16 points
+//                             per wave -- its own search, positions, 32-bit stand-ins, ordered adds
+//   ~100 .. ~420 on average   feature_search_kernel + sorted_words_kernel (point_features_sorted_words): 8 lanes per point,
+//                             256 or 512 positions
+//   beyond, and every point whose order the stand-ins do not decide (equal distances)
+//                             sorted_collect_wave_kernel (up to 512 keys, a wave per point) / sorted_collect_kernel (a
+//                             workgroup per point) -> 64-bit keys (d2 bits << 32 | original index: d2 >= +0, so the unsigned
+//                             order of the keys IS ascending (d2, index)) in global memory -> sorted_add_kernel
+//   sparse queries            features_sorted_kernel (point_features_sorted): 64-bit keys in LDS, in windows of d2
+// point_features_sorted, per wave and pass:
 //   search   as in point_features: accept words of 32 candidates -> the point's small word list in LDS
-//   collect  every accepted neighbor's key (d2 bits << 32 | original index: d2 >= +0, so the unsigned order of
-//            the keys IS ascending (d2, index)) -> the point's key list in LDS, lcap keys per point
-//   sort     bitonic network over the key lists IN REGISTERS (sort_key_lists): lane g of the group holds a
-//            quarter of the list, comparators across lanes go through DPP
+//   collect  every accepted neighbor's key -> the point's key list in LDS, lcap keys per point
+//   sort     bitonic network over the lists IN REGISTERS (sort_key_lists): lane g of the group holds a quarter of the
+//            list, comparators across lanes go through DPP
 //   add      the keys in order, 4 per round: normal of the neighbor from the caller's array (by original
 //            index), contribution from the d2 in the key, the 4 histogram updates lane after lane (hpp:350-355)
 // A neighborhood with more than lcap points takes several passes, each over a window [lo, hi) of keys: when a
@@ -1805,14 +1814,12 @@ __device__ __forceinline__ int keep_keys_below(unsigned long long *keys, int pi,
     return out;
 }
 
-// DEFER (the kernel over whole views): a point whose list runs full is not cut into windows here -- it takes no further
-// part, `deferred` comes back true and the caller hands it to the kernels for large neighborhoods (one search wasted, none
-// repeated).  Without DEFER (the sparse query kernel, which has no such kernels behind it) the windows below do the work.
-template <int G, bool DEFER>
+// (the sparse query kernel: no wave / workgroup kernels behind it -- a list that runs full is cut into windows)
+template <int G>
 __device__ __forceinline__ int point_features_sorted(const float4 *__restrict__ pts, const char *__restrict__ nrmsrc,
                                                      unsigned ns, const int *__restrict__ cell_start, const GridDesc &g,
                                                      const FeatDesc &fin, float4 p, float4 np, float *H, uint2 *ent, int ecap,
-                                                     unsigned long long *keys, int lcap, bool active, bool &deferred) {
+                                                     unsigned long long *keys, int lcap, bool active) {
     constexpr int kPts = kLanes / G;
     const int tid = threadIdx.x, pi = tid / G, gq = tid % G;
     FeatDesc f;
@@ -1842,7 +1849,6 @@ __device__ __forceinline__ int point_features_sorted(const float4 *__restrict__ 
     // still ends with ALL keys of [lo, hi), and the next pass takes [hi, key_end).
     unsigned long long lo = 0ull, hi = key_end;
     bool dropped = false;                          // hpp:336: element 0 of the whole order has been dropped
-    deferred = false;
     int kf = 0;
     for (int pass = 0;; ++pass) {
         int cnt = 0;                               // keys in the point's list (the same in the lanes of the group)
@@ -1887,16 +1893,8 @@ __device__ __forceinline__ int point_features_sorted(const float4 *__restrict__ 
                     slot.q = pts[tt];
                 };
                 auto collect = [&](Taken &now) {
-                    if (DEFER) {           // no room for the keys of this round: the point leaves (its list is not used any more)
-                        if (cnt > lcap - G) {
-                            deferred = true;
-                            cnt = 0;
-                            rs.ny = 0;             // its rows are over: it does not hold up the others' walk any more
-                            rs.t1 = rs.t;
-                        }
-                    }
                     // room for the G keys of this round in every list, else: a pivot inside the window, the list filtered
-                    while (!DEFER && __any(cnt > lcap - G)) {
+                    while (__any(cnt > lcap - G)) {
                         if (cnt > lcap - G) {
                             const unsigned lb = (unsigned)(lo >> 32), hb = (unsigned)(hi >> 32);
                             if (hb - lb >= 2u) {           // halve the window in d2 (its values, not its bits: even counts on a surface)
@@ -1912,8 +1910,7 @@ __device__ __forceinline__ int point_features_sorted(const float4 *__restrict__ 
                     }
                     const unsigned long long key = ((unsigned long long)__float_as_uint(dist2(p.x, p.y, p.z, now.q)) << 32) |
                                                    (unsigned long long)(unsigned)__float_as_int(now.q.w);
-                    // (DEFER: one pass over the whole window [0, key_end), and every accepted key is inside it)
-                    const bool app = DEFER ? now.valid & !deferred : now.valid & (key >= lo) & (key < hi);
+                    const bool app = now.valid & (key >= lo) & (key < hi);
                     const unsigned gb = (unsigned)(__ballot(app) >> group_shift) & ((1u << G) - 1u);
                     if (app) keys[(cnt + __popc(gb & ((1u << gq) - 1u))) * kPts + pi] = key;
                     cnt += __popc(gb);
@@ -1930,7 +1927,6 @@ __device__ __forceinline__ int point_features_sorted(const float4 *__restrict__ 
                 } while (__any((w != 0u) | (e < ecnt) | pa.valid | pb.valid));
             }
             if (rs.exhausted()) break;
-            if (DEFER && !__any(active && !deferred)) break;           // every point of the wave has left for the large path
         }
         // ---- sort the lists (the one place where the network is instantiated)
         if (lcap <= kSortedListKeys / 2) sort_key_lists<G, kSortedListKeys / G / 2>(keys, pi, gq, cnt, f.r2);     // (uniform)
@@ -1976,7 +1972,7 @@ __device__ __forceinline__ int point_features_sorted(const float4 *__restrict__ 
             } while (__any((k - G < cnt) | pa.valid | pb.valid));
 #undef KPL_SORTED_ROUND
         }
-        if (DEFER || !__any(hi != key_end)) break;
+        if (!__any(hi != key_end)) break;
         // the next pass: the keys from the pivot on; a point whose window was never cut is done (an empty window)
         lo = hi != key_end ? hi : key_end;
         hi = key_end;
@@ -2771,7 +2767,7 @@ __device__ __forceinline__ ViewBlock view_block(int by_xcd) {
 // being searched here first.  A cheap test on the index alone -- the population of the point's own cell (one pair of
 // cell_start[] entries): the box of a point holds about nine such cells on a surface, so more than kLargeCell points in the
 // cell are about 170 neighbors or more, where the register sort of 128 keys is at its end.  The test only has to be
-// roughly right: a point it lets through whose list runs full is deferred to the same kernels (DEFER below).  (Summing
+// roughly right: a point it lets through whose list runs full is deferred to the same kernels (point_features_sorted_view).  (Summing
 // the candidates of the whole box -- 32 dependent loads per lane in a kernel with two waves per SIMD -- cost 7 % of the
 // stage on views that have no large point at all.)
 // A cell with more than kHugeCell points (~530 neighbors) is beyond what a wave sorts (kWaveKeys): such a point is listed for
@@ -3252,8 +3248,7 @@ __global__ __launch_bounds__(kLanes) void features_sorted_kernel(QueryBatch qb, 
     }
     const float4 p = s >= 0 ? q.pts[s] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 np = s >= 0 ? q.nrm[s] : make_float4(0.f, 0.f, 0.f, 0.f);
-    bool deferred_unused;
-    point_features_sorted<G, false>(q.pts, q.nrmsrc, q.ns, q.cell_start, g, q.f, p, np, H, ent, ecap, keys, lcap, s >= 0, deferred_unused);
+    point_features_sorted<G>(q.pts, q.nrmsrc, q.ns, q.cell_start, g, q.f, p, np, H, ent, ecap, keys, lcap, s >= 0);
     if (qi >= q.m) return;
     float *o = q.out + (size_t)qi * q.f.F;
     for (int c = gq; c < q.f.F; c += G) o[c] = s >= 0 ? H[c * kPts + pi] : NAN;
@@ -3266,7 +3261,7 @@ __global__ __launch_bounds__(kLanes) void features_sorted_kernel(QueryBatch qb, 
 // per point there (46 ms per 63 k-point view against 1.8 ms in the canonical order).  Points in crowded cells (own_cell_population > kLargeCell)
 // and points whose register list ran full take three kernels instead:
 //   feature_sorted_kernel  lists them instead of scoring them (DevState::large_count, ViewDev::large_list), and with them
-//                          the points whose register list ran full (DEFER)
+//                          the points whose list ran full, or whose order the stand-ins do not decide
 //   sorted_collect_kernel  ONE WORKGROUP PER POINT: its 256 threads walk the rows of the box together -- consecutive
 //                          storage positions, coalesced 16-byte loads, no lock step with other points --, the accepted
 //                          neighbors' keys (d2 bits << 32 | original index) go to a list in LDS, the list is sorted there
