@@ -88,10 +88,11 @@ typedef struct kpl_params {
  *              pcl::search::KdTree constructed with sorted = true to setSearchMethod (FLANN sorts its radius
  *              result set by (distance, index)).  Element 0 is then the query itself (or a duplicate of it with a
  *              lower index).  This is the order in which results can be compared bit for bit with a PCL build of
- *              the reference.  Cost against CANONICAL (round 6): ~3.1x at 70 neighbors per point
- *              (per-point sort in the registers of four lanes), 3.9-4.7x between 125 and 512 (word lists + eight lanes
- *              per point up to ~250 keys, a wave per point beyond), ~2.5x at the ~2 300 of the reference's default radius
- *              (a workgroup per point). */
+ *              the reference.  Cost against CANONICAL (round 6): 2.1-2.4x up to ~125 neighbors per
+ *              point, 2.5-3.3x between ~100 and ~420 (word lists, eight lanes per point), ~5x around 500 (a wave / a
+ *              workgroup per point), ~2.3x at the ~2 300 of the reference's default radius.  The order of a point's
+ *              neighbors is decided by 32-bit stand-ins of their (distance, index) keys wherever those differ, by the
+ *              64-bit keys themselves where distances are equal or almost equal -- the same order either way. */
 enum { KPL_NEIGHBORS_CANONICAL = 0, KPL_NEIGHBORS_SORTED = 1 };
 
 /* How the feature kernels WALK the canonical order (never what they compute: every choice gives the same bits --
@@ -116,12 +117,12 @@ int kpl_get_feature_walk(const kpl_detector *h, int *walk, int *lanes_per_point,
 /* What the handle's LAST scoring launch took -- a plain read of the handle, no wait, nothing cleared (kpl_get_timing, which
  * carries the same three walk fields, waits for its events and clears the recorded times). */
 typedef struct kpl_launch_info {
-    int walk;               /* KPL_WALK_LANES / KPL_WALK_TWO_PASS; -1: sorted order (register lists / wave / workgroup kernels), or no
+    int walk;               /* KPL_WALK_LANES / KPL_WALK_TWO_PASS; -1: sorted order (per-point lists / wave / workgroup kernels), or no
                                call yet; sorted order with KPL_WALK_TWO_PASS: through the word lists, eight lanes per point   */
     int lanes_per_point;
     int accept_words;       /* KPL_WALK_LANES: accept words a point collected between two drains (24 / 20 / 16 / 12)      */
-    int sorted_list_keys;   /* sorted order: keys per point of the register-sort lists (128, or what the handle measured; 256
-                               through the word lists)                                                                  */
+    int sorted_list_keys;   /* sorted order: neighbors per point the lists of the launch held (128, or what the handle measured;
+                               256 or 512 through the word lists)                                                       */
     int sorted_all_large;   /* sorted order: 1 = every point went straight to the wave / workgroup-per-point kernels      */
 } kpl_launch_info;
 int kpl_get_last_launch(const kpl_detector *h, kpl_launch_info *out);
