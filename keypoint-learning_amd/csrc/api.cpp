@@ -332,7 +332,7 @@ void choose_walk(const kpl_detector *h, FeatDesc &f) {
 }
 // sorted order through the word lists: mean neighbors per point up to which a view enters / stays, and up to which 256 positions
 // per point are the better choice (beyond: 512)
-constexpr double kWordsEnterBelow = 410.0, kWordsStayBelow = 430.0, kWords256BelowKf = 225.0;
+constexpr double kWordsEnterBelow = 455.0, kWordsStayBelow = 475.0, kWords256BelowKf = 225.0;
 static_assert(kWords12BelowKf == 80.0 && kWords16BelowKf == 140.0 && kWords20BelowKf == 175.0, "words_for() spells these out");
 
 NmsDesc make_nms(const kpl_params &p) {
@@ -680,11 +680,11 @@ int prepare_detect(kpl_detector *h, float *d_scores, int *d_kp_idx, int kp_cap, 
             feat.words = words_for(h);
         }
     }
-    // sorted order, 100 .. ~420 neighbors per point on average: through the word lists (sorted_words_kernel: 256 or 512 positions
+    // sorted order, 100 .. ~460 neighbors per point on average: through the word lists (sorted_words_kernel: 256 or 512 positions
     // per point, eight lanes each; points beyond, and points with equal distances, are listed for the wave / workgroup kernels).
     // Entered from what an all_large launch stored per point, kept while the kernel's own sample of the mean stays in range.
     // 8 x 200 k points, feature stage: K_f 190 -> 3.5 ms with 256 positions / 4.6 with 512; 230 -> 5.4 / 5.5; 275 -> 10.2 / 6.6
-    // (wave kernel: 9.1); 375 -> 8.3 (11.3); 490 -> 23.4 (21.5)
+    // (wave kernel: 9.1); 375 -> 8.3 (11.3); 430 -> 9.2 (12.8); 460 -> 13.4; 490 -> 23.2 (21.4)
     bool words_mode = false;
     if (feat.sorted) {
         const bool sized_alike = h->all_large_n > 0 && (long long)n * 4 >= (long long)h->all_large_n * 3 && (long long)n * 3 <= (long long)h->all_large_n * 4;
