@@ -89,7 +89,7 @@ typedef struct kpl_params {
  *              result set by (distance, index)).  Element 0 is then the query itself (or a duplicate of it with a
  *              lower index).  This is the order in which results can be compared bit for bit with a PCL build of
  *              the reference.  Cost against CANONICAL (round 6): 2.1-2.4x up to ~125 neighbors per
- *              point, 2.5-3.3x between ~100 and ~420 (word lists, eight lanes per point), ~5x around 500 (a wave / a
+ *              point, 2.5-3.4x between ~100 and ~460 (word lists, eight lanes per point), ~5x around 500 (a wave / a
  *              workgroup per point), ~2.3x at the ~2 300 of the reference's default radius.  The order of a point's
  *              neighbors is decided by 32-bit stand-ins of their (distance, index) keys wherever those differ, by the
  *              64-bit keys themselves where distances are equal or almost equal -- the same order either way. */

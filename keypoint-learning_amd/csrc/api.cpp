@@ -332,7 +332,9 @@ void choose_walk(const kpl_detector *h, FeatDesc &f) {
 }
 // sorted order through the word lists: mean neighbors per point up to which a view enters / stays, and up to which 256 positions
 // per point are the better choice (beyond: 512)
-constexpr double kWordsEnterBelow = 455.0, kWordsStayBelow = 475.0, kWords256BelowKf = 225.0;
+// (what decides about entering is the keys an all_large launch STORED per listed point, chunk tails included: 400 at a true
+// mean of 375, 482 at 430, 490 at 460, 501 at 490 -- what decides about staying is the sampled mean itself)
+constexpr double kWordsEnterBelow = 495.0, kWordsStayBelow = 480.0, kWords256BelowKf = 225.0;
 static_assert(kWords12BelowKf == 80.0 && kWords16BelowKf == 140.0 && kWords20BelowKf == 175.0, "words_for() spells these out");
 
 NmsDesc make_nms(const kpl_params &p) {
