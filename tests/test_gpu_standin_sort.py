@@ -73,3 +73,28 @@ def test_a_stream_of_lattice_views_goes_straight_to_the_exact_kernels(kpl, oracl
         assert cases.same_bits(scores, want), k
         record.append(det.getLastLaunch()["sorted_all_large"])
     assert 0 in record[:2] and record[2:] == [1, 1, 1], record
+
+
+@pytest.mark.parametrize("A,B", [(8, 10), (1, 1), (15, 17), (3, 2)])
+@pytest.mark.parametrize("rmul,mode", [(5.0, (-1, 0)), (9.0, (1, 256)), (12.5, (1, 512))])
+def test_histogram_shapes_through_every_sorted_kernel(kpl, oracle, cases, A, B, rmul, mode):
+    """whole views (compute(), four calls on one handle: the last ones run the kernel the handle settled on -- the position-list
+    kernel, the word lists with 256 and with 512 positions) at histogram shapes from one cell to the 255-cell limit"""
+    from tools import synth
+    xyz, nrm = synth.make_cloud(110, 90, seed=8, nan_points=7, nan_normals=9)
+    xyz, nrm = synth.shuffle_cloud(xyz, nrm, 1234)
+    r = float(np.float32(rmul * oracle.cloud_resolution(xyz)))
+    fa = synth.random_forest(A * B, ntrees=6, max_depth=8, seed=30 + A, target_nodes_per_tree=120)
+    det = make_det(kpl, A, B, r, 0.0, 0.0, fa)
+    det.setNonMaxima(False)
+    want, _ = oracle.detect(xyz, nrm, A, B, r, 0.0, 0.0, cases.oracle_forest(fa), non_maxima=False, order=oracle.ORDER_SORTED,
+                            threads=cases.usable_cores())
+    for k in range(4):
+        det.setInputCloud(xyz)
+        det.setNormals(nrm)
+        _, scores = det.compute()
+        assert cases.same_bits(scores, want), k
+    ll = det.getLastLaunch()
+    assert ll["walk"] == mode[0] and ll["sorted_all_large"] == 0, ll
+    if mode[1]:
+        assert ll["sorted_list_keys"] == mode[1], ll
