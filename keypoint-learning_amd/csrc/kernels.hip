@@ -2008,8 +2008,8 @@ __device__ __forceinline__ int point_features_sorted(const float4 *__restrict__ 
 //   sort     every lane loads the records of its 32 slots (12 bytes: xyz), d2 as everywhere -> the 32-bit stand-in
 //            q(d2) << 8 | slot (see sort_key_lists); the network KeySort32 over 8 lanes x 32 stand-ins in registers; the
 //            positions written back in that order
-//   add      G positions per round: record (xyz + original index) -> d2 again (the same arithmetic, the same bits), the
-//            normal by original index, then as point_features_sorted (hpp:334-359; element 0 dropped, hpp:336)
+//   add      G positions per round: the neighbor's records in storage order -- xyz -> d2 again (the same arithmetic, the same
+//            bits), its normal --, then as point_features_sorted (hpp:334-359; element 0 dropped, hpp:336)
 // A point with more neighbors than the list holds, or with two neighbours in the sorted stand-ins that share a q (equal or
 // almost equal distances: only the 64-bit keys (d2, index) order those), is listed for the wave / workgroup kernels like the
 // deferred points of feature_sorted_kernel.  Same keys, same order, same arithmetic: the same bits.
@@ -2094,56 +2094,48 @@ __device__ __forceinline__ void expand_words(unsigned *tl, int lcap, int pi, int
     }
 }
 
-// the feature loop (hpp:334-359) over a point's positions in sorted order, G per round; hpp:336: element 0 of the order is
-// dropped.  Position -> the neighbor's record (xyz + original index), requested four rounds ahead of its use -> d2 (the
-// arithmetic the stand-in saw: the same bits) and the normal by original index, requested two rounds ahead
+// the feature loop (hpp:334-359) over a point's positions in sorted order, G per round (element 0 of the order is
+// dropped, hpp:336).  A position names the neighbor's records in STORAGE order: xyz -> d2 again (the arithmetic the stand-in
+// saw: the same bits), and the normal as the canonical kernels read it (x = NaN where it is not finite: cell_sort_store) --
+// two 12-byte reads next to those of the point's other neighbors, requested three rounds ahead, where the 64-bit keys
+// (d2, original index) of the other kernels need a gather into the caller's normal array per neighbor.
 template <int G>
 __device__ __forceinline__ void add_sorted_positions(const unsigned *tl, int lcap, int cnt, const float4 *__restrict__ pts,
-                                                     const char *__restrict__ nrmsrc, unsigned ns, const FeatDesc &f, const float4 &p,
+                                                     const float4 *__restrict__ nrm, const FeatDesc &f, const float4 &p,
                                                      const float4 &np, int col_address, int pi, int gq) {
     constexpr int kPts = kLanes / G;
     struct Next {
         bool valid;
-        float4 q;
-        float d2;
-        f32x3 n;
+        f32x3 q, n;
     };
     int k = cnt > 0 ? 1 : 0;
-    auto request_record = [&](Next &s) {
+    auto request = [&](Next &s) {
         const int idx = k + gq;
         s.valid = idx < cnt;
         const unsigned t = tl[min(idx, lcap - 1) * kPts + pi];
         k += G;
-        s.q = pts[s.valid ? t : 0u];
+        const int tt = s.valid ? (int)t : 0;
+        s.q = ld12(pts, tt);
+        s.n = ld12(nrm, tt);
     };
-    auto request_normal = [&](Next &s) {
-        s.d2 = dist2(p.x, p.y, p.z, s.q);
-        const unsigned orig = s.valid ? (unsigned)__float_as_int(s.q.w) : 0u;
-        s.n = *reinterpret_cast<const f32x3 *>(nrmsrc + (size_t)orig * ns);
-    };
-    constexpr int kRing = 5;
-    Next sl[kRing];
+    constexpr int kAhead = 3;
+    Next sl[kAhead + 1];
 #pragma unroll
-    for (int q = 0; q < kRing; ++q) {
+    for (int q = 0; q <= kAhead; ++q) {
         sl[q].valid = false;
-        sl[q].q = make_float4(0.f, 0.f, 0.f, 0.f);
-        sl[q].d2 = 0.f;
-        sl[q].n = f32x3{0.f, 0.f, 0.f};
+        sl[q].q = sl[q].n = f32x3{0.f, 0.f, 0.f};
     }
 #pragma unroll
-    for (int q = 0; q < kRing - 1; ++q) request_record(sl[q]);
-    request_normal(sl[0]);
-    request_normal(sl[1]);
+    for (int q = 0; q < kAhead; ++q) request(sl[q]);
     bool more = true;
     while (more) {
 #pragma unroll
-        for (int q = 0; q < kRing; ++q) {
+        for (int q = 0; q <= kAhead; ++q) {
             Next &now = sl[q];
-            request_record(sl[(q + 4) % kRing]);
-            request_normal(sl[(q + 2) % kRing]);
-            const bool has_ = now.valid & finite3(now.n.x, now.n.y, now.n.z);          /* hpp:338 */
+            request(sl[(q + kAhead) % (kAhead + 1)]);
+            const bool has_ = now.valid & (now.n.x == now.n.x);                        /* hpp:338 */
             Contribution c_;
-            if (has_) c_ = neighbor_contribution<kPts>(f, now.d2, np, now.n, col_address);
+            if (has_) c_ = neighbor_contribution<kPts>(f, dist2(p.x, p.y, p.z, now.q), np, now.n, col_address);
 #pragma unroll
             for (int sub_ = 0; sub_ < G; ++sub_) {
                 if (has_ & (gq == sub_)) apply_contribution(c_, request_cells(c_));
@@ -2153,7 +2145,7 @@ __device__ __forceinline__ void add_sorted_positions(const unsigned *tl, int lca
         }
         bool pending = false;
 #pragma unroll
-        for (int q = 0; q < kRing; ++q) pending |= sl[q].valid;
+        for (int q = 0; q <= kAhead; ++q) pending |= sl[q].valid;
         more = __any(pending);
     }
 }
@@ -2197,7 +2189,7 @@ __device__ __forceinline__ FeatDesc pinned_feat(const FeatDesc &fin) {
 }
 
 template <int G, int EMAX>
-__device__ __forceinline__ int point_features_sorted_words(const float4 *__restrict__ pts, const char *__restrict__ nrmsrc, unsigned ns,
+__device__ __forceinline__ int point_features_sorted_words(const float4 *__restrict__ pts, const float4 *__restrict__ nrm,
                                                            const FeatDesc &fin, float4 p, float4 np, float *H,
                                                            unsigned *tl, const uint2 *__restrict__ list, int stride,
                                                            int ecnt, bool &deferred) {
@@ -2230,7 +2222,7 @@ __device__ __forceinline__ int point_features_sorted_words(const float4 *__restr
             cnt = 0;
         }
     }
-    add_sorted_positions<G>(tl, lcap, cnt, pts, nrmsrc, ns, f, p, np, col_address, pi, gq);
+    add_sorted_positions<G>(tl, lcap, cnt, pts, nrm, f, p, np, col_address, pi, gq);
     normalize_rows<G>(H, f, pi, gq);
     return kf;
 }
@@ -2241,7 +2233,7 @@ __device__ __forceinline__ int point_features_sorted_words(const float4 *__restr
 // ~16 waves per CU where the 64-bit key lists kept 8-10.  overflow: the list ran full (the search stops: kf is not the
 // neighborhood's size then); deferred: overflow, or an order the stand-ins do not decide -- a point for the wave / workgroup kernels.
 template <int G>
-__device__ __forceinline__ int point_features_sorted_view(const float4 *__restrict__ pts, const char *__restrict__ nrmsrc, unsigned ns,
+__device__ __forceinline__ int point_features_sorted_view(const float4 *__restrict__ pts, const float4 *__restrict__ nrm,
                                                           const int *__restrict__ cell_start, const GridDesc &g, const FeatDesc &fin,
                                                           float4 p, float4 np, float *H, uint2 *ent, int ecap, unsigned *tl, int lcap,
                                                           bool active, bool &deferred, bool &overflow) {
@@ -2299,7 +2291,7 @@ __device__ __forceinline__ int point_features_sorted_view(const float4 *__restri
             cnt = 0;
         }
     }
-    add_sorted_positions<G>(tl, lcap, cnt, pts, nrmsrc, ns, f, p, np, col_address, pi, gq);
+    add_sorted_positions<G>(tl, lcap, cnt, pts, nrm, f, p, np, col_address, pi, gq);
     normalize_rows<G>(H, f, pi, gq);
     return kf;
 }
@@ -2923,7 +2915,7 @@ __global__ __launch_bounds__(kLanes) void feature_sorted_kernel(Batch b, int max
     bool deferred = false, overflow = false;
     int kf = 0;
     if (__any(w.scoreable && !large))           // (a wave whose points are all large only lists them)
-        kf = point_features_sorted_view<G>(v.pts, v.nrmsrc, v.ns, v.cell_start, v.ds->grid, v.f, w.p, w.np, H, ent, ecap,
+        kf = point_features_sorted_view<G>(v.pts, v.nrm, v.cell_start, v.ds->grid, v.f, w.p, w.np, H, ent, ecap,
                                            tl, lcap, w.scoreable && !large, deferred, overflow);
     else
         for (int c = gq; c < v.f.F; c += G) H[c * kPts + pi] = 0.0f;      // (what a point that is not scored leaves in its column)
@@ -2977,7 +2969,7 @@ __global__ __launch_bounds__(kLanes) void sorted_words_kernel(Batch b, int maxF,
     const int ecnt = w.scoreable ? v.wseg_len[w.s] : 0;
     const uint2 *list = v.words + (w.scoreable ? v.wseg_start[w.s] : 0u);
     bool deferred = false;
-    const int kf = point_features_sorted_words<G, EMAX>(v.pts, v.nrmsrc, v.ns, v.f, w.p, w.np, H, tl, list, kLanes / kSearchGroup, ecnt, deferred);
+    const int kf = point_features_sorted_words<G, EMAX>(v.pts, v.nrm, v.f, w.p, w.np, H, tl, list, kLanes / kSearchGroup, ecnt, deferred);
     // a point whose list ran full: for the wave-per-point kernel (and the workgroup kernel behind it), as in feature_sorted_kernel
     const unsigned long long lbal = __ballot(deferred && gq == 0);
     if (lbal != 0ull) {
