@@ -1722,6 +1722,8 @@ int kpl_collect_stats(kpl_detector *h, kpl_stats *out, void *stream) {
     if (!h || !out) return KPL_ERR_INVALID_ARG;
     memset(out, 0, sizeof(*out));
     int rc = use_device(h);
+    if (!rc) rc = streams_ready(h);      // (out_kp below is also the set-up thread's: a handle used through the device entry points
+                                         //  only has not joined it yet)
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     KPL_HIP(h, h->stats.ensure(sizeof(StatsDev)));
